@@ -1,0 +1,639 @@
+/* oracle/fsm_oracle_impl.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, serial, structure-of-arrays) of the reference's
+ * rectilinear fast-sweeping eikonal solver.  This file is a "template": it is
+ * included twice by fsm_oracle.c with
+ *     REAL = float,  SFX(name) = name##_f32
+ *     REAL = double, SFX(name) = name##_f64
+ * so that both instantiations of the reference (T1 = float / double) are
+ * restated with the reference's exact arithmetic, including the promotion to
+ * double that the reference's double literals (2., 0.5, 1./3., small ...) force
+ * when T1 = float.
+ *
+ * It is NOT the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may call it, and only as the checker / the timed CPU
+ * baseline.  Every function cites the reference file:line it follows
+ * (paths relative to /root/reference).
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference.py compares this
+ * restatement bit-for-bit with the compiled, unmodified reference
+ * (oracle/_ref/libttcr_ref.so, built by oracle/Makefile from the sources under
+ * /root/reference) in the build container, and tests/test_oracle_golden.py
+ * compares it with the committed vectors in tests/golden/ (generated from that
+ * same compiled reference by tests/golden/make_golden.py).
+ */
+
+#ifndef REAL
+#error "include from fsm_oracle.c"
+#endif
+
+/* ttcr/ttcr_t.h:42-43 */
+#define FSM_SMALL 1.e-4
+#define FSM_SMALL2 (FSM_SMALL * FSM_SMALL)
+
+/* ------------------------------------------------------------------ 3D -- */
+
+/* Node coordinate as built by Grid3Drn::buildGridNodes (ttcr/Grid3Drn.h:388-399):
+ * T1 x = xmin + ni*dx with ni an unsigned 32-bit integer. */
+static REAL SFX(coord)(REAL cmin, uint32_t n, REAL d) { return cmin + n * d; }
+
+/* Grid3Drn::update_node, ttcr/Grid3Drn.h:2902-2959 */
+static void SFX(update_node3d)(REAL* T, const REAL* s, REAL dx, size_t nnx, size_t nny, size_t nnz,
+                               size_t i, size_t j, size_t k) {
+    const size_t ncx = nnx - 1, ncy = nny - 1, ncz = nnz - 1;
+    REAL a1, a2, a3, t;
+
+    if (k == 0)
+        a1 = T[((k + 1) * nny + j) * nnx + i];
+    else if (k == ncz)
+        a1 = T[((k - 1) * nny + j) * nnx + i];
+    else {
+        a1 = T[((k - 1) * nny + j) * nnx + i];
+        t = T[((k + 1) * nny + j) * nnx + i];
+        a1 = a1 < t ? a1 : t;
+    }
+
+    if (j == 0)
+        a2 = T[(k * nny + j + 1) * nnx + i];
+    else if (j == ncy)
+        a2 = T[(k * nny + j - 1) * nnx + i];
+    else {
+        a2 = T[(k * nny + j - 1) * nnx + i];
+        t = T[(k * nny + j + 1) * nnx + i];
+        a2 = a2 < t ? a2 : t;
+    }
+
+    if (i == 0)
+        a3 = T[(k * nny + j) * nnx + i + 1];
+    else if (i == ncx)
+        a3 = T[(k * nny + j) * nnx + i - 1];
+    else {
+        a3 = T[(k * nny + j) * nnx + i - 1];
+        t = T[(k * nny + j) * nnx + i + 1];
+        a3 = a3 < t ? a3 : t;
+    }
+
+    if (a1 > a2) { REAL w = a1; a1 = a2; a2 = w; }
+    if (a1 > a3) { REAL w = a1; a1 = a3; a3 = w; }
+    if (a2 > a3) { REAL w = a2; a2 = a3; a3 = w; }
+
+    const size_t n = (k * nny + j) * nnx + i;
+    REAL fh = s[n] * dx;
+
+    t = a1 + fh;
+    if (t > a2) {
+        /* double literals: evaluated in double also when REAL is float */
+        t = 0.5 * (a1 + a2 + sqrt(2. * fh * fh - (a1 - a2) * (a1 - a2)));
+        if (t > a3) {
+            t = 1. / 3. * ((a1 + a2 + a3) + sqrt(-2. * a1 * a1 + 2. * a1 * a2 - 2. * a2 * a2 +
+                                                 2. * a1 * a3 + 2. * a2 * a3 -
+                                                 2. * a3 * a3 + 3. * fh * fh));
+        }
+    }
+    if (t < T[n]) T[n] = t;
+}
+
+/* Grid3Drn::sweep, ttcr/Grid3Drn.h:2816-2899: 8 lexicographic Gauss-Seidel
+ * sweeps, k outer / j / i inner, sign order (i,j,k) = +++ -++ +-+ --+ ++- -+- +-- --- */
+static void SFX(sweep3d)(REAL* T, const REAL* s, const unsigned char* frozen, REAL dx, size_t nnx,
+                         size_t nny, size_t nnz) {
+    for (int dir = 0; dir < 8; ++dir) {
+        const int ri = dir & 1, rj = (dir >> 1) & 1, rk = (dir >> 2) & 1;
+        for (size_t kk = 0; kk < nnz; ++kk) {
+            const size_t k = rk ? nnz - 1 - kk : kk;
+            for (size_t jj = 0; jj < nny; ++jj) {
+                const size_t j = rj ? nny - 1 - jj : jj;
+                for (size_t ii = 0; ii < nnx; ++ii) {
+                    const size_t i = ri ? nnx - 1 - ii : ii;
+                    if (!frozen[(k * nny + j) * nnx + i]) SFX(update_node3d)(T, s, dx, nnx, nny, nnz, i, j, k);
+                }
+            }
+        }
+    }
+}
+
+/* Node3Dn::getDistance, ttcr/Node3Dn.h:142-144 */
+static REAL SFX(dist3d)(REAL x, REAL y, REAL z, REAL px, REAL py, REAL pz) {
+    return (REAL)sqrt((x - px) * (x - px) + (y - py) * (y - py) + (z - pz) * (z - pz));
+}
+
+/* Grid3Drn::getCellNo, ttcr/Grid3Drn.h:207-215, followed by the decomposition of
+ * the flat cell number done in initFSM (:3530-3534); both in the reference's
+ * unsigned 32-bit arithmetic. */
+static void SFX(cell3d)(const SFX(fsm_grid3d) * g, REAL px, REAL py, REAL pz, ptrdiff_t* ci,
+                        ptrdiff_t* cj, ptrdiff_t* ck) {
+    const uint32_t ncx = (uint32_t)(g->nnx - 1), ncy = (uint32_t)(g->nny - 1);
+    REAL x = g->xmax - px < FSM_SMALL2 ? (REAL)(g->xmax - .5 * g->dx) : px;
+    REAL y = g->ymax - py < FSM_SMALL2 ? (REAL)(g->ymax - .5 * g->dx) : py;
+    REAL z = g->zmax - pz < FSM_SMALL2 ? (REAL)(g->zmax - .5 * g->dx) : pz;
+    uint32_t nx = (uint32_t)(FSM_SMALL2 + (x - g->xmin) / g->dx);
+    uint32_t ny = (uint32_t)(FSM_SMALL2 + (y - g->ymin) / g->dx);
+    uint32_t nz = (uint32_t)(FSM_SMALL2 + (z - g->zmin) / g->dx);
+    const ptrdiff_t cellNo = (ptrdiff_t)(uint32_t)(ny * ncx + nz * (ncx * ncy) + nx);
+    const ptrdiff_t k = cellNo / ((ptrdiff_t)ncy * ncx);
+    const ptrdiff_t j = (cellNo - k * (ptrdiff_t)ncy * ncx) / ncx;
+    *ci = cellNo - (k * (ptrdiff_t)ncy + j) * ncx;
+    *cj = j;
+    *ck = k;
+}
+
+/* Grid3Drn::initFSM, ttcr/Grid3Drn.h:3487-3556 */
+static void SFX(init3d)(const SFX(fsm_grid3d) * g, const REAL* s, REAL* T, unsigned char* frozen,
+                        int n_src, const REAL* src, const REAL* t0, int npts) {
+    const ptrdiff_t nnx = g->nnx, nny = g->nny, nnz = g->nnz;
+    const ptrdiff_t ncx = nnx - 1, ncy = nny - 1, ncz = nnz - 1;
+    for (int n = 0; n < n_src; ++n) {
+        const REAL px = src[3 * n], py = src[3 * n + 1], pz = src[3 * n + 2];
+        /* first node (in linear order) with |coord - Tx| < small on every axis
+         * (Node3Dn::operator==, ttcr/Node3Dn.h:147-149).  The test is separable,
+         * so the first match in x-fastest order is (first i, first j, first k). */
+        ptrdiff_t fi = -1, fj = -1, fk = -1;
+        for (ptrdiff_t i = 0; i < nnx && fi < 0; ++i)
+            if (FABS(SFX(coord)(g->xmin, (uint32_t)i, g->dx) - px) < FSM_SMALL) fi = i;
+        for (ptrdiff_t j = 0; j < nny && fj < 0; ++j)
+            if (FABS(SFX(coord)(g->ymin, (uint32_t)j, g->dx) - py) < FSM_SMALL) fj = j;
+        for (ptrdiff_t k = 0; k < nnz && fk < 0; ++k)
+            if (FABS(SFX(coord)(g->zmin, (uint32_t)k, g->dx) - pz) < FSM_SMALL) fk = k;
+        if (fi >= 0 && fj >= 0 && fk >= 0) {
+            const ptrdiff_t i = fi, j = fj, k = fk;
+            const size_t nn = (size_t)((k * nny + j) * nnx + i);
+            T[nn] = t0[n];
+            frozen[nn] = 1;
+            for (ptrdiff_t kk = k - npts; kk <= k + npts; ++kk) {
+                if (kk < 0 || kk > ncz) continue;
+                for (ptrdiff_t jj = j - npts; jj <= j + npts; ++jj) {
+                    if (jj < 0 || jj > ncy) continue;
+                    for (ptrdiff_t ii = i - npts; ii <= i + npts; ++ii) {
+                        if (ii >= 0 && ii <= ncx && !(ii == i && jj == j && kk == k)) {
+                            const size_t m = (size_t)((kk * nny + jj) * nnx + ii);
+                            REAL d = SFX(dist3d)(SFX(coord)(g->xmin, (uint32_t)ii, g->dx),
+                                                 SFX(coord)(g->ymin, (uint32_t)jj, g->dx),
+                                                 SFX(coord)(g->zmin, (uint32_t)kk, g->dx), px, py, pz);
+                            REAL tt = t0[n] + d * s[m];
+                            T[m] = tt;
+                            frozen[m] = 1;
+                        }
+                    }
+                }
+            }
+        } else {
+            ptrdiff_t i, j, k;
+            SFX(cell3d)(g, px, py, pz, &i, &j, &k);
+            for (ptrdiff_t kk = k - (npts - 1); kk <= k + npts; ++kk) {
+                if (kk < 0 || kk > ncz) continue;
+                for (ptrdiff_t jj = j - (npts - 1); jj <= j + npts; ++jj) {
+                    if (jj < 0 || jj > ncy) continue;
+                    for (ptrdiff_t ii = i - (npts - 1); ii <= i + npts; ++ii) {
+                        /* node (i,j,k) itself is skipped, as in the reference (:3541) */
+                        if (ii >= 0 && ii <= ncx && !(ii == i && jj == j && kk == k)) {
+                            const size_t m = (size_t)((kk * nny + jj) * nnx + ii);
+                            REAL d = SFX(dist3d)(SFX(coord)(g->xmin, (uint32_t)ii, g->dx),
+                                                 SFX(coord)(g->ymin, (uint32_t)jj, g->dx),
+                                                 SFX(coord)(g->zmin, (uint32_t)kk, g->dx), px, py, pz);
+                            REAL tt = t0[n] + d * s[m];
+                            T[m] = tt;
+                            frozen[m] = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* Grid3Drn ctor (ttcr/Grid3Drn.h:67-78) + Grid3Drnfs ctor (ttcr/Grid3Drnfs.h:39-50)
+ * + translateOrigin handling of buildGridNodes (ttcr/Grid3Drn.h:362-372). */
+void SFX(fsm_grid3d_init)(SFX(fsm_grid3d) * g, uint32_t ncx, uint32_t ncy, uint32_t ncz, REAL dx,
+                          REAL xmin, REAL ymin, REAL zmin, int translate) {
+    g->nnx = (size_t)ncx + 1;
+    g->nny = (size_t)ncy + 1;
+    g->nnz = (size_t)ncz + 1;
+    g->dx = dx;
+    g->xmin = xmin; g->ymin = ymin; g->zmin = zmin;
+    g->xmax = xmin + ncx * dx;
+    g->ymax = ymin + ncy * dx;
+    g->zmax = zmin + ncz * dx;
+    g->ox = g->oy = g->oz = 0;
+    if (translate) {
+        g->ox = xmin; g->oy = ymin; g->oz = zmin;
+        g->xmax -= g->xmin; g->ymax -= g->ymin; g->zmax -= g->zmin;
+        g->xmin = 0; g->ymin = 0; g->zmin = 0;
+    }
+}
+
+/* Grid3Drn::checkPts, ttcr/Grid3Drn.h:771-790.  Returns 1 if a point is outside. */
+int SFX(fsm_outside3d)(const SFX(fsm_grid3d) * g, int n, const REAL* p) {
+    for (int m = 0; m < n; ++m) {
+        if (p[3 * m] < g->xmin || p[3 * m] > g->xmax || p[3 * m + 1] < g->ymin ||
+            p[3 * m + 1] > g->ymax || p[3 * m + 2] < g->zmin || p[3 * m + 2] > g->zmax)
+            return 1;
+    }
+    return 0;
+}
+
+/* Grid3Drcfs::setSlowness, ttcr/Grid3Drcfs.h:88-171: cell -> node slowness.
+ * Written as one generic loop: a node averages the cells that touch it; the
+ * reference's summation order inside each branch is k outer / j / i inner with the
+ * "+0" neighbour first (i, then i-1; ...), except on the x-min/x-max faces where k
+ * is innermost; this loop reproduces both (the factors .5/.25/.125 are exact). */
+void SFX(fsm_cells_to_nodes3d)(size_t ncx, size_t ncy, size_t ncz, const REAL* sc, REAL* sn) {
+    const size_t nnx = ncx + 1, nny = ncy + 1, nnz = ncz + 1;
+    for (size_t k = 0; k < nnz; ++k)
+        for (size_t j = 0; j < nny; ++j)
+            for (size_t i = 0; i < nnx; ++i) {
+                /* candidate cell indices along each axis: c, then c-1 */
+                size_t ci[2], cj[2], ck[2];
+                int ni = 0, nj = 0, nk = 0;
+                if (i < ncx) ci[ni++] = i;
+                if (i > 0) ci[ni++] = i - 1;
+                if (j < ncy) cj[nj++] = j;
+                if (j > 0) cj[nj++] = j - 1;
+                if (k < ncz) ck[nk++] = k;
+                if (k > 0) ck[nk++] = k - 1;
+                REAL sum = 0;
+                int first = 1;
+                if (ni == 1) {
+                    /* x-min / x-max faces (:139-146): k varies fastest in the reference's sum */
+                    for (int b = 0; b < nj; ++b)
+                        for (int a = 0; a < nk; ++a) {
+                            REAL v = sc[(ck[a] * ncy + cj[b]) * ncx + ci[0]];
+                            if (first) { sum = v; first = 0; } else sum = sum + v;
+                        }
+                } else {
+                    for (int a = 0; a < nk; ++a)
+                        for (int b = 0; b < nj; ++b)
+                            for (int c = 0; c < ni; ++c) {
+                                REAL v = sc[(ck[a] * ncy + cj[b]) * ncx + ci[c]];
+                                if (first) { sum = v; first = 0; } else sum = sum + v;
+                            }
+                }
+                const int cnt = ni * nj * nk;
+                REAL out;
+                if (cnt == 1) out = sum;
+                else if (cnt == 2) out = (REAL)(0.5 * sum);
+                else if (cnt == 4) out = (REAL)(0.25 * sum);
+                else out = (REAL)(0.125 * sum);
+                sn[(k * nny + j) * nnx + i] = out;
+            }
+}
+
+/* Driver loop of Grid3Drnfs::raytrace (ttcr/Grid3Drnfs.h:84-155), weno3 == false
+ * branch (:137-153), preceded by reinit (:92-94) and initFSM (:97-100).
+ * eps is the per-node tolerance; the ctor scales it by the node count (:49).
+ * src are in grid coordinates (origin already subtracted when translated).
+ * change_hist (optional, length maxit) receives the L1 change of every iteration.
+ * Returns niter. */
+int SFX(fsm_solve3d)(const SFX(fsm_grid3d) * g, const REAL* s, int n_src, const REAL* src,
+                     const REAL* t0, REAL eps, int maxit, REAL* T, REAL* change_hist) {
+    const size_t N = g->nnx * g->nny * g->nnz;
+    REAL epsilon = eps;
+    epsilon *= (REAL)N;
+    unsigned char* frozen = (unsigned char*)calloc(N, 1);
+    REAL* times = (REAL*)malloc(N * sizeof(REAL));
+    for (size_t n = 0; n < N; ++n) T[n] = REAL_MAX;
+    SFX(init3d)(g, s, T, frozen, n_src, src, t0, 1);
+    for (size_t n = 0; n < N; ++n) times[n] = T[n];
+    REAL change = REAL_MAX;
+    int niter = 0;
+    while (change >= epsilon && niter < maxit) {
+        SFX(sweep3d)(T, s, frozen, g->dx, g->nnx, g->nny, g->nnz);
+        change = 0.0;
+        for (size_t n = 0; n < N; ++n) {
+            REAL dt = FABS(times[n] - T[n]);
+            change += dt;
+            times[n] = T[n];
+        }
+        if (change_hist) change_hist[niter] = change;
+        niter++;
+    }
+    free(times);
+    free(frozen);
+    return niter;
+}
+
+/* Grid3Drn::getIJK (ttcr/Grid3Drn.h:233-237) + getTraveltime (:794-930):
+ * node value / linear / bilinear / trilinear interpolation at a receiver. */
+REAL SFX(fsm_interp3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL px, REAL py, REAL pz) {
+    const size_t nnx = g->nnx, nny = g->nny;
+    const REAL xmin = g->xmin, ymin = g->ymin, zmin = g->zmin, dx = g->dx, dy = g->dx, dz = g->dx;
+    const uint32_t i = (uint32_t)(FSM_SMALL2 + (px - xmin) / dx);
+    const uint32_t j = (uint32_t)(FSM_SMALL2 + (py - ymin) / dy);
+    const uint32_t k = (uint32_t)(FSM_SMALL2 + (pz - zmin) / dz);
+    const int onx = FABS(px - (xmin + i * dx)) < FSM_SMALL2;
+    const int ony = FABS(py - (ymin + j * dy)) < FSM_SMALL2;
+    const int onz = FABS(pz - (zmin + k * dz)) < FSM_SMALL2;
+#define TT(ii, jj, kk) T[((size_t)(kk) * nny + (jj)) * nnx + (ii)]
+    REAL tt;
+    if (onx && ony && onz) {
+        return TT(i, j, k);
+    } else if (onx && ony) {
+        REAL t1 = TT(i, j, k), t2 = TT(i, j, k + 1);
+        REAL w1 = (zmin + (k + 1) * dz - pz) / dz, w2 = (pz - (zmin + k * dz)) / dz;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onx && onz) {
+        REAL t1 = TT(i, j, k), t2 = TT(i, j + 1, k);
+        REAL w1 = (ymin + (j + 1) * dy - py) / dy, w2 = (py - (ymin + j * dy)) / dy;
+        tt = t1 * w1 + t2 * w2;
+    } else if (ony && onz) {
+        REAL t1 = TT(i, j, k), t2 = TT(i + 1, j, k);
+        REAL w1 = (xmin + (i + 1) * dx - px) / dx, w2 = (px - (xmin + i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onx) {
+        REAL t1 = TT(i, j, k), t2 = TT(i, j, k + 1), t3 = TT(i, j + 1, k), t4 = TT(i, j + 1, k + 1);
+        REAL w1 = (zmin + (k + 1) * dz - pz) / dz, w2 = (pz - (zmin + k * dz)) / dz;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (ymin + (j + 1) * dy - py) / dy;
+        w2 = (py - (ymin + j * dy)) / dy;
+        tt = t1 * w1 + t2 * w2;
+    } else if (ony) {
+        REAL t1 = TT(i, j, k), t2 = TT(i, j, k + 1), t3 = TT(i + 1, j, k), t4 = TT(i + 1, j, k + 1);
+        REAL w1 = (zmin + (k + 1) * dz - pz) / dz, w2 = (pz - (zmin + k * dz)) / dz;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (xmin + (i + 1) * dx - px) / dx;
+        w2 = (px - (xmin + i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onz) {
+        REAL t1 = TT(i, j, k), t2 = TT(i, j + 1, k), t3 = TT(i + 1, j, k), t4 = TT(i + 1, j + 1, k);
+        REAL w1 = (ymin + (j + 1) * dy - py) / dy, w2 = (py - (ymin + j * dy)) / dy;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (xmin + (i + 1) * dx - px) / dx;
+        w2 = (px - (xmin + i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else {
+        REAL t1 = TT(i, j, k), t2 = TT(i, j, k + 1), t3 = TT(i, j + 1, k), t4 = TT(i, j + 1, k + 1);
+        REAL t5 = TT(i + 1, j, k), t6 = TT(i + 1, j, k + 1), t7 = TT(i + 1, j + 1, k),
+             t8 = TT(i + 1, j + 1, k + 1);
+        REAL w1 = (zmin + (k + 1) * dz - pz) / dz, w2 = (pz - (zmin + k * dz)) / dz;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        t3 = t5 * w1 + t6 * w2;
+        t4 = t7 * w1 + t8 * w2;
+        w1 = (ymin + (j + 1) * dy - py) / dy;
+        w2 = (py - (ymin + j * dy)) / dy;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (xmin + (i + 1) * dx - px) / dx;
+        w2 = (px - (xmin + i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    }
+#undef TT
+    return tt;
+}
+
+/* ------------------------------------------------------------------ 2D -- */
+/* 2D node index is z-fastest: n = i*(ncz+1)+j (ttcr/Grid2Drn.h:720). */
+
+void SFX(fsm_grid2d_init)(SFX(fsm_grid2d) * g, uint32_t ncx, uint32_t ncz, REAL dx, REAL dz,
+                          REAL xmin, REAL zmin) {
+    /* Grid2Drn ctor, ttcr/Grid2Drn.h:58-66 */
+    g->nnx = (size_t)ncx + 1;
+    g->nnz = (size_t)ncz + 1;
+    g->dx = dx; g->dz = dz;
+    g->xmin = xmin; g->zmin = zmin;
+    g->xmax = xmin + ncx * dx;
+    g->zmax = zmin + ncz * dz;
+}
+
+int SFX(fsm_outside2d)(const SFX(fsm_grid2d) * g, int n, const REAL* p) {
+    for (int m = 0; m < n; ++m)
+        if (p[2 * m] < g->xmin || p[2 * m] > g->xmax || p[2 * m + 1] < g->zmin || p[2 * m + 1] > g->zmax)
+            return 1;
+    return 0;
+}
+
+/* neighbour minima shared by the 2D updates (ttcr/Grid2Drn.h:923-943) */
+static void SFX(ab2d)(const REAL* T, size_t nnx, size_t nnz, size_t i, size_t j, REAL* pa, REAL* pb) {
+    const size_t ncx = nnx - 1, ncz = nnz - 1;
+    REAL a, b, t;
+    if (i == 0)
+        a = T[(i + 1) * nnz + j];
+    else if (i == ncx)
+        a = T[(i - 1) * nnz + j];
+    else {
+        a = T[(i - 1) * nnz + j];
+        t = T[(i + 1) * nnz + j];
+        a = a < t ? a : t;
+    }
+    if (j == 0)
+        b = T[i * nnz + j + 1];
+    else if (j == ncz)
+        b = T[i * nnz + j - 1];
+    else {
+        b = T[i * nnz + j - 1];
+        t = T[i * nnz + j + 1];
+        b = b < t ? b : t;
+    }
+    *pa = a;
+    *pb = b;
+}
+
+/* Grid2Drn::update_node, ttcr/Grid2Drn.h:920-954 (square cells) */
+static void SFX(update_node2d)(REAL* T, const REAL* s, REAL dx, size_t nnx, size_t nnz, size_t i, size_t j) {
+    REAL a, b, t;
+    SFX(ab2d)(T, nnx, nnz, i, j, &a, &b);
+    REAL fh = s[i * nnz + j] * dx;
+    if (FABS(a - b) >= fh)
+        t = (a < b ? a : b) + fh;
+    else
+        t = 0.5 * (a + b + sqrt(2. * fh * fh - (a - b) * (a - b)));
+    if (t < T[i * nnz + j]) T[i * nnz + j] = t;
+}
+
+/* Grid2Drn::update_node_xz, ttcr/Grid2Drn.h:1019-1058 (dx != dz) */
+static void SFX(update_node2d_xz)(REAL* T, const REAL* s, REAL dx, REAL dz, size_t nnx, size_t nnz,
+                                  size_t i, size_t j) {
+    REAL a, b, t;
+    SFX(ab2d)(T, nnx, nnz, i, j, &a, &b);
+    const REAL sn = s[i * nnz + j];
+    if (a < b && ((b - a) / dx) > sn) {
+        t = a + sn * dx;
+    } else if (a > b && ((a - b) / dz) > sn) {
+        t = b + sn * dz;
+    } else {
+        REAL dx2 = dx * dx;
+        REAL dz2 = dz * dz;
+        REAL s2 = sn * sn;
+        t = (b * dx2 + a * dz2) / (dx2 + dz2) +
+            sqrt((2.0 * a * b * dx2 * dz2 - a * a * dx2 * dz2 - b * b * dx2 * dz2 + dx2 * dx2 * dz2 * s2 +
+                  dx2 * dz2 * dz2 * s2) /
+                 ((dx2 + dz2) * (dx2 + dz2)));
+    }
+    if (t < T[i * nnz + j]) T[i * nnz + j] = t;
+}
+
+/* Grid2Drn::sweep / sweep_xz, ttcr/Grid2Drn.h:713-752, :797-835:
+ * directions (i+,j+), (i-,j+), (i-,j-), (i+,j-), j innermost. */
+static void SFX(sweep2d)(REAL* T, const REAL* s, const unsigned char* frozen, REAL dx, REAL dz, int xz,
+                         size_t nnx, size_t nnz) {
+    static const int RI[4] = {0, 1, 1, 0};
+    static const int RJ[4] = {0, 0, 1, 1};
+    for (int dir = 0; dir < 4; ++dir) {
+        for (size_t ii = 0; ii < nnx; ++ii) {
+            const size_t i = RI[dir] ? nnx - 1 - ii : ii;
+            for (size_t jj = 0; jj < nnz; ++jj) {
+                const size_t j = RJ[dir] ? nnz - 1 - jj : jj;
+                if (!frozen[i * nnz + j]) {
+                    if (xz)
+                        SFX(update_node2d_xz)(T, s, dx, dz, nnx, nnz, i, j);
+                    else
+                        SFX(update_node2d)(T, s, dx, nnx, nnz, i, j);
+                }
+            }
+        }
+    }
+}
+
+/* Node2Dn::getDistance, ttcr/Node2Dn.h:134-136 */
+static REAL SFX(dist2d)(REAL x, REAL z, REAL px, REAL pz) {
+    return (REAL)sqrt((x - px) * (x - px) + (z - pz) * (z - pz));
+}
+
+/* Grid2Drn::initFSM, ttcr/Grid2Drn.h:1360-1418.  Differs from 3D: on-node
+ * neighbours use the mean of the neighbour's and the source node's slowness
+ * (:1384), the off-node branch skips nothing (:1403-1412), and getCellNo uses
+ * `small`, not `small2` (:173-179). */
+static void SFX(init2d)(const SFX(fsm_grid2d) * g, const REAL* s, REAL* T, unsigned char* frozen,
+                        int n_src, const REAL* src, const REAL* t0, int npts) {
+    const ptrdiff_t nnx = g->nnx, nnz = g->nnz, ncx = nnx - 1, ncz = nnz - 1;
+    for (int n = 0; n < n_src; ++n) {
+        const REAL px = src[2 * n], pz = src[2 * n + 1];
+        ptrdiff_t fi = -1, fj = -1;
+        for (ptrdiff_t i = 0; i < nnx && fi < 0; ++i)
+            if (FABS(SFX(coord)(g->xmin, (uint32_t)i, g->dx) - px) < FSM_SMALL) fi = i;
+        for (ptrdiff_t j = 0; j < nnz && fj < 0; ++j)
+            if (FABS(SFX(coord)(g->zmin, (uint32_t)j, g->dz) - pz) < FSM_SMALL) fj = j;
+        if (fi >= 0 && fj >= 0) {
+            const ptrdiff_t i = fi, j = fj;
+            const size_t nn = (size_t)(i * nnz + j);
+            T[nn] = t0[n];
+            frozen[nn] = 1;
+            for (ptrdiff_t ii = i - npts; ii <= i + npts; ++ii) {
+                if (ii < 0 || ii > ncx) continue;
+                for (ptrdiff_t jj = j - npts; jj <= j + npts; ++jj) {
+                    if (jj >= 0 && jj <= ncz && !(ii == i && jj == j)) {
+                        const size_t m = (size_t)(ii * nnz + jj);
+                        REAL d = SFX(dist2d)(SFX(coord)(g->xmin, (uint32_t)ii, g->dx),
+                                             SFX(coord)(g->zmin, (uint32_t)jj, g->dz), px, pz);
+                        REAL tt = t0[n] + d * 0.5 * (s[m] + s[nn]);
+                        T[m] = tt;
+                        frozen[m] = 1;
+                    }
+                }
+            }
+        } else {
+            REAL x = g->xmax - px < FSM_SMALL ? (REAL)(g->xmax - .5 * g->dx) : px;
+            REAL z = g->zmax - pz < FSM_SMALL ? (REAL)(g->zmax - .5 * g->dz) : pz;
+            const uint32_t cnx = (uint32_t)(FSM_SMALL + (x - g->xmin) / g->dx);
+            const uint32_t cnz = (uint32_t)(FSM_SMALL + (z - g->zmin) / g->dz);
+            const ptrdiff_t cellNo = (ptrdiff_t)(uint32_t)(cnx * (uint32_t)ncz + cnz);
+            const ptrdiff_t i = cellNo / ncz;
+            const ptrdiff_t j = cellNo - i * ncz;
+            for (ptrdiff_t ii = i - (npts - 1); ii <= i + npts; ++ii) {
+                if (ii < 0 || ii > ncx) continue;
+                for (ptrdiff_t jj = j - (npts - 1); jj <= j + npts; ++jj) {
+                    if (jj >= 0 && jj <= ncz) {
+                        const size_t m = (size_t)(ii * nnz + jj);
+                        REAL d = SFX(dist2d)(SFX(coord)(g->xmin, (uint32_t)ii, g->dx),
+                                             SFX(coord)(g->zmin, (uint32_t)jj, g->dz), px, pz);
+                        REAL tt = t0[n] + d * s[m];
+                        T[m] = tt;
+                        frozen[m] = 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* Grid2Drcfs::setSlowness, ttcr/Grid2Drcfs.h:98-138 (cells z-fastest: c = i*ncz + j).
+ * Summation order of the reference: (i,j) (i,j-1) (i-1,j) (i-1,j-1). */
+void SFX(fsm_cells_to_nodes2d)(size_t ncx, size_t ncz, const REAL* sc, REAL* sn) {
+    const size_t nnx = ncx + 1, nnz = ncz + 1;
+    for (size_t i = 0; i < nnx; ++i)
+        for (size_t j = 0; j < nnz; ++j) {
+            size_t ci[2], cj[2];
+            int ni = 0, nj = 0;
+            if (i < ncx) ci[ni++] = i;
+            if (i > 0) ci[ni++] = i - 1;
+            if (j < ncz) cj[nj++] = j;
+            if (j > 0) cj[nj++] = j - 1;
+            REAL sum = 0;
+            int first = 1;
+            for (int a = 0; a < ni; ++a)
+                for (int b = 0; b < nj; ++b) {
+                    REAL v = sc[ci[a] * ncz + cj[b]];
+                    if (first) { sum = v; first = 0; } else sum = sum + v;
+                }
+            const int cnt = ni * nj;
+            sn[i * nnz + j] = cnt == 1 ? sum : (cnt == 2 ? (REAL)(0.5 * sum) : (REAL)(0.25 * sum));
+        }
+}
+
+/* Grid2Drnfs::raytrace driver, ttcr/Grid2Drnfs.h:198-299, weno3 == false,
+ * rotated_template == false branch (:277-297). */
+int SFX(fsm_solve2d)(const SFX(fsm_grid2d) * g, const REAL* s, int n_src, const REAL* src,
+                     const REAL* t0, REAL eps, int maxit, REAL* T, REAL* change_hist) {
+    const size_t N = g->nnx * g->nnz;
+    REAL epsilon = eps;
+    epsilon *= (REAL)N;
+    unsigned char* frozen = (unsigned char*)calloc(N, 1);
+    REAL* times = (REAL*)malloc(N * sizeof(REAL));
+    for (size_t n = 0; n < N; ++n) T[n] = REAL_MAX;
+    SFX(init2d)(g, s, T, frozen, n_src, src, t0, 1);
+    for (size_t n = 0; n < N; ++n) times[n] = T[n];
+    REAL change = REAL_MAX;
+    int niter = 0;
+    const int xz = !(g->dx == g->dz);
+    while (change >= epsilon && niter < maxit) {
+        SFX(sweep2d)(T, s, frozen, g->dx, g->dz, xz, g->nnx, g->nnz);
+        change = 0.0;
+        for (size_t n = 0; n < N; ++n) {
+            REAL dt = FABS(times[n] - T[n]);
+            change += dt;
+            times[n] = T[n];
+        }
+        if (change_hist) change_hist[niter] = change;
+        niter++;
+    }
+    free(times);
+    free(frozen);
+    return niter;
+}
+
+/* Grid2Drn::getIJ (ttcr/Grid2Drn.h:186-189) + getTraveltime (:359-414) */
+REAL SFX(fsm_interp2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL pz) {
+    const size_t nnz = g->nnz;
+    const REAL xmin = g->xmin, zmin = g->zmin, dx = g->dx, dz = g->dz;
+    const uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+    const uint32_t j = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+    const int onx = FABS(px - (xmin + i * dx)) < FSM_SMALL;
+    const int onz = FABS(pz - (zmin + j * dz)) < FSM_SMALL;
+    REAL tt;
+    if (onx && onz) {
+        return T[(size_t)i * nnz + j];
+    } else if (onx) {
+        REAL t1 = T[(size_t)i * nnz + j], t2 = T[(size_t)i * nnz + j + 1];
+        REAL w1 = (zmin + (j + 1) * dz - pz) / dz, w2 = (pz - (zmin + j * dz)) / dz;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onz) {
+        REAL t1 = T[(size_t)i * nnz + j], t2 = T[(size_t)(i + 1) * nnz + j];
+        REAL w1 = (xmin + (i + 1) * dx - px) / dx, w2 = (px - (xmin + i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else {
+        REAL t1 = T[(size_t)i * nnz + j], t2 = T[(size_t)(i + 1) * nnz + j];
+        REAL t3 = T[(size_t)i * nnz + j + 1], t4 = T[(size_t)(i + 1) * nnz + j + 1];
+        REAL w1 = (xmin + (i + 1) * dx - px) / dx, w2 = (px - (xmin + i * dx)) / dx;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (zmin + (j + 1) * dz - pz) / dz;
+        w2 = (pz - (zmin + j * dz)) / dz;
+        tt = t1 * w1 + t2 * w2;
+    }
+    return tt;
+}
+
+#undef FSM_SMALL
+#undef FSM_SMALL2

@@ -1,0 +1,245 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of the CPU checker(s):
+
+* ``liboracle.so``          this repo's plain-C restatement of the reference FSM
+                            solver (oracle/fsm_oracle.c); travels to the GPU box prebuilt.
+* ``_ref/libttcr_ref.so``   the unmodified reference headers compiled where they lie under
+                            /root/reference (build container only, see oracle/Makefile).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module, and only as the checker / the timed CPU baseline.  The product
+(``ttcr_amd``) never imports it.
+
+All flat 3-D arrays are x-fastest (n = (k*nny + j)*nnx + i, ttcr/Grid3Drn.h:2823); flat 2-D
+arrays are z-fastest (n = i*nnz + j, ttcr/Grid2Drn.h:720).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+
+def build(with_ref=True):
+    """Compile liboracle.so (and _ref/libttcr_ref.so when /root/reference is present)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if with_ref and os.path.isdir("/root/reference/ttcr"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libttcr_ref.so"))
+
+
+class _G3(C.Structure):
+    pass
+
+
+def _g3(ct):
+    class G(C.Structure):
+        _fields_ = [("nnx", C.c_size_t), ("nny", C.c_size_t), ("nnz", C.c_size_t)] + [
+            (n, ct) for n in ("dx", "xmin", "ymin", "zmin", "xmax", "ymax", "zmax", "ox", "oy", "oz")
+        ]
+
+    return G
+
+
+def _g2(ct):
+    class G(C.Structure):
+        _fields_ = [("nnx", C.c_size_t), ("nnz", C.c_size_t)] + [
+            (n, ct) for n in ("dx", "dz", "xmin", "zmin", "xmax", "zmax")
+        ]
+
+    return G
+
+
+_TYPES = {
+    np.dtype(np.float32): ("f32", C.c_float, _g3(C.c_float), _g2(C.c_float)),
+    np.dtype(np.float64): ("f64", C.c_double, _g3(C.c_double), _g2(C.c_double)),
+}
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(with_ref=False)
+        _LIB = C.CDLL(path)
+        for sfx, ct, _, _ in _TYPES.values():
+            getattr(_LIB, "fsm_interp3d_" + sfx).restype = ct
+            getattr(_LIB, "fsm_interp2d_" + sfx).restype = ct
+    return _LIB
+
+
+def ref():
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libttcr_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/_ref/libttcr_ref.so not built (needs /root/reference)")
+        _REF = C.CDLL(path)
+        _REF.ref_last_error.restype = C.c_char_p
+    return _REF
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _prep_pts(dt, pts, ncol):
+    pts = np.ascontiguousarray(np.asarray(pts, dtype=dt).reshape(-1, ncol))
+    return pts
+
+
+# --------------------------------------------------------------------------- 3D
+
+
+def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
+            cell_slowness=False, translate=False, rcv=None):
+    """Restatement of Grid3Drnfs / Grid3Drcfs ::raytrace (weno=False, tt_from_rp=False).
+
+    ncells = (ncx, ncy, ncz) CELL counts, as in the reference constructors.
+    Returns dict(tt=flat node field, niter, change=per-iteration L1 change, tt_rcv).
+    """
+    dt = np.dtype(dtype)
+    sfx, ct, G3, _ = _TYPES[dt]
+    L = lib()
+    ncx, ncy, ncz = (int(v) for v in ncells)
+    g = G3()
+    getattr(L, "fsm_grid3d_init_" + sfx)(C.byref(g), C.c_uint32(ncx), C.c_uint32(ncy), C.c_uint32(ncz),
+                                         ct(dx), ct(origin[0]), ct(origin[1]), ct(origin[2]),
+                                         C.c_int(int(translate)))
+    nn = (ncx + 1) * (ncy + 1) * (ncz + 1)
+    s = np.ascontiguousarray(np.asarray(slowness, dtype=dt).ravel())
+    if cell_slowness:
+        assert s.size == ncx * ncy * ncz
+        sn = np.empty(nn, dtype=dt)
+        getattr(L, "fsm_cells_to_nodes3d_" + sfx)(C.c_size_t(ncx), C.c_size_t(ncy), C.c_size_t(ncz),
+                                                  _p(s), _p(sn))
+    else:
+        assert s.size == nn
+        sn = s
+    src = _prep_pts(dt, src, 3).copy()
+    nsrc = src.shape[0]
+    t0 = np.zeros(nsrc, dtype=dt) if t0 is None else np.ascontiguousarray(np.asarray(t0, dtype=dt))
+    if translate:  # Grid3D::raytrace subtracts the stored origin (ttcr/Grid3D.h:478-485)
+        src -= np.array([g.ox, g.oy, g.oz], dtype=dt)
+    if getattr(L, "fsm_outside3d_" + sfx)(C.byref(g), C.c_int(nsrc), _p(src)):
+        raise RuntimeError("Error: Point outside grid.")
+    T = np.empty(nn, dtype=dt)
+    hist = np.zeros(maxit, dtype=dt)
+    niter = getattr(L, "fsm_solve3d_" + sfx)(C.byref(g), _p(sn), C.c_int(nsrc), _p(src), _p(t0), ct(eps),
+                                             C.c_int(maxit), _p(T), _p(hist))
+    out = dict(tt=T, niter=int(niter), change=hist[:niter].copy(), node_slowness=sn)
+    if rcv is not None:
+        r = _prep_pts(dt, rcv, 3).copy()
+        if translate:
+            r -= np.array([g.ox, g.oy, g.oz], dtype=dt)
+        f = getattr(L, "fsm_interp3d_" + sfx)
+        out["tt_rcv"] = np.array([f(C.byref(g), _p(T), ct(p[0]), ct(p[1]), ct(p[2])) for p in r], dtype=dt)
+    return out
+
+
+def cells_to_nodes3d(dtype, ncells, sc):
+    dt = np.dtype(dtype)
+    sfx = _TYPES[dt][0]
+    ncx, ncy, ncz = (int(v) for v in ncells)
+    sc = np.ascontiguousarray(np.asarray(sc, dtype=dt).ravel())
+    sn = np.empty((ncx + 1) * (ncy + 1) * (ncz + 1), dtype=dt)
+    getattr(lib(), "fsm_cells_to_nodes3d_" + sfx)(C.c_size_t(ncx), C.c_size_t(ncy), C.c_size_t(ncz), _p(sc), _p(sn))
+    return sn
+
+
+def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
+                cell_slowness=False, translate=False, rcv=None, weno=False):
+    """The compiled, unmodified reference (build container only)."""
+    dt = np.dtype(dtype)
+    sfx, ct = _TYPES[dt][:2]
+    R = ref()
+    ncx, ncy, ncz = (int(v) for v in ncells)
+    nn = (ncx + 1) * (ncy + 1) * (ncz + 1)
+    s = np.ascontiguousarray(np.asarray(slowness, dtype=dt).ravel())
+    src = _prep_pts(dt, src, 3)
+    nsrc = src.shape[0]
+    t0 = np.zeros(nsrc, dtype=dt) if t0 is None else np.ascontiguousarray(np.asarray(t0, dtype=dt))
+    r = _prep_pts(dt, rcv if rcv is not None else np.zeros((0, 3)), 3)
+    tt_rcv = np.empty(r.shape[0], dtype=dt)
+    T = np.empty(nn, dtype=dt)
+    niter = (C.c_int * 2)()
+    rc = getattr(R, "ref_fsm3d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncy),
+                                        C.c_uint32(ncz), ct(dx), ct(origin[0]), ct(origin[1]), ct(origin[2]),
+                                        ct(eps), C.c_int(maxit), C.c_int(int(weno)), C.c_int(int(translate)),
+                                        _p(s), C.c_int(nsrc), _p(src), _p(t0), C.c_int(r.shape[0]), _p(r),
+                                        _p(tt_rcv), _p(T), niter)
+    if rc != 0:
+        raise RuntimeError(R.ref_last_error().decode())
+    return dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
+
+
+# --------------------------------------------------------------------------- 2D
+
+
+def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
+            cell_slowness=False, rcv=None):
+    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (weno=False, rotated_template=False)."""
+    dt = np.dtype(dtype)
+    sfx, ct, _, G2 = _TYPES[dt]
+    L = lib()
+    ncx, ncz = (int(v) for v in ncells)
+    g = G2()
+    getattr(L, "fsm_grid2d_init_" + sfx)(C.byref(g), C.c_uint32(ncx), C.c_uint32(ncz), ct(dx), ct(dz),
+                                         ct(origin[0]), ct(origin[1]))
+    nn = (ncx + 1) * (ncz + 1)
+    s = np.ascontiguousarray(np.asarray(slowness, dtype=dt).ravel())
+    if cell_slowness:
+        assert s.size == ncx * ncz
+        sn = np.empty(nn, dtype=dt)
+        getattr(L, "fsm_cells_to_nodes2d_" + sfx)(C.c_size_t(ncx), C.c_size_t(ncz), _p(s), _p(sn))
+    else:
+        assert s.size == nn
+        sn = s
+    src = _prep_pts(dt, src, 2)
+    nsrc = src.shape[0]
+    t0 = np.zeros(nsrc, dtype=dt) if t0 is None else np.ascontiguousarray(np.asarray(t0, dtype=dt))
+    if getattr(L, "fsm_outside2d_" + sfx)(C.byref(g), C.c_int(nsrc), _p(src)):
+        raise RuntimeError("Error: Point outside grid.")
+    T = np.empty(nn, dtype=dt)
+    hist = np.zeros(maxit, dtype=dt)
+    niter = getattr(L, "fsm_solve2d_" + sfx)(C.byref(g), _p(sn), C.c_int(nsrc), _p(src), _p(t0), ct(eps),
+                                             C.c_int(maxit), _p(T), _p(hist))
+    out = dict(tt=T, niter=int(niter), change=hist[:niter].copy(), node_slowness=sn)
+    if rcv is not None:
+        r = _prep_pts(dt, rcv, 2)
+        f = getattr(L, "fsm_interp2d_" + sfx)
+        out["tt_rcv"] = np.array([f(C.byref(g), _p(T), ct(p[0]), ct(p[1])) for p in r], dtype=dt)
+    return out
+
+
+def ref_solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
+                cell_slowness=False, rcv=None, weno=False, rotated=False):
+    dt = np.dtype(dtype)
+    sfx, ct = _TYPES[dt][:2]
+    R = ref()
+    ncx, ncz = (int(v) for v in ncells)
+    nn = (ncx + 1) * (ncz + 1)
+    s = np.ascontiguousarray(np.asarray(slowness, dtype=dt).ravel())
+    src = _prep_pts(dt, src, 2)
+    nsrc = src.shape[0]
+    t0 = np.zeros(nsrc, dtype=dt) if t0 is None else np.ascontiguousarray(np.asarray(t0, dtype=dt))
+    r = _prep_pts(dt, rcv if rcv is not None else np.zeros((0, 2)), 2)
+    tt_rcv = np.empty(r.shape[0], dtype=dt)
+    T = np.empty(nn, dtype=dt)
+    niter = (C.c_int * 2)()
+    rc = getattr(R, "ref_fsm2d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncz), ct(dx),
+                                        ct(dz), ct(origin[0]), ct(origin[1]), ct(eps), C.c_int(maxit),
+                                        C.c_int(int(weno)), C.c_int(int(rotated)), _p(s), C.c_int(nsrc), _p(src),
+                                        _p(t0), C.c_int(r.shape[0]), _p(r), _p(tt_rcv), _p(T), niter)
+    if rc != 0:
+        raise RuntimeError(R.ref_last_error().decode())
+    return dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)

@@ -1,0 +1,138 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY (never shipped, never on the product path).
+//
+// Thin extern "C" driver around the UNMODIFIED reference headers, which are
+// #include'd by absolute path from /root/reference at build time (nothing of
+// the reference is copied into this repo).  It is compiled by oracle/Makefile
+// into oracle/_ref/libttcr_ref.so (git-ignored) and is used in the build
+// container to (a) generate tests/golden/*.npz and (b) validate the C
+// restatement in oracle/fsm_oracle.c value-for-value.
+//
+// Reference entry points exercised:
+//   Grid3Drnfs<T,uint32_t>  ttcr/Grid3Drnfs.h:39-50, :84-155
+//   Grid3Drcfs<T,uint32_t>  ttcr/Grid3Drcfs.h:41-52, :88-171
+//   Grid2Drnfs<T,uint32_t,sxz<T>>  ttcr/Grid2Drnfs.h:84-95, :198-299
+//   Grid2Drcfs<T,uint32_t,sxz<T>>  ttcr/Grid2Drcfs.h:98-138
+// called through the public base-class overloads Grid3D::raytrace
+// (ttcr/Grid3D.h:470-502) / Grid2D::raytrace.
+#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "Grid2Drcfs.h"
+#include "Grid2Drnfs.h"
+#include "Grid3Drcfs.h"
+#include "Grid3Drnfs.h"
+
+namespace ttcr {
+int verbose = 0;
+int gpu_profile = 0;
+}  // namespace ttcr
+
+static thread_local std::string g_err;
+
+template <typename T, typename GRID>
+static int run3d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const T* src_xyz,
+                 const T* t0, int n_rcv, const T* rcv_xyz, T* tt_rcv, T* tt_grid, int* niter) {
+    using namespace ttcr;
+    try {
+        std::vector<T> s(slowness, slowness + n_slowness);
+        g.setSlowness(s);
+        std::vector<sxyz<T>> Tx(n_src), Rx(n_rcv);
+        std::vector<T> vt0(t0, t0 + n_src), tt;
+        for (int n = 0; n < n_src; ++n) Tx[n] = {src_xyz[3 * n], src_xyz[3 * n + 1], src_xyz[3 * n + 2]};
+        for (int n = 0; n < n_rcv; ++n) Rx[n] = {rcv_xyz[3 * n], rcv_xyz[3 * n + 1], rcv_xyz[3 * n + 2]};
+        static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, 0);
+        for (int n = 0; n < n_rcv; ++n) tt_rcv[n] = tt[n];
+        std::vector<T> grid_tt;
+        g.getTT(grid_tt, 0);
+        std::memcpy(tt_grid, grid_tt.data(), grid_tt.size() * sizeof(T));
+        niter[0] = g.get_niter();
+        niter[1] = g.get_niterw();
+        return 0;
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+
+template <typename T, typename GRID>
+static int run2d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const T* src_xz,
+                 const T* t0, int n_rcv, const T* rcv_xz, T* tt_rcv, T* tt_grid, int* niter) {
+    using namespace ttcr;
+    try {
+        std::vector<T> s(slowness, slowness + n_slowness);
+        g.setSlowness(s);
+        std::vector<sxz<T>> Tx(n_src), Rx(n_rcv);
+        std::vector<T> vt0(t0, t0 + n_src), tt;
+        for (int n = 0; n < n_src; ++n) Tx[n] = {src_xz[2 * n], src_xz[2 * n + 1]};
+        for (int n = 0; n < n_rcv; ++n) Rx[n] = {rcv_xz[2 * n], rcv_xz[2 * n + 1]};
+        static_cast<Grid2D<T, uint32_t, sxz<T>>&>(g).raytrace(Tx, vt0, Rx, tt, 0);
+        for (int n = 0; n < n_rcv; ++n) tt_rcv[n] = tt[n];
+        std::vector<T> grid_tt;
+        g.getTT(grid_tt, 0);
+        std::memcpy(tt_grid, grid_tt.data(), grid_tt.size() * sizeof(T));
+        niter[0] = g.get_niter();
+        niter[1] = g.get_niterw();
+        return 0;
+    } catch (std::exception& e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+
+// ncx/ncy/ncz are CELL counts, as in the reference constructors.
+#define REF3D(NAME, T)                                                                              \
+    extern "C" int NAME(int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz, T dx, T xmin,  \
+                        T ymin, T zmin, T eps, int maxit, int weno, int translate,                  \
+                        const T* slowness, int n_src, const T* src_xyz, const T* t0, int n_rcv,     \
+                        const T* rcv_xyz, T* tt_rcv, T* tt_grid, int* niter) {                      \
+        try {                                                                                       \
+            if (cell_slowness) {                                                                    \
+                ttcr::Grid3Drcfs<T, uint32_t> g(ncx, ncy, ncz, dx, xmin, ymin, zmin, eps, maxit,    \
+                                                weno != 0, false, false, 1, translate != 0);        \
+                return run3d<T>(g, slowness, (size_t)ncx * ncy * ncz, n_src, src_xyz, t0, n_rcv,    \
+                                rcv_xyz, tt_rcv, tt_grid, niter);                                   \
+            }                                                                                       \
+            ttcr::Grid3Drnfs<T, uint32_t> g(ncx, ncy, ncz, dx, xmin, ymin, zmin, eps, maxit,        \
+                                            weno != 0, false, false, 1, translate != 0);            \
+            return run3d<T>(g, slowness, (size_t)(ncx + 1) * (ncy + 1) * (ncz + 1), n_src, src_xyz, \
+                            t0, n_rcv, rcv_xyz, tt_rcv, tt_grid, niter);                            \
+        } catch (std::exception & e) {                                                              \
+            g_err = e.what();                                                                       \
+            return 1;                                                                               \
+        }                                                                                           \
+    }
+
+REF3D(ref_fsm3d_f32, float)
+REF3D(ref_fsm3d_f64, double)
+
+#define REF2D(NAME, T)                                                                             \
+    extern "C" int NAME(int cell_slowness, uint32_t ncx, uint32_t ncz, T dx, T dz, T xmin, T zmin, \
+                        T eps, int maxit, int weno, int rotated, const T* slowness, int n_src,     \
+                        const T* src_xz, const T* t0, int n_rcv, const T* rcv_xz, T* tt_rcv,       \
+                        T* tt_grid, int* niter) {                                                  \
+        try {                                                                                      \
+            if (cell_slowness) {                                                                   \
+                ttcr::Grid2Drcfs<T, uint32_t, ttcr::sxz<T>> g(ncx, ncz, dx, dz, xmin, zmin, eps,   \
+                                                              maxit, weno != 0, rotated != 0,      \
+                                                              false, 1);                           \
+                return run2d<T>(g, slowness, (size_t)ncx * ncz, n_src, src_xz, t0, n_rcv, rcv_xz,  \
+                                tt_rcv, tt_grid, niter);                                           \
+            }                                                                                      \
+            ttcr::Grid2Drnfs<T, uint32_t, ttcr::sxz<T>> g(ncx, ncz, dx, dz, xmin, zmin, eps,       \
+                                                          maxit, weno != 0, rotated != 0, false,   \
+                                                          1);                                      \
+            return run2d<T>(g, slowness, (size_t)(ncx + 1) * (ncz + 1), n_src, src_xz, t0, n_rcv,  \
+                            rcv_xz, tt_rcv, tt_grid, niter);                                       \
+        } catch (std::exception & e) {                                                             \
+            g_err = e.what();                                                                      \
+            return 1;                                                                              \
+        }                                                                                          \
+    }
+
+REF2D(ref_fsm2d_f32, float)
+REF2D(ref_fsm2d_f64, double)
+
+extern "C" const char* ref_last_error() { return g_err.c_str(); }

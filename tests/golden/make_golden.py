@@ -1,0 +1,52 @@
+"""Generate tests/golden/fsm_golden.npz from the UNMODIFIED reference, compiled where it
+lies under /root/reference (oracle/_ref/libttcr_ref.so, recipe in oracle/Makefile).
+
+Run in the build container only:   python tests/golden/make_golden.py
+
+For every case of tests/cases.py and both dtypes the file holds the reference's outputs
+  <case>/<dtype>/tt       full node traveltime field (Grid3Drn::getTT, flat, x-fastest / z-fastest)
+  <case>/<dtype>/niter    get_niter()
+  <case>/<dtype>/tt_rcv   Grid3Drn::getTraveltime at the case's receivers (tt_from_rp = false)
+and the inputs  <case>/slowness (float64; cast to the dtype under test), so that the
+vectors do not depend on numpy's random generator staying stable.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import cases  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    O.build(with_ref=True)
+    out = {}
+    for c in cases.cases3d() + cases.cases2d():
+        out[f"{c['name']}/slowness"] = c["slowness"]
+        out[f"{c['name']}/src"] = c["src"]
+        out[f"{c['name']}/t0"] = c["t0"]
+        out[f"{c['name']}/rcv"] = c["rcv"]
+        for dt in (np.float32, np.float64):
+            if c["dim"] == 3:
+                r = O.ref_solve3d(dt, c["ncells"], c["dx"], c["origin"], c["slowness"], c["src"], c["t0"],
+                                  cell_slowness=c["cell_slowness"], translate=c["translate"], rcv=c["rcv"])
+            else:
+                r = O.ref_solve2d(dt, c["ncells"], c["dx"], c["dz"], c["origin"], c["slowness"], c["src"],
+                                  c["t0"], cell_slowness=c["cell_slowness"], rcv=c["rcv"])
+            key = f"{c['name']}/{np.dtype(dt).name}"
+            out[key + "/tt"] = r["tt"]
+            out[key + "/niter"] = np.int32(r["niter"])
+            out[key + "/tt_rcv"] = r["tt_rcv"]
+            print(key, "niter", r["niter"])
+    path = os.path.join(HERE, "fsm_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
