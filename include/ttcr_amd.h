@@ -1,0 +1,133 @@
+/* include/ttcr_amd.h -- C ABI of the MI355X-native fast-sweeping (FSM) eikonal solver.
+ *
+ * This is the drop-in boundary for the rectilinear FSM path of groupeLIAMG/ttcr:
+ * every entry point replaces one member of the C++ interface that ttcrpy's Cython
+ * layer programs against (src/ttcrpy/rgrid.pxd:30-145 -> ttcr/Grid3D.h, ttcr/Grid2D.h
+ * and the Grid{2,3}Dr{n,c}fs leaves).  Paths below are relative to the reference root.
+ * Plain pointers and sizes only; no C++/torch types; no exceptions cross the boundary
+ * (integer status + ttcr_fsm_last_error()).
+ *
+ * Conventions (identical to the reference):
+ *   - 3-D flat arrays are x-fastest:  n = (k*(ncy+1)+j)*(ncx+1)+i   (ttcr/Grid3Drn.h:2823)
+ *     3-D cell arrays:                c = (k*ncy+j)*ncx+i            (ttcr/Grid3Drcfs.h:96-171)
+ *   - 2-D flat arrays are z-fastest:  n = i*(ncz+1)+j                (ttcr/Grid2Drn.h:720)
+ *     2-D cell arrays:                c = i*ncz+j                    (ttcr/Grid2Drcfs.h:113-137)
+ *   - nc* are CELL counts (nodes = cells+1), as in the reference constructors.
+ *   - `dtype` selects the reference instantiation: TTCR_F32 <-> <float,uint32_t>,
+ *     TTCR_F64 <-> <double,uint32_t>; all `const void*` arrays hold that type.
+ *   - a "slot" is the reference's threadNo: a private traveltime field kept on the
+ *     device until the next solve in the same slot (ttcr/Node3Dn.h:109-110).
+ */
+#ifndef TTCR_AMD_H
+#define TTCR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ttcr_fsm_grid ttcr_fsm_grid; /* opaque */
+
+enum { TTCR_F32 = 0, TTCR_F64 = 1 };
+
+/* status codes; the Python layer maps them to the exceptions the reference raises */
+enum {
+    TTCR_OK = 0,
+    TTCR_ERR_VALUE = 1,       /* bad argument (Python ValueError in rgrid.pyx)            */
+    TTCR_ERR_RUNTIME = 2,     /* std::runtime_error / length_error / logic_error -> RuntimeError */
+    TTCR_ERR_DEVICE = 3,      /* HIP failure (no silent CPU fallback: the call fails)     */
+    TTCR_ERR_UNSUPPORTED = 4  /* feature of the reference interface not built yet         */
+};
+
+/* Number of visible HIP devices (0 when none / runtime missing). */
+int ttcr_fsm_device_count(void);
+
+/* Message of the last failing call on this thread (also valid when create fails). */
+const char* ttcr_fsm_last_error(void);
+
+/* Replaces: Grid3Drnfs<T,uint32_t>::Grid3Drnfs  (ttcr/Grid3Drnfs.h:39-50)  [cell_slowness = 0]
+ *           Grid3Drcfs<T,uint32_t>::Grid3Drcfs  (ttcr/Grid3Drcfs.h:41-52)  [cell_slowness = 1]
+ * as constructed in src/ttcrpy/rgrid.pyx:217-224, 254-261 (and the _f twins :1917-1954).
+ * eps is the per-node tolerance (scaled by the node count like the ctor does, :49),
+ * n_slots is the reference's `nt`, device is the HIP device ordinal (-1: current). */
+int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncy,
+                      uint32_t ncz, double dx, double xmin, double ymin, double zmin, double eps,
+                      int maxit, int weno, int n_slots, int translate_origin, int device);
+
+/* Replaces: Grid2Drnfs<T,uint32_t,sxz<T>>::Grid2Drnfs (ttcr/Grid2Drnfs.h:84-95)
+ *           Grid2Drcfs<...>::Grid2Drcfs               (ttcr/Grid2Drcfs.h:45-58)
+ * as constructed in src/ttcrpy/rgrid.pyx:2962-2966. */
+int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncz,
+                      double dx, double dz, double xmin, double zmin, double eps, int maxit, int weno,
+                      int rotated_template, int n_slots, int device);
+
+/* Replaces: `del self.grid` (src/ttcrpy/rgrid.pyx:284-285). */
+void ttcr_fsm_destroy(ttcr_fsm_grid* g);
+
+/* Replaces: Grid3Drn::setSlowness (ttcr/Grid3Drn.h:82-89), Grid3Drcfs::setSlowness
+ * (ttcr/Grid3Drcfs.h:88-171), Grid2Drn::setSlowness (ttcr/Grid2Drn.h:71-78),
+ * Grid2Drcfs::setSlowness (ttcr/Grid2Drcfs.h:98-138).  n must equal the node count
+ * (node grids) or the cell count (cell grids), else TTCR_ERR_RUNTIME with the
+ * reference's message.  `s` is a host pointer; the _device variant takes a pointer
+ * that is already resident in HBM on the grid's device (no PCIe copy). */
+int ttcr_fsm_set_slowness(ttcr_fsm_grid* g, const void* s, size_t n);
+int ttcr_fsm_set_slowness_device(ttcr_fsm_grid* g, const void* d_s, size_t n);
+
+/* Replaces: Grid3Drn::getSlowness (ttcr/Grid3Drn.h:90-97): NODE slowness, n = node count. */
+int ttcr_fsm_get_slowness(ttcr_fsm_grid* g, void* out, size_t n);
+
+/* Replaces: Grid3D::raytrace(Tx,t0,Rx,traveltimes,threadNo) (ttcr/Grid3D.h:470-502) ->
+ * Grid3Drnfs::raytrace (ttcr/Grid3Drnfs.h:84-155) with tt_from_rp = false, and the 2-D
+ * twin Grid2D::raytrace -> Grid2Drnfs::raytrace (ttcr/Grid2Drnfs.h:198-299).
+ * tx: n_tx points (3 or 2 coordinates each) forming ONE source, t0: n_tx origin times,
+ * rx: n_rx receivers, tt_out: n_rx traveltimes (Grid3Drn::getTraveltime, :794-930).
+ * Points outside the grid -> TTCR_ERR_RUNTIME "Error: Point (...) outside grid." */
+int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx,
+                      const void* rx, void* tt_out);
+
+/* Replaces: the multi-source overload Grid3D::raytrace(vector<vector<sxyz>>&...)
+ * (ttcr/Grid3D.h:810-853).  Source n owns tx/t0 rows [tx_off[n], tx_off[n+1]) and rx /
+ * tt_out rows [rx_off[n], rx_off[n+1]).  Sources are block-distributed over the slots
+ * like get_blk_size (ttcr/Grid3D.h:451-465) and solved concurrently on the device. */
+int ttcr_fsm_raytrace_multi(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx,
+                            const void* t0, const int* rx_off, const void* rx, void* tt_out);
+
+/* Replaces: Grid3Drn::getTT(tt, threadNo) (ttcr/Grid3Drn.h:102-108). n = node count. */
+int ttcr_fsm_get_tt(ttcr_fsm_grid* g, int slot, void* out, size_t n);
+/* Device pointer of a slot's traveltime field (stays owned by the grid). */
+int ttcr_fsm_get_tt_device(ttcr_fsm_grid* g, int slot, void** d_ptr);
+
+/* Replaces: Grid3Drn::getTraveltime(pt, nt) (ttcr/Grid3Drn.h:794-930) / 2-D (:359-414). */
+int ttcr_fsm_interp(ttcr_fsm_grid* g, int slot, int n_pts, const void* pts, void* tt_out);
+
+/* Replaces: get_niter()/get_niterw() (ttcr/Grid3Drnfs.h:56-57); per slot here
+ * (the reference keeps one racy value per grid). */
+int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw);
+
+/* Replaces: getNthreads() (ttcr/Grid3D.h) and the node/cell counts of rgrid.pyx:386-404. */
+int ttcr_fsm_n_slots(const ttcr_fsm_grid* g);
+size_t ttcr_fsm_n_nodes(const ttcr_fsm_grid* g);
+size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
+
+/* Tuning / measurement knobs (no reference equivalent):
+ *   "fixed_iters"  > 0: run exactly that many sweep-iterations, ignore eps
+ *   "max_batch"    sources swept concurrently by one launch sequence (default: n_slots)
+ *   "use_graph"    1: replay the per-iteration launch sequence from a hipGraph (default 1) */
+int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
+
+typedef struct {
+    double sweep_ms;        /* HIP-event time of all sweep launches of the last raytrace call   */
+    double total_ms;        /* wall time of the last raytrace call (host clock, incl. copies)  */
+    long long kernel_launches; /* sweep-tile kernel launches in the last call                  */
+    long long node_updates;    /* nodes * 8 (or 4) * iterations, summed over sources           */
+    int iterations;         /* max sweep-iterations over the sources of the last call          */
+    int n_sources;
+} ttcr_fsm_timing;
+int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTCR_AMD_H */

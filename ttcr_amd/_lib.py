@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI declared in include/ttcr_amd.h (libttcr_amd.so).
+
+This is the stub a ttcrpy maintainer would mirror in Cython.  The library
+is the product: if it is missing or has no HIP device, calls fail loudly -- there is no CPU
+or oracle fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libttcr_amd.so")
+
+TTCR_F32, TTCR_F64 = 0, 1
+OK, ERR_VALUE, ERR_RUNTIME, ERR_DEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+
+# every symbol include/ttcr_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_U32 = C.c_uint32
+_D = C.c_double
+_I = C.c_int
+
+
+class Timing(C.Structure):
+    _fields_ = [("sweep_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_longlong),
+                ("node_updates", C.c_longlong), ("iterations", C.c_int), ("n_sources", C.c_int)]
+
+
+SYMBOLS = {
+    "ttcr_fsm_device_count": (_I, []),
+    "ttcr_fsm_last_error": (C.c_char_p, []),
+    "ttcr_fsm3d_create": (_I, [C.POINTER(_P), _I, _I, _U32, _U32, _U32, _D, _D, _D, _D, _D, _I, _I, _I, _I, _I]),
+    "ttcr_fsm2d_create": (_I, [C.POINTER(_P), _I, _I, _U32, _U32, _D, _D, _D, _D, _D, _I, _I, _I, _I, _I]),
+    "ttcr_fsm_destroy": (None, [_P]),
+    "ttcr_fsm_set_slowness": (_I, [_P, _P, C.c_size_t]),
+    "ttcr_fsm_set_slowness_device": (_I, [_P, _P, C.c_size_t]),
+    "ttcr_fsm_get_slowness": (_I, [_P, _P, C.c_size_t]),
+    "ttcr_fsm_raytrace": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "ttcr_fsm_raytrace_multi": (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
+    "ttcr_fsm_get_tt": (_I, [_P, _I, _P, C.c_size_t]),
+    "ttcr_fsm_get_tt_device": (_I, [_P, _I, C.POINTER(_P)]),
+    "ttcr_fsm_interp": (_I, [_P, _I, _I, _P, _P]),
+    "ttcr_fsm_get_niter": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "ttcr_fsm_n_slots": (_I, [_P]),
+    "ttcr_fsm_n_nodes": (C.c_size_t, [_P]),
+    "ttcr_fsm_n_cells": (C.c_size_t, [_P]),
+    "ttcr_fsm_set_option": (_I, [_P, C.c_char_p, _D]),
+    "ttcr_fsm_last_timing": (_I, [_P, C.POINTER(Timing)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libttcr_amd.so (built in-tree by ttcr_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -m ttcr_amd.build). "
+                "ttcr_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().ttcr_fsm_last_error().decode(errors="replace")
+
+
+class UnsupportedError(NotImplementedError):
+    pass
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def check(status):
+    """Map a C status to the exception the reference's Python layer would raise."""
+    if status == OK:
+        return
+    msg = last_error()
+    if status == ERR_VALUE:
+        raise ValueError(msg)
+    if status == ERR_UNSUPPORTED:
+        raise UnsupportedError(msg)
+    if status == ERR_DEVICE:
+        raise DeviceError(msg)
+    raise RuntimeError(msg)  # std::runtime_error / length_error / logic_error via Cython `except +`

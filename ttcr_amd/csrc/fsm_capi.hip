@@ -1,0 +1,721 @@
+// ttcr_amd/csrc/fsm_capi.hip -- host side of the MI355X FSM solver + the C ABI of
+// include/ttcr_amd.h.  Mirrors the *interface* of the reference's Grid3D/Grid2D FSM leaves
+// (ttcr/Grid3Drnfs.h, Grid3Drcfs.h, Grid2Drnfs.h, Grid2Drcfs.h) -- constructor arguments,
+// setSlowness/getTT/raytrace semantics, error messages -- on top of the kernels in
+// fsm_kernels.h.  There is no CPU fallback: without a HIP device every call fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ttcr_amd.h"
+#include "fsm_kernels.h"
+
+namespace ttcr_amd {
+
+static thread_local std::string g_last_error;
+
+struct ValueError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct DeviceError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct Unsupported : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            std::ostringstream _m;                                                               \
+            _m << "HIP error " << hipGetErrorString(_e) << " at " << __FILE__ << ":" << __LINE__ \
+               << " (" #expr ")";                                                                \
+            throw DeviceError(_m.str());                                                         \
+        }                                                                                        \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void reserve(size_t m) {
+        if (m <= n) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        HIP_CHECK(hipMalloc((void**)&p, m * sizeof(T)));
+        n = m;
+    }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+struct Timing {
+    double sweep_ms = 0, total_ms = 0;
+    long long launches = 0, node_updates = 0;
+    int iterations = 0, n_sources = 0;
+};
+
+class GridBase {
+   public:
+    virtual ~GridBase() {}
+    virtual void set_slowness(const void* s, size_t n, bool on_device) = 0;
+    virtual void get_slowness(void* out, size_t n) = 0;
+    virtual void raytrace_multi(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
+                                const void* rx, void* tt_out, int forced_slot) = 0;
+    virtual void get_tt(int slot, void* out, size_t n) = 0;
+    virtual void* tt_device(int slot) = 0;
+    virtual void interp(int slot, int n, const void* pts, void* out) = 0;
+    int dim = 3, dtype = 0, n_slots = 1, device = 0;
+    size_t n_nodes = 0, n_cells = 0;
+    std::vector<int> niter;
+    int fixed_iters = 0, max_batch = 0, use_graph = 1;
+    Timing timing;
+};
+
+// tile shapes (threads = PJ*PK); see DESIGN.md section 4 for the LDS budget
+template <typename T, int DIM> struct TileCfg;
+template <> struct TileCfg<float, 3> { static constexpr int PJ = 16, PK = 16, BL = 16; };
+template <> struct TileCfg<double, 3> { static constexpr int PJ = 16, PK = 8, BL = 16; };
+template <> struct TileCfg<float, 2> { static constexpr int PJ = 128, PK = 1, BL = 32; };
+template <> struct TileCfg<double, 2> { static constexpr int PJ = 128, PK = 1, BL = 32; };
+
+template <typename T>
+class GridT : public GridBase {
+   public:
+    // reference geometry, all in T like the reference members (ttcr/Grid3Drn.h:67-78)
+    uint32_t ncx, ncy, ncz;  // cells; 2-D: ncy = 0
+    T dx, dz, xmin, ymin, zmin, xmax, ymax, zmax, ox = 0, oy = 0, oz = 0;
+    T epsilon;
+    int nitermax;
+    bool cell, translate;
+    bool have_slowness = false;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
+    DevBuf<uint32_t> d_mask;
+    DevBuf<int> d_bbox, d_slots;
+    DevBuf<double> d_change;
+    DevBuf<InitPoint<T>> d_pts;
+    double* h_change = nullptr;  // pinned
+    int* h_slots = nullptr;      // pinned
+    size_t mask_words = 0;
+    SweepGeom geom;
+    int n_launch = 0;  // launches per sweep direction
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_batch = 0;
+
+    GridT(int dim_, bool cell_, uint32_t nx, uint32_t ny, uint32_t nz, double ddx, double ddz, double minx,
+          double miny, double minz, double eps, int maxit, int nslots, bool translate_, int dev) {
+        dim = dim_;
+        dtype = sizeof(T) == 4 ? TTCR_F32 : TTCR_F64;
+        cell = cell_;
+        translate = translate_;
+        ncx = nx; ncy = ny; ncz = nz;
+        dx = (T)ddx;
+        dz = (T)ddz;
+        xmin = (T)minx; ymin = (T)miny; zmin = (T)minz;
+        // xmax(minx+nx*ddx) etc. in T arithmetic (ttcr/Grid3Drn.h:73, ttcr/Grid2Drn.h:62)
+        xmax = xmin + (T)nx * dx;
+        if (dim == 3) {
+            ymax = ymin + (T)ny * dx;
+            zmax = zmin + (T)nz * dx;
+        } else {
+            ymax = ymin;
+            zmax = zmin + (T)nz * dz;
+        }
+        if (translate) {  // buildGridNodes, ttcr/Grid3Drn.h:362-372
+            ox = xmin; oy = ymin; oz = zmin;
+            xmax -= xmin; ymax -= ymin; zmax -= zmin;
+            xmin = 0; ymin = 0; zmin = 0;
+        }
+        n_nodes = dim == 3 ? (size_t)(nx + 1) * (ny + 1) * (nz + 1) : (size_t)(nx + 1) * (nz + 1);
+        n_cells = dim == 3 ? (size_t)nx * ny * nz : (size_t)nx * nz;
+        if (n_nodes >= (1ull << 32)) throw ValueError("grid too large: node index must fit uint32 (reference T2)");
+        epsilon = (T)eps;
+        epsilon *= (T)n_nodes;  // ttcr/Grid3Drnfs.h:49
+        nitermax = maxit;
+        n_slots = nslots;
+        niter.assign(n_slots, 0);
+        max_batch = n_slots;
+        device = dev;
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&ev0));
+        HIP_CHECK(hipEventCreate(&ev1));
+        d_s.reserve(n_nodes);
+        d_tt.reserve(n_nodes * (size_t)n_slots);
+        mask_words = (n_nodes + 31) / 32;
+        d_mask.reserve(mask_words * (size_t)n_slots);
+        d_bbox.reserve(6 * (size_t)n_slots);
+        d_slots.reserve(n_slots);
+        d_change.reserve(n_slots);
+        HIP_CHECK(hipHostMalloc((void**)&h_change, sizeof(double) * n_slots));
+        HIP_CHECK(hipHostMalloc((void**)&h_slots, sizeof(int) * n_slots));
+        HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_slots * sizeof(T), stream));
+
+        if (dim == 3) {
+            using C = TileCfg<T, 3>;
+            geom.NF = nx + 1; geom.NJ = ny + 1; geom.NK = nz + 1;
+            geom.npj = (geom.NJ + C::PJ - 1) / C::PJ;
+            geom.npk = (geom.NK + C::PK - 1) / C::PK;
+            n_launch = count_launches(C::BL);
+        } else {  // F = z (fastest), J = x
+            using C = TileCfg<T, 2>;
+            geom.NF = nz + 1; geom.NJ = nx + 1; geom.NK = 1;
+            geom.npj = (geom.NJ + C::PJ - 1) / C::PJ;
+            geom.npk = 1;
+            n_launch = count_launches(C::BL);
+        }
+        geom.n_nodes = (uint32_t)n_nodes;
+    }
+
+    ~GridT() override {
+        (void)hipSetDevice(device);
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (h_change) (void)hipHostFree(h_change);
+        if (h_slots) (void)hipHostFree(h_slots);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int count_launches(int BL) const {
+        const int Lhi = (geom.NJ - 1) + (geom.NK - 1) + geom.NF - 1;
+        const int m = geom.npj + geom.npk - 2;
+        return (Lhi + m * (BL - 1)) / BL + 1;
+    }
+
+    // ---- slowness ---------------------------------------------------------------------
+    void set_slowness(const void* s, size_t n, bool on_device) override {
+        HIP_CHECK(hipSetDevice(device));
+        const size_t expect = cell ? n_cells : n_nodes;
+        if (n != expect) throw std::length_error("Error: slowness vectors of incompatible size.");
+        const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (!cell) {
+            HIP_CHECK(hipMemcpyAsync(d_s.p, s, n * sizeof(T), kind, stream));
+        } else {
+            d_cells.reserve(n_cells);
+            HIP_CHECK(hipMemcpyAsync(d_cells.p, s, n * sizeof(T), kind, stream));
+            const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 4096);
+            if (dim == 3)
+                fsm_cells_to_nodes3d<T><<<blocks, 256, 0, stream>>>(d_cells.p, d_s.p, (int)ncx, (int)ncy, (int)ncz);
+            else
+                fsm_cells_to_nodes2d<T><<<blocks, 256, 0, stream>>>(d_cells.p, d_s.p, (int)ncx, (int)ncz);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        have_slowness = true;
+    }
+
+    void get_slowness(void* out, size_t n) override {
+        HIP_CHECK(hipSetDevice(device));
+        if (n != n_nodes) throw std::length_error("Error: slowness vectors of incompatible size.");
+        HIP_CHECK(hipMemcpyAsync(out, d_s.p, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    void get_tt(int slot, void* out, size_t n) override {
+        HIP_CHECK(hipSetDevice(device));
+        check_slot(slot);
+        if (n != n_nodes) throw ValueError("traveltime buffer has wrong size");
+        HIP_CHECK(hipMemcpyAsync(out, d_tt.p + (size_t)slot * n_nodes, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    void* tt_device(int slot) override {
+        check_slot(slot);
+        return d_tt.p + (size_t)slot * n_nodes;
+    }
+
+    void check_slot(int slot) const {
+        if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
+    }
+
+    // ---- points -----------------------------------------------------------------------
+    int ncoord() const { return dim == 3 ? 3 : 2; }
+
+    // Grid3Drn::checkPts (ttcr/Grid3Drn.h:771-790) / Grid2Drn::checkPts (ttcr/Grid2Drn.h:333-342)
+    void check_pts(const T* p, int n) const {
+        for (int m = 0; m < n; ++m) {
+            if (dim == 3) {
+                const T x = p[3 * m], y = p[3 * m + 1], z = p[3 * m + 2];
+                if (x < xmin || x > xmax || y < ymin || y > ymax || z < zmin || z > zmax) {
+                    std::ostringstream msg;
+                    msg << "Error: Point (" << x << ' ' << y << ' ' << z << ") outside grid.";
+                    throw std::runtime_error(msg.str());
+                }
+            } else {
+                const T x = p[2 * m], z = p[2 * m + 1];
+                if (x < xmin || x > xmax || z < zmin || z > zmax) {
+                    std::ostringstream msg;
+                    msg << "Error: Point (" << x << ", " << z << ") outside grid.";
+                    throw std::runtime_error(msg.str());
+                }
+            }
+        }
+    }
+
+    static T node_coord_h(T cmin, uint32_t n, T d) { return cmin + (T)n * d; }
+
+    // first node index whose coordinate is within `small` of v (Node3Dn::operator==,
+    // ttcr/Node3Dn.h:147-149, scanned in increasing order like initFSM's linear search)
+    int first_match(T cmin, T d, uint32_t nn, T v) const {
+        const double small = 1.e-4;
+        // candidates around the nearest node; scan a window that covers every possible match
+        double est = ((double)v - (double)cmin) / (double)d;
+        long c = (long)std::floor(est);
+        long span = (long)std::ceil(small / std::fabs((double)d)) + 2;
+        long lo = std::max<long>(0, c - span), hi = std::min<long>((long)nn - 1, c + span + 1);
+        for (long i = lo; i <= hi; ++i) {
+            const T diff = node_coord_h(cmin, (uint32_t)i, d) - v;
+            if ((double)(diff < 0 ? -diff : diff) < small) return (int)i;
+        }
+        return -1;
+    }
+
+    InitPoint<T> locate(const T* p, T t0) const {
+        InitPoint<T> q;
+        std::memset(&q, 0, sizeof(q));
+        q.t0 = t0;
+        if (dim == 3) {
+            q.x = p[0]; q.y = p[1]; q.z = p[2];
+            const int fi = first_match(xmin, dx, ncx + 1, q.x);
+            const int fj = first_match(ymin, dx, ncy + 1, q.y);
+            const int fk = first_match(zmin, dx, ncz + 1, q.z);
+            if (fi >= 0 && fj >= 0 && fk >= 0) {
+                q.on_node = 1; q.i = fi; q.j = fj; q.k = fk;
+            } else {
+                // Grid3Drn::getCellNo (ttcr/Grid3Drn.h:207-215) + decomposition (:3530-3534)
+                const double small2 = 1.e-4 * 1.e-4;
+                const T x = (double)(xmax - q.x) < small2 ? (T)((double)xmax - .5 * (double)dx) : q.x;
+                const T y = (double)(ymax - q.y) < small2 ? (T)((double)ymax - .5 * (double)dx) : q.y;
+                const T z = (double)(zmax - q.z) < small2 ? (T)((double)zmax - .5 * (double)dx) : q.z;
+                const uint32_t nx = (uint32_t)(small2 + (double)((x - xmin) / dx));
+                const uint32_t ny = (uint32_t)(small2 + (double)((y - ymin) / dx));
+                const uint32_t nz = (uint32_t)(small2 + (double)((z - zmin) / dx));
+                const uint32_t cellNo = ny * ncx + nz * (ncx * ncy) + nx;
+                const long c = (long)cellNo;
+                const long k = c / ((long)ncy * ncx);
+                const long j = (c - k * (long)ncy * ncx) / ncx;
+                q.i = (int)(c - (k * (long)ncy + j) * ncx);
+                q.j = (int)j;
+                q.k = (int)k;
+            }
+        } else {
+            q.x = p[0]; q.z = p[1]; q.y = 0;
+            const int fi = first_match(xmin, dx, ncx + 1, q.x);
+            const int fk = first_match(zmin, dz, ncz + 1, q.z);
+            if (fi >= 0 && fk >= 0) {
+                q.on_node = 1; q.i = fi; q.k = fk;
+            } else {
+                // Grid2Drn::getCellNo uses `small` (ttcr/Grid2Drn.h:173-179)
+                const double small = 1.e-4;
+                const T x = (double)(xmax - q.x) < small ? (T)((double)xmax - .5 * (double)dx) : q.x;
+                const T z = (double)(zmax - q.z) < small ? (T)((double)zmax - .5 * (double)dz) : q.z;
+                const uint32_t nx = (uint32_t)(small + (double)((x - xmin) / dx));
+                const uint32_t nz = (uint32_t)(small + (double)((z - zmin) / dz));
+                const long c = (long)(uint32_t)(nx * ncz + nz);
+                q.i = (int)(c / ncz);
+                q.k = (int)(c - (long)q.i * ncz);
+            }
+        }
+        return q;
+    }
+
+    // ---- sweeps -----------------------------------------------------------------------
+    template <int DIM>
+    void launch_sweeps(int batch) {
+        using C = TileCfg<T, DIM>;
+        SweepArgs<T> a;
+        a.tt = d_tt.p;
+        a.slowness = d_s.p;
+        a.frozen = d_mask.p;
+        a.bbox = d_bbox.p;
+        a.change = d_change.p;
+        a.slots = d_slots.p;
+        a.g = geom;
+        a.mask_words = (uint32_t)mask_words;
+        a.dx = dx;
+        a.dz = dz;
+        a.variant = DIM == 3 ? 0 : (dx == dz ? 1 : 2);
+        const dim3 grid(geom.npj, geom.npk, batch), block(C::PJ * C::PK);
+        const int ndir = DIM == 3 ? 8 : 4;
+        // 2-D direction order (i+,j+), (i-,j+), (i-,j-), (i+,j-)  (ttcr/Grid2Drn.h:717-751);
+        // here F = z (the reference's j), J = x (the reference's i)
+        static const int RX2[4] = {0, 1, 1, 0}, RZ2[4] = {0, 0, 1, 1};
+        for (int d = 0; d < ndir; ++d) {
+            if (DIM == 3) {
+                a.rf = d & 1; a.rj = (d >> 1) & 1; a.rk = (d >> 2) & 1;  // ttcr/Grid3Drn.h:2816-2899
+            } else {
+                a.rj = RX2[d]; a.rf = RZ2[d]; a.rk = 0;
+            }
+            for (int w = 0; w < n_launch; ++w) {
+                a.w = w;
+                fsm_sweep_tile<T, C::PJ, C::PK, C::BL, DIM == 3><<<grid, block, 0, stream>>>(a);
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+    }
+
+    void run_iteration(int batch) {
+        const int ndir = dim == 3 ? 8 : 4;
+        if (use_graph) {
+            if (!graph_exec || graph_batch != batch) {
+                if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+                if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+                HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    if (dim == 3) launch_sweeps<3>(batch); else launch_sweeps<2>(batch);
+                } catch (...) {
+                    hipGraph_t junk = nullptr;
+                    (void)hipStreamEndCapture(stream, &junk);
+                    if (junk) (void)hipGraphDestroy(junk);
+                    throw;
+                }
+                HIP_CHECK(hipStreamEndCapture(stream, &graph));
+                HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+                graph_batch = batch;
+            }
+            HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+        } else {
+            if (dim == 3) launch_sweeps<3>(batch); else launch_sweeps<2>(batch);
+        }
+        timing.launches += (long long)ndir * n_launch;
+    }
+
+    // One batch: sources src_ids[b] solved concurrently, source b in slot slot_ids[b].
+    void solve_batch(const std::vector<int>& slot_ids, const std::vector<int>& src_ids, const int* tx_off,
+                     const T* tx, const T* t0) {
+        const int nb = (int)slot_ids.size();
+        const int nc = ncoord();
+        // reinit + initFSM (ttcr/Grid3Drnfs.h:92-100)
+        size_t tot_pts = 0;
+        for (int b = 0; b < nb; ++b) tot_pts += tx_off[src_ids[b] + 1] - tx_off[src_ids[b]];
+        std::vector<InitPoint<T>> pts;
+        pts.reserve(tot_pts);
+        std::vector<size_t> first(nb);
+        for (int b = 0; b < nb; ++b) {
+            first[b] = pts.size();
+            for (int n = tx_off[src_ids[b]]; n < tx_off[src_ids[b] + 1]; ++n) pts.push_back(locate(tx + (size_t)nc * n, t0[n]));
+        }
+        d_pts.reserve(std::max<size_t>(tot_pts, 1));
+        HIP_CHECK(hipMemcpyAsync(d_pts.p, pts.data(), pts.size() * sizeof(InitPoint<T>), hipMemcpyHostToDevice, stream));
+        for (int b = 0; b < nb; ++b) {
+            const int slot = slot_ids[b];
+            T* tt = d_tt.p + (size_t)slot * n_nodes;
+            const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
+            fsm_fill<T><<<blocks, 256, 0, stream>>>(tt, n_nodes, real_traits<T>::max());
+            HIP_CHECK(hipMemsetAsync(d_mask.p + (size_t)slot * mask_words, 0, mask_words * sizeof(uint32_t), stream));
+            InitArgs<T> ia;
+            ia.tt = tt;
+            ia.slowness = d_s.p;
+            ia.frozen = d_mask.p + (size_t)slot * mask_words;
+            ia.bbox = d_bbox.p + 6 * (size_t)slot;
+            ia.pts = d_pts.p + first[b];
+            ia.n_pts = tx_off[src_ids[b] + 1] - tx_off[src_ids[b]];
+            ia.npts = 1;
+            ia.nnx = ncx + 1;
+            ia.nny = dim == 3 ? ncy + 1 : 1;
+            ia.nnz = ncz + 1;
+            ia.dx = dx; ia.dz = dz; ia.xmin = xmin; ia.ymin = ymin; ia.zmin = zmin;
+            ia.dim = dim;
+            fsm_init_source<T><<<1, 128, 0, stream>>>(ia);
+            niter[slot] = 0;
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream));  // pts vector goes out of scope below; also surfaces errors early
+
+        // driver loop of Grid3Drnfs::raytrace (ttcr/Grid3Drnfs.h:137-153), per source
+        std::vector<int> active(slot_ids);
+        const int maxit = fixed_iters > 0 ? fixed_iters : nitermax;
+        int it = 0;
+        const int ndir = dim == 3 ? 8 : 4;
+        // the graph is built for a fixed z-extent; finished sources are masked with slot -1 ... but
+        // a masked block still has to read slots[z], so keep the list compact and pad with -1.
+        HIP_CHECK(hipEventRecord(ev0, stream));
+        while (!active.empty() && it < maxit) {
+            for (int b = 0; b < nb; ++b) h_slots[b] = b < (int)active.size() ? active[b] : -1;
+            HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * nb, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
+            run_iteration(nb);
+            HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            ++it;
+            std::vector<int> next;
+            for (int s : active) {
+                niter[s] = it;
+                timing.node_updates += (long long)n_nodes * ndir;
+                const bool go_on = fixed_iters > 0 ? true : (h_change[s] >= (double)epsilon);
+                if (go_on) next.push_back(s);
+            }
+            active.swap(next);
+        }
+        HIP_CHECK(hipEventRecord(ev1, stream));
+        HIP_CHECK(hipEventSynchronize(ev1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        timing.sweep_ms += ms;
+        timing.iterations = std::max(timing.iterations, it);
+    }
+
+    void interp(int slot, int n, const void* pts, void* out) override {
+        HIP_CHECK(hipSetDevice(device));
+        check_slot(slot);
+        if (n <= 0) return;
+        const int nc = ncoord();
+        std::vector<T> p((const T*)pts, (const T*)pts + (size_t)nc * n);
+        if (translate)
+            for (int m = 0; m < n; ++m) { p[3 * m] -= ox; p[3 * m + 1] -= oy; p[3 * m + 2] -= oz; }
+        check_pts(p.data(), n);
+        interp_grid_coords(slot, n, p.data(), (T*)out);
+    }
+
+    void interp_grid_coords(int slot, int n, const T* p, T* out) {
+        if (n <= 0) return;
+        const int nc = ncoord();
+        d_rx.reserve((size_t)nc * n);
+        d_out.reserve(n);
+        HIP_CHECK(hipMemcpyAsync(d_rx.p, p, sizeof(T) * nc * n, hipMemcpyHostToDevice, stream));
+        const T* tt = d_tt.p + (size_t)slot * n_nodes;
+        const int blocks = (n + 127) / 128;
+        if (dim == 3)
+            fsm_interp3d<T><<<blocks, 128, 0, stream>>>(tt, d_rx.p, d_out.p, n, (int)ncx + 1, (int)ncy + 1, dx, xmin, ymin, zmin);
+        else
+            fsm_interp2d<T><<<blocks, 128, 0, stream>>>(tt, d_rx.p, d_out.p, n, (int)ncz + 1, dx, dz, xmin, zmin);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    // Grid3D::raytrace multi-source overload (ttcr/Grid3D.h:810-853)
+    void raytrace_multi(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off,
+                        const void* rx_v, void* tt_out_v, int forced_slot) override {
+        HIP_CHECK(hipSetDevice(device));
+        const auto wall0 = std::chrono::steady_clock::now();
+        timing = Timing();
+        timing.n_sources = n_src;
+        if (!have_slowness) throw std::runtime_error("Error: slowness has not been assigned.");
+        if (n_src <= 0) return;
+        if (forced_slot >= 0) {
+            check_slot(forced_slot);
+            if (n_src != 1) throw ValueError("a thread number can only be given for a single source");
+        }
+        const int nc = ncoord();
+        const int n_tx = tx_off[n_src], n_rx = rx_off[n_src];
+        std::vector<T> tx((const T*)tx_v, (const T*)tx_v + (size_t)nc * n_tx);
+        std::vector<T> rx((const T*)rx_v, (const T*)rx_v + (size_t)nc * n_rx);
+        const T* t0 = (const T*)t0_v;
+        T* tt_out = (T*)tt_out_v;
+        if (translate) {  // Grid3D::raytrace subtracts the origin (ttcr/Grid3D.h:478-485)
+            for (int m = 0; m < n_tx; ++m) { tx[3 * m] -= ox; tx[3 * m + 1] -= oy; tx[3 * m + 2] -= oz; }
+            for (int m = 0; m < n_rx; ++m) { rx[3 * m] -= ox; rx[3 * m + 1] -= oy; rx[3 * m + 2] -= oz; }
+        }
+        for (int n = 0; n < n_src; ++n) {
+            if (tx_off[n + 1] <= tx_off[n]) throw ValueError("every source needs at least one point");
+            check_pts(tx.data() + (size_t)nc * tx_off[n], tx_off[n + 1] - tx_off[n]);
+            check_pts(rx.data() + (size_t)nc * rx_off[n], rx_off[n + 1] - rx_off[n]);
+        }
+        // block distribution of the sources over the slots: get_blk_size (ttcr/Grid3D.h:451-465)
+        const int n_blk = std::min(n_slots, n_src);
+        std::vector<int> blk(n_blk, 0);
+        for (int n = 0; n < n_src; ++n) blk[n % n_blk] += 1;
+        std::vector<int> start(n_blk, 0);
+        for (int b = 1; b < n_blk; ++b) start[b] = start[b - 1] + blk[b - 1];
+        const int rounds = *std::max_element(blk.begin(), blk.end());
+        const int mb = std::max(1, std::min(max_batch > 0 ? max_batch : n_slots, n_slots));
+        for (int r = 0; r < rounds; ++r) {
+            std::vector<int> slots, srcs;
+            for (int b = 0; b < n_blk; ++b)
+                if (r < blk[b]) { slots.push_back(forced_slot >= 0 ? forced_slot : b); srcs.push_back(start[b] + r); }
+            for (size_t c0 = 0; c0 < slots.size(); c0 += mb) {
+                const size_t c1 = std::min(slots.size(), c0 + mb);
+                std::vector<int> sl(slots.begin() + c0, slots.begin() + c1), sr(srcs.begin() + c0, srcs.begin() + c1);
+                solve_batch(sl, sr, tx_off, tx.data(), t0);
+                for (size_t b = 0; b < sl.size(); ++b) {
+                    const int n = sr[b];
+                    interp_grid_coords(sl[b], rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n]);
+                }
+            }
+        }
+        timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+};
+
+}  // namespace ttcr_amd
+
+// =============================================================================== C ABI
+using namespace ttcr_amd;
+
+struct ttcr_fsm_grid {
+    std::unique_ptr<GridBase> impl;
+};
+
+template <typename F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return TTCR_OK;
+    } catch (const ValueError& e) {
+        g_last_error = e.what();
+        return TTCR_ERR_VALUE;
+    } catch (const DeviceError& e) {
+        g_last_error = e.what();
+        return TTCR_ERR_DEVICE;
+    } catch (const Unsupported& e) {
+        g_last_error = e.what();
+        return TTCR_ERR_UNSUPPORTED;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return TTCR_ERR_RUNTIME;
+    }
+}
+
+static int pick_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        throw DeviceError("no HIP device available: the MI355X FSM backend has no CPU fallback");
+    if (device < 0) {
+        int cur = 0;
+        HIP_CHECK(hipGetDevice(&cur));
+        return cur;
+    }
+    if (device >= n) throw ValueError("device ordinal out of range");
+    return device;
+}
+
+extern "C" {
+
+int ttcr_fsm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* ttcr_fsm_last_error(void) { return g_last_error.c_str(); }
+
+int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz,
+                      double dx, double xmin, double ymin, double zmin, double eps, int maxit, int weno, int n_slots,
+                      int translate_origin, int device) {
+    return guarded([&] {
+        if (!out) throw ValueError("null output handle");
+        *out = nullptr;
+        if (dtype != TTCR_F32 && dtype != TTCR_F64) throw ValueError("dtype must be TTCR_F32 or TTCR_F64");
+        if (ncx < 1 || ncy < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
+        if (n_slots < 1) throw ValueError("n_slots must be >= 1");
+        if (!(dx > 0)) throw ValueError("dx must be positive");
+        if (weno) throw Unsupported("weno=True (third-order WENO stage, ttcr/Grid3Drn.h:2962-3484) is not built yet; use weno=False");
+        const int dev = pick_device(device);
+        auto g = std::make_unique<ttcr_fsm_grid>();
+        if (dtype == TTCR_F32)
+            g->impl.reset(new GridT<float>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev));
+        else
+            g->impl.reset(new GridT<double>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev));
+        *out = g.release();
+    });
+}
+
+int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncz, double dx, double dz,
+                      double xmin, double zmin, double eps, int maxit, int weno, int rotated_template, int n_slots, int device) {
+    return guarded([&] {
+        if (!out) throw ValueError("null output handle");
+        *out = nullptr;
+        if (dtype != TTCR_F32 && dtype != TTCR_F64) throw ValueError("dtype must be TTCR_F32 or TTCR_F64");
+        if (ncx < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
+        if (n_slots < 1) throw ValueError("n_slots must be >= 1");
+        if (!(dx > 0) || !(dz > 0)) throw ValueError("dx and dz must be positive");
+        if (weno) throw Unsupported("weno=True (third-order WENO stage, ttcr/Grid2Drn.h:838-917) is not built yet; use weno=False");
+        if (rotated_template) throw Unsupported("rotated_template=True (sweep45, ttcr/Grid2Drn.h:756-794) is not built yet");
+        const int dev = pick_device(device);
+        auto g = std::make_unique<ttcr_fsm_grid>();
+        if (dtype == TTCR_F32)
+            g->impl.reset(new GridT<float>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev));
+        else
+            g->impl.reset(new GridT<double>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev));
+        *out = g.release();
+    });
+}
+
+void ttcr_fsm_destroy(ttcr_fsm_grid* g) { delete g; }
+
+int ttcr_fsm_set_slowness(ttcr_fsm_grid* g, const void* s, size_t n) {
+    return guarded([&] { g->impl->set_slowness(s, n, false); });
+}
+int ttcr_fsm_set_slowness_device(ttcr_fsm_grid* g, const void* d_s, size_t n) {
+    return guarded([&] { g->impl->set_slowness(d_s, n, true); });
+}
+int ttcr_fsm_get_slowness(ttcr_fsm_grid* g, void* out, size_t n) {
+    return guarded([&] { g->impl->get_slowness(out, n); });
+}
+
+int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                      void* tt_out) {
+    return guarded([&] {
+        if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
+        const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
+        g->impl->raytrace_multi(1, tx_off, tx, t0, rx_off, rx, tt_out, slot);
+    });
+}
+
+int ttcr_fsm_raytrace_multi(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0,
+                            const int* rx_off, const void* rx, void* tt_out) {
+    return guarded([&] { g->impl->raytrace_multi(n_src, tx_off, tx, t0, rx_off, rx, tt_out, -1); });
+}
+
+int ttcr_fsm_get_tt(ttcr_fsm_grid* g, int slot, void* out, size_t n) {
+    return guarded([&] { g->impl->get_tt(slot, out, n); });
+}
+int ttcr_fsm_get_tt_device(ttcr_fsm_grid* g, int slot, void** d_ptr) {
+    return guarded([&] { *d_ptr = g->impl->tt_device(slot); });
+}
+int ttcr_fsm_interp(ttcr_fsm_grid* g, int slot, int n_pts, const void* pts, void* tt_out) {
+    return guarded([&] { g->impl->interp(slot, n_pts, pts, tt_out); });
+}
+int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw) {
+    return guarded([&] {
+        if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
+        if (niter) *niter = g->impl->niter[slot];
+        if (niterw) *niterw = 0;
+    });
+}
+int ttcr_fsm_n_slots(const ttcr_fsm_grid* g) { return g->impl->n_slots; }
+size_t ttcr_fsm_n_nodes(const ttcr_fsm_grid* g) { return g->impl->n_nodes; }
+size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g) { return g->impl->n_cells; }
+
+int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
+    return guarded([&] {
+        const std::string k(key ? key : "");
+        if (k == "fixed_iters") g->impl->fixed_iters = (int)value;
+        else if (k == "max_batch") g->impl->max_batch = (int)value;
+        else if (k == "use_graph") g->impl->use_graph = value != 0;
+        else throw ValueError("unknown option '" + k + "'");
+    });
+}
+
+int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out) {
+    return guarded([&] {
+        const Timing& t = g->impl->timing;
+        out->sweep_ms = t.sweep_ms;
+        out->total_ms = t.total_ms;
+        out->kernel_launches = t.launches;
+        out->node_updates = t.node_updates;
+        out->iterations = t.iterations;
+        out->n_sources = t.n_sources;
+    });
+}
+
+}  // extern "C"

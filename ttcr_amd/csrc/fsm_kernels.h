@@ -1,0 +1,607 @@
+// ttcr_amd/csrc/fsm_kernels.h -- CDNA4 (gfx950) kernels of the fast-sweeping eikonal solver.
+//
+// What the reference does (ttcr/Grid3Drn.h:2816-2959, ttcr/Grid2Drn.h:713-954): in-place
+// Gauss-Seidel sweeps in 8 (3-D) / 4 (2-D) lexicographic directions; each node solves a
+// local first-order Godunov quadratic from the minima of its axis neighbours.
+//
+// How it is done here (not a port): a sweep in direction d is a partial order -- node
+// (i',j',k') (indices oriented along d) needs its three upwind neighbours already updated
+// and its three downwind neighbours not yet.  Any linear extension of that order gives the
+// serial result bit for bit.  We use a *skewed pencil march*:
+//
+//   * level  L = i' + j' + k'   (i' is the memory-contiguous axis)
+//   * a workgroup owns a PJ x PK patch of (j',k') columns; thread (tj,tk) owns one column and
+//     at level L updates its node i' = L - j' - k'.  All threads of a level are independent,
+//     so a patch advances one level per step with PJ*PK-way parallelism and no ramp.
+//   * a launch processes, for every patch, one TILE of BL consecutive levels.  Patch
+//     m = TJ+TK gets the level window [BL*w - m*(BL-1), +BL) in launch w: with that shift a
+//     tile depends only on tiles of launch w-1 (own previous window and the two upwind
+//     patches), and every tile it could race with is provably disjoint, so
+//     all tiles of a launch run concurrently with no inter-workgroup communication.
+//   * the tile (own columns + 1-column halo, BL+2 levels) is staged in LDS in skewed form:
+//     row = column, entry q = level, so global loads/stores run along i (coalesced, rows are
+//     contiguous in HBM) while the march reads one LDS column per level (conflict-free,
+//     odd row stride).
+//   * convergence: each thread accumulates the decrease of its nodes in fp64; a __shfl_down
+//     wavefront reduction + one atomicAdd per wave gives sum|T_old-T_new| of the iteration
+//     (updates only ever decrease T, so the per-sweep decreases telescope to the L1 change the
+//     reference computes from a snapshot, ttcr/Grid3Drnfs.h:141-152) without a snapshot array.
+//   * a tile that changed nothing skips its write-back.
+//
+// Arithmetic mirrors the reference exactly (see update3/update2): for float grids the
+// quadratic branches are evaluated in double and rounded once, because the reference's double
+// literals promote them.  Compile with -ffp-contract=off: fused a1+s*dx would change rounding;
+// the fma() calls below are deliberate (the products are exact in double, so fma(x,y,acc) ==
+// round(x*y+acc) == the reference's separately rounded add).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ttcr_amd {
+
+template <typename T> struct real_traits;
+template <> struct real_traits<float> {
+    static __host__ __device__ constexpr float max() { return 3.402823466e+38f; }
+    static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+};
+template <> struct real_traits<double> {
+    static __host__ __device__ constexpr double max() { return 1.7976931348623157e+308; }
+    static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+};
+
+__device__ __forceinline__ float rmin(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ double rmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ float rmax(float a, float b) { return a < b ? b : a; }
+__device__ __forceinline__ double rmax(double a, double b) { return a < b ? b : a; }
+
+// ---- 3-D local solver: Grid3Drn::update_node, ttcr/Grid3Drn.h:2936-2956 -------------------
+// inputs: the three axis minima (any order), node slowness s, cell size dx. Returns candidate t.
+__device__ __forceinline__ float update3(float ax, float ay, float az, float s, float dx) {
+    // sort (std::swap network of :2936-2938; values only, so min/max is equivalent)
+    const float lo = rmin(rmin(ax, ay), az);
+    const float hi = rmax(rmax(ax, ay), az);
+    const float mid = rmax(rmin(ax, ay), rmin(rmax(ax, ay), az));
+    const float a1 = lo, a2 = mid, a3 = hi;
+    const float fh = s * dx;
+    float t = a1 + fh;
+    if (t > a2) {
+        const double d1 = a1, d2 = a2, dfh = fh;
+        // 2.*fh*fh - (a1-a2)*(a1-a2): product exact in double, (a1-a2)^2 rounded in float
+        const float df = a1 - a2;
+        const float df2 = df * df;
+        const double disc2 = __builtin_fma(2.0 * dfh, dfh, -(double)df2);
+        const float s12 = a1 + a2;
+        t = (float)(0.5 * ((double)s12 + __builtin_sqrt(disc2)));
+        if (t > a3) {
+            const double d3 = a3;
+            // -2.*a1*a1 + 2.*a1*a2 - 2.*a2*a2 + 2.*a1*a3 + 2.*a2*a3 - 2.*a3*a3 + 3.*fh*fh,
+            // left to right; every product is exact in double, each fma rounds once like the add
+            double r = (-2.0 * d1) * d1;
+            r = __builtin_fma(2.0 * d1, d2, r);
+            r = __builtin_fma(-2.0 * d2, d2, r);
+            r = __builtin_fma(2.0 * d1, d3, r);
+            r = __builtin_fma(2.0 * d2, d3, r);
+            r = __builtin_fma(-2.0 * d3, d3, r);
+            r = __builtin_fma(3.0 * dfh, dfh, r);
+            const float s123 = s12 + a3;
+            t = (float)((1. / 3.) * ((double)s123 + __builtin_sqrt(r)));
+        }
+    }
+    return t;
+}
+
+__device__ __forceinline__ double update3(double ax, double ay, double az, double s, double dx) {
+    const double a1 = rmin(rmin(ax, ay), az);
+    const double a3 = rmax(rmax(ax, ay), az);
+    const double a2 = rmax(rmin(ax, ay), rmin(rmax(ax, ay), az));
+    const double fh = s * dx;
+    double t = a1 + fh;
+    if (t > a2) {
+        t = 0.5 * (a1 + a2 + __builtin_sqrt(2. * fh * fh - (a1 - a2) * (a1 - a2)));
+        if (t > a3) {
+            t = 1. / 3. * ((a1 + a2 + a3) + __builtin_sqrt(-2. * a1 * a1 + 2. * a1 * a2 - 2. * a2 * a2 +
+                                                            2. * a1 * a3 + 2. * a2 * a3 -
+                                                            2. * a3 * a3 + 3. * fh * fh));
+        }
+    }
+    return t;
+}
+
+// ---- 2-D local solvers ---------------------------------------------------------------------
+// Grid2Drn::update_node, ttcr/Grid2Drn.h:945-950 (square cells). a: x-axis minimum, b: z-axis.
+__device__ __forceinline__ float update2(float a, float b, float s, float dx) {
+    const float fh = s * dx;
+    const float d = a - b;
+    if (__builtin_fabsf(d) >= fh) return (a < b ? a : b) + fh;
+    const float d2 = d * d;
+    const double dfh = fh;
+    const double disc = __builtin_fma(2.0 * dfh, dfh, -(double)d2);
+    const float sab = a + b;
+    return (float)(0.5 * ((double)sab + __builtin_sqrt(disc)));
+}
+__device__ __forceinline__ double update2(double a, double b, double s, double dx) {
+    const double fh = s * dx;
+    if (__builtin_fabs(a - b) >= fh) return (a < b ? a : b) + fh;
+    return 0.5 * (a + b + __builtin_sqrt(2. * fh * fh - (a - b) * (a - b)));
+}
+
+// Grid2Drn::update_node_xz, ttcr/Grid2Drn.h:1041-1054 (dx != dz)
+__device__ __forceinline__ float update2_xz(float a, float b, float sn, float dx, float dz) {
+    if (a < b && ((b - a) / dx) > sn) return a + sn * dx;
+    if (a > b && ((a - b) / dz) > sn) return b + sn * dz;
+    const float dx2 = dx * dx, dz2 = dz * dz, s2 = sn * sn;
+    // 2.0*a*b*dx2*dz2 is a double chain; the other four terms are float chains, promoted on use
+    const double t1 = (((2.0 * (double)a) * (double)b) * (double)dx2) * (double)dz2;
+    const float t2 = ((a * a) * dx2) * dz2;
+    const float t3 = ((b * b) * dx2) * dz2;
+    const float t4 = ((dx2 * dx2) * dz2) * s2;
+    const float t5 = ((dx2 * dz2) * dz2) * s2;
+    const double num = (((t1 - (double)t2) - (double)t3) + (double)t4) + (double)t5;
+    const float den = (dx2 + dz2) * (dx2 + dz2);
+    const float lin = (b * dx2 + a * dz2) / (dx2 + dz2);
+    return (float)((double)lin + __builtin_sqrt(num / (double)den));
+}
+__device__ __forceinline__ double update2_xz(double a, double b, double sn, double dx, double dz) {
+    if (a < b && ((b - a) / dx) > sn) return a + sn * dx;
+    if (a > b && ((a - b) / dz) > sn) return b + sn * dz;
+    const double dx2 = dx * dx, dz2 = dz * dz, s2 = sn * sn;
+    return (b * dx2 + a * dz2) / (dx2 + dz2) +
+           __builtin_sqrt((2.0 * a * b * dx2 * dz2 - a * a * dx2 * dz2 - b * b * dx2 * dz2 + dx2 * dx2 * dz2 * s2 +
+                           dx2 * dz2 * dz2 * s2) /
+                          ((dx2 + dz2) * (dx2 + dz2)));
+}
+
+// ---- sweep-tile kernel ---------------------------------------------------------------------
+// Unified 3-D / 2-D geometry: "fast" axis F (memory stride 1), "mid" axis J (stride NF),
+// "slow" axis K (stride NF*NJ).  3-D: F=x, J=y, K=z.  2-D (z-fastest): F=z, J=x, NK=1.
+struct SweepGeom {
+    int NF, NJ, NK;        // node counts
+    int npj, npk;          // patches along J and K
+    uint32_t n_nodes;      // NF*NJ*NK
+};
+
+template <typename T>
+struct SweepArgs {
+    T* tt;                    // [n_slots][n_nodes] traveltime fields
+    const T* slowness;        // [n_nodes] node slowness
+    const uint32_t* frozen;   // [n_slots][mask_words] frozen bit per node
+    const int* bbox;          // [n_slots][6] natural-index bounding box of frozen nodes (lo/hi per F,J,K)
+    double* change;           // [n_slots] L1 decrease accumulated over the iteration
+    const int* slots;         // [batch] slot handled by blockIdx.z
+    SweepGeom g;
+    uint32_t mask_words;
+    T dx, dz;                 // cell size along J-axis(x)/F-axis(z) in 2-D; dx only in 3-D
+    int rf, rj, rk;           // 1: axis swept in decreasing index
+    int w;                    // launch index within the sweep
+    int variant;              // 0: 3-D, 1: 2-D square cells, 2: 2-D dx != dz
+};
+
+template <typename T, int PJ, int PK, int BL, bool IS3D>
+__global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
+    constexpr int NT = PJ * PK;
+    constexpr int RJ = PJ + 2;                      // tile rows along J incl. halo
+    constexpr int NROWS = IS3D ? RJ * (PK + 2) : RJ;
+    constexpr int NQ = BL + 2;                      // levels incl. halo
+    constexpr int RS = NQ | 1;                      // odd LDS row stride (bank-conflict-free column reads)
+    constexpr int SS = BL | 1;
+    static_assert(IS3D || PK == 1, "2-D uses PK = 1");
+
+    __shared__ T Tt[NROWS * RS];
+    __shared__ T St[NT * SS];
+
+    const int tid = threadIdx.x;
+    const int TJ = blockIdx.x, TK = blockIdx.y;
+    const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
+    const int j0 = TJ * PJ, k0 = TK * PK;
+    const int jmaxp = (j0 + PJ < NJ ? j0 + PJ : NJ) - 1;
+    const int kmaxp = (k0 + PK < NK ? k0 + PK : NK) - 1;
+    const int L0 = BL * a.w - (TJ + TK) * (BL - 1);
+    // levels at which this patch has nodes
+    if (L0 + BL - 1 < j0 + k0 || L0 > jmaxp + kmaxp + NF - 1) return;
+
+    const int slot = a.slots[blockIdx.z];
+    if (slot < 0) return;  // source already converged: its blocks are masked out of the batch
+    T* __restrict__ Tg = a.tt + (size_t)slot * a.g.n_nodes;
+    const T* __restrict__ Sg = a.slowness;
+    const T INF = real_traits<T>::inf();
+    const int rf = a.rf, rj = a.rj, rk = a.rk;
+
+    // ---- stage the T tile: rows = columns (with halo), entries = levels L0-1 .. L0+BL
+    for (int f = tid; f < NROWS * NQ; f += NT) {
+        const int row = f / NQ, q = f - row * NQ;
+        const int hj = row % RJ - 1;
+        const int hk = IS3D ? row / RJ - 1 : 0;
+        const bool halo_j = (hj < 0) | (hj >= PJ);
+        const bool halo_k = IS3D && ((hk < 0) | (hk >= PK));
+        if (halo_j && halo_k) continue;  // corner rows are never read
+        // upwind halo rows are read at q-1 (q in 0..BL-1), downwind ones at q+1 (2..BL+1)
+        if (((hj < 0) | (hk < 0)) && q > BL - 1) continue;
+        if (((hj >= PJ) | (IS3D && hk >= PK)) && q < 2) continue;
+        const int jp = j0 + hj, kp = k0 + hk;
+        const int ip = L0 - 1 + q - jp - kp;
+        T v = INF;
+        if (jp >= 0 && jp < NJ && kp >= 0 && kp < NK && ip >= 0 && ip < NF) {
+            const int i = rf ? NF - 1 - ip : ip;
+            const int j = rj ? NJ - 1 - jp : jp;
+            const int k = rk ? NK - 1 - kp : kp;
+            v = Tg[((uint32_t)k * NJ + j) * NF + i];
+        }
+        Tt[row * RS + q] = v;
+    }
+    // ---- stage node slowness of the own columns, levels L0 .. L0+BL-1
+    for (int f = tid; f < NT * BL; f += NT) {
+        const int c = f / BL, q = f - c * BL;
+        const int jp = j0 + c % PJ, kp = k0 + c / PJ;
+        const int ip = L0 + q - jp - kp;
+        T v = 0;
+        if (jp < NJ && kp < NK && ip >= 0 && ip < NF) {
+            const int i = rf ? NF - 1 - ip : ip;
+            const int j = rj ? NJ - 1 - jp : jp;
+            const int k = rk ? NK - 1 - kp : kp;
+            v = Sg[((uint32_t)k * NJ + j) * NF + i];
+        }
+        St[c * SS + q] = v;
+    }
+
+    // ---- does this tile touch the frozen (source) neighbourhood?  block-uniform test
+    const int* bb = a.bbox + 6 * slot;
+    bool near_src;
+    {
+        int ilo = L0 - jmaxp - kmaxp, ihi = L0 + BL - 1 - j0 - k0;
+        ilo = ilo < 0 ? 0 : ilo;
+        ihi = ihi > NF - 1 ? NF - 1 : ihi;
+        const int flo = rf ? NF - 1 - ihi : ilo, fhi = rf ? NF - 1 - ilo : ihi;
+        const int jlo = rj ? NJ - 1 - jmaxp : j0, jhi = rj ? NJ - 1 - j0 : jmaxp;
+        const int klo = rk ? NK - 1 - kmaxp : k0, khi = rk ? NK - 1 - k0 : kmaxp;
+        near_src = !(fhi < bb[0] || flo > bb[1] || jhi < bb[2] || jlo > bb[3] || khi < bb[4] || klo > bb[5]);
+    }
+    const uint32_t* __restrict__ Fz = a.frozen + (size_t)slot * a.mask_words;
+
+    const int tj = tid % PJ, tk = tid / PJ;
+    const int jp = j0 + tj, kp = k0 + tk;
+    const bool col_ok = jp < NJ && kp < NK;
+    const int row = IS3D ? (tk + 1) * RJ + tj + 1 : tj + 1;
+    const int jn = rj ? NJ - 1 - jp : jp;
+    const int kn = rk ? NK - 1 - kp : kp;
+    const uint32_t colbase = ((uint32_t)kn * NJ + jn) * NF;
+    const T dx = a.dx, dz = a.dz;
+    const int variant = a.variant;
+    double acc = 0.0;
+    bool changed = false;
+
+    __syncthreads();
+
+#pragma unroll
+    for (int q = 1; q <= BL; ++q) {
+        const int ip = L0 - 1 + q - jp - kp;
+        bool active = col_ok && ip >= 0 && ip < NF;
+        if (near_src && active) {
+            const uint32_t n = colbase + (rf ? NF - 1 - ip : ip);
+            active = !((Fz[n >> 5] >> (n & 31)) & 1u);
+        }
+        const T c = Tt[row * RS + q];
+        // axis minima: a missing neighbour is +inf in the tile == the reference's one-sided pick
+        const T af = rmin(Tt[row * RS + q - 1], Tt[row * RS + q + 1]);
+        const T aj = rmin(Tt[(row - 1) * RS + q - 1], Tt[(row + 1) * RS + q + 1]);
+        const T s = St[tid * SS + q - 1];
+        T t;
+        if (IS3D) {
+            const T ak = rmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
+            t = update3(ak, aj, af, s, dx);
+        } else {
+            // 2-D: J axis is x (a), F axis is z (b)
+            t = variant == 1 ? update2(aj, af, s, dx) : update2_xz(aj, af, s, dx, dz);
+        }
+        if (active && t < c) {
+            Tt[row * RS + q] = t;
+            acc += (double)(c - t);
+            changed = true;
+        }
+        __syncthreads();
+    }
+
+    // ---- write back (only when something in the tile changed)
+    if (__syncthreads_or(changed)) {
+        for (int f = tid; f < NT * BL; f += NT) {
+            const int c = f / BL, q = f - c * BL;
+            const int cj = c % PJ, ck = c / PJ;
+            const int jq = j0 + cj, kq = k0 + ck;
+            const int ip = L0 + q - jq - kq;
+            if (jq < NJ && kq < NK && ip >= 0 && ip < NF) {
+                const int i = rf ? NF - 1 - ip : ip;
+                const int j = rj ? NJ - 1 - jq : jq;
+                const int k = rk ? NK - 1 - kq : kq;
+                const int r2 = IS3D ? (ck + 1) * RJ + cj + 1 : cj + 1;
+                Tg[((uint32_t)k * NJ + j) * NF + i] = Tt[r2 * RS + q + 1];
+            }
+        }
+        // wavefront (64-lane) reduction of the decrease, one atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((tid & 63) == 0 && acc != 0.0) atomicAdd(a.change + slot, acc);
+    }
+}
+
+// ---- small kernels -------------------------------------------------------------------------
+
+template <typename T>
+__global__ void fsm_fill(T* p, size_t n, T v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// Grid3Drcfs::setSlowness (ttcr/Grid3Drcfs.h:88-171) / Grid2Drcfs::setSlowness
+// (ttcr/Grid2Drcfs.h:98-138): node slowness = mean of the touching cells, summed in the
+// reference's order (see oracle/fsm_oracle_impl.h for the order analysis).
+template <typename T>
+__global__ void fsm_cells_to_nodes3d(const T* __restrict__ sc, T* __restrict__ sn, int ncx, int ncy, int ncz) {
+    const int nnx = ncx + 1, nny = ncy + 1, nnz = ncz + 1;
+    const size_t N = (size_t)nnx * nny * nnz;
+    for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < N; n += (size_t)gridDim.x * blockDim.x) {
+        const int i = n % nnx, j = (n / nnx) % nny, k = n / ((size_t)nnx * nny);
+        int ci[2], cj[2], ck[2], ni = 0, nj = 0, nk = 0;
+        if (i < ncx) ci[ni++] = i;
+        if (i > 0) ci[ni++] = i - 1;
+        if (j < ncy) cj[nj++] = j;
+        if (j > 0) cj[nj++] = j - 1;
+        if (k < ncz) ck[nk++] = k;
+        if (k > 0) ck[nk++] = k - 1;
+        T sum = 0;
+        bool first = true;
+        if (ni == 1) {
+            for (int b = 0; b < nj; ++b)
+                for (int a = 0; a < nk; ++a) {
+                    const T v = sc[((size_t)ck[a] * ncy + cj[b]) * ncx + ci[0]];
+                    sum = first ? v : sum + v;
+                    first = false;
+                }
+        } else {
+            for (int a = 0; a < nk; ++a)
+                for (int b = 0; b < nj; ++b)
+                    for (int c = 0; c < ni; ++c) {
+                        const T v = sc[((size_t)ck[a] * ncy + cj[b]) * ncx + ci[c]];
+                        sum = first ? v : sum + v;
+                        first = false;
+                    }
+        }
+        const int cnt = ni * nj * nk;
+        sn[n] = cnt == 1 ? sum : (cnt == 2 ? (T)(0.5 * sum) : (cnt == 4 ? (T)(0.25 * sum) : (T)(0.125 * sum)));
+    }
+}
+
+template <typename T>
+__global__ void fsm_cells_to_nodes2d(const T* __restrict__ sc, T* __restrict__ sn, int ncx, int ncz) {
+    const int nnx = ncx + 1, nnz = ncz + 1;
+    const size_t N = (size_t)nnx * nnz;
+    for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < N; n += (size_t)gridDim.x * blockDim.x) {
+        const int j = n % nnz, i = n / nnz;
+        int ci[2], cj[2], ni = 0, nj = 0;
+        if (i < ncx) ci[ni++] = i;
+        if (i > 0) ci[ni++] = i - 1;
+        if (j < ncz) cj[nj++] = j;
+        if (j > 0) cj[nj++] = j - 1;
+        T sum = 0;
+        bool first = true;
+        for (int a = 0; a < ni; ++a)
+            for (int b = 0; b < nj; ++b) {
+                const T v = sc[(size_t)ci[a] * ncz + cj[b]];
+                sum = first ? v : sum + v;
+                first = false;
+            }
+        const int cnt = ni * nj;
+        sn[n] = cnt == 1 ? sum : (cnt == 2 ? (T)(0.5 * sum) : (T)(0.25 * sum));
+    }
+}
+
+// Source initialisation: Grid3Drn::initFSM (ttcr/Grid3Drn.h:3487-3556) and Grid2Drn::initFSM
+// (ttcr/Grid2Drn.h:1360-1418).  The host has already located each source point (node hit or
+// enclosing cell, with the reference's tolerance tests); this kernel applies the points of ONE
+// source in order (later points overwrite earlier ones) to one slot.
+template <typename T>
+struct InitPoint {
+    T x, y, z, t0;       // source point (grid coordinates) and origin time; 2-D: x, z used
+    int i, j, k;         // node (on_node) or cell indices
+    int on_node;
+};
+
+template <typename T>
+struct InitArgs {
+    T* tt;                 // slot field
+    const T* slowness;
+    uint32_t* frozen;      // slot mask
+    int* bbox;             // slot bbox (F,J,K lo/hi) -- written by thread 0
+    const InitPoint<T>* pts;
+    int n_pts, npts;       // npts = 1 (first order)
+    int nnx, nny, nnz;     // 2-D: nnx, nnz, nny = 1
+    T dx, dz, xmin, ymin, zmin;
+    int dim;
+};
+
+template <typename T>
+__device__ __forceinline__ T node_coord(T cmin, uint32_t n, T d) { return cmin + (T)n * d; }
+
+template <typename T>
+__global__ void fsm_init_source(const InitArgs<T> a) {
+    // one block; box nodes are handled by the first threads, points strictly in order
+    const int tid = threadIdx.x;
+    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+    for (int n = 0; n < a.n_pts; ++n) {
+        const InitPoint<T> p = a.pts[n];
+        const int npts = a.npts;
+        const int b0 = p.on_node ? -npts : -(npts - 1);
+        const int w = npts - b0 + 1;  // box edge
+        const int nbox = a.dim == 3 ? w * w * w : w * w;
+        if (p.on_node && tid == 0) {
+            const size_t nn = a.dim == 3 ? ((size_t)p.k * a.nny + p.j) * a.nnx + p.i : (size_t)p.i * a.nnz + p.k;
+            a.tt[nn] = p.t0;
+            atomicOr(&a.frozen[nn >> 5], 1u << (nn & 31));
+        }
+        __syncthreads();
+        for (int b = tid; b < nbox; b += blockDim.x) {
+            if (a.dim == 3) {
+                const int ii = p.i + b0 + b % w, jj = p.j + b0 + (b / w) % w, kk = p.k + b0 + b / (w * w);
+                if (ii < 0 || ii >= a.nnx || jj < 0 || jj >= a.nny || kk < 0 || kk >= a.nnz) continue;
+                if (ii == p.i && jj == p.j && kk == p.k) continue;  // skipped in both branches (:3505, :3541)
+                const size_t m = ((size_t)kk * a.nny + jj) * a.nnx + ii;
+                const T x = node_coord(a.xmin, ii, a.dx), y = node_coord(a.ymin, jj, a.dx), z = node_coord(a.zmin, kk, a.dx);
+                const T d2 = (x - p.x) * (x - p.x) + (y - p.y) * (y - p.y) + (z - p.z) * (z - p.z);
+                const T d = (T)__builtin_sqrt((double)d2);  // == correctly rounded sqrt in T
+                a.tt[m] = p.t0 + d * a.slowness[m];
+                atomicOr(&a.frozen[m >> 5], 1u << (m & 31));
+            } else {
+                const int ii = p.i + b0 + b / w, kk = p.k + b0 + b % w;  // kk: z index
+                if (ii < 0 || ii >= a.nnx || kk < 0 || kk >= a.nnz) continue;
+                if (p.on_node && ii == p.i && kk == p.k) continue;  // 2-D skips only in the on-node branch
+                const size_t m = (size_t)ii * a.nnz + kk;
+                const T x = node_coord(a.xmin, ii, a.dx), z = node_coord(a.zmin, kk, a.dz);
+                const T d2 = (x - p.x) * (x - p.x) + (z - p.z) * (z - p.z);
+                const T d = (T)__builtin_sqrt((double)d2);
+                T tt;
+                if (p.on_node) {
+                    // t0 + dist*0.5*(s_nbr + s_src): the 0.5 literal makes this a double chain (:1384)
+                    const size_t nn = (size_t)p.i * a.nnz + p.k;
+                    const T ssum = a.slowness[m] + a.slowness[nn];
+                    tt = (T)((double)p.t0 + ((double)d * 0.5) * (double)ssum);
+                } else {
+                    tt = p.t0 + d * a.slowness[m];
+                }
+                a.tt[m] = tt;
+                atomicOr(&a.frozen[m >> 5], 1u << (m & 31));
+            }
+        }
+        __syncthreads();
+        // bounding box of everything this point may have frozen (clipped)
+        const int ci[3] = {p.i, p.j, p.k};
+        const int nn3[3] = {a.nnx, a.dim == 3 ? a.nny : 1, a.nnz};
+        for (int d = 0; d < 3; ++d) {
+            if (a.dim == 2 && d == 1) { lo[1] = 0; hi[1] = 0; continue; }
+            int l = ci[d] + b0, h = ci[d] + npts;
+            l = l < 0 ? 0 : l;
+            h = h > nn3[d] - 1 ? nn3[d] - 1 : h;
+            lo[d] = l < lo[d] ? l : lo[d];
+            hi[d] = h > hi[d] ? h : hi[d];
+        }
+    }
+    if (tid == 0) {
+        // stored in the sweep kernel's (F, J, K) axis order
+        if (a.dim == 3) {
+            a.bbox[0] = lo[0]; a.bbox[1] = hi[0]; a.bbox[2] = lo[1]; a.bbox[3] = hi[1]; a.bbox[4] = lo[2]; a.bbox[5] = hi[2];
+        } else {  // F = z, J = x, K = none
+            a.bbox[0] = lo[2]; a.bbox[1] = hi[2]; a.bbox[2] = lo[0]; a.bbox[3] = hi[0]; a.bbox[4] = 0; a.bbox[5] = 0;
+        }
+    }
+}
+
+// Receiver traveltimes: Grid3Drn::getTraveltime (ttcr/Grid3Drn.h:794-930)
+template <typename T>
+__global__ void fsm_interp3d(const T* __restrict__ Tn, const T* __restrict__ pts, T* __restrict__ out, int n,
+                             int nnx, int nny, T dx, T xmin, T ymin, T zmin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double small2 = 1.e-4 * 1.e-4;
+    const T px = pts[3 * r], py = pts[3 * r + 1], pz = pts[3 * r + 2];
+    const T dy = dx, dz = dx;
+    const uint32_t i = (uint32_t)(small2 + (double)((px - xmin) / dx));
+    const uint32_t j = (uint32_t)(small2 + (double)((py - ymin) / dy));
+    const uint32_t k = (uint32_t)(small2 + (double)((pz - zmin) / dz));
+    auto ab = [](T v) { return v < 0 ? -v : v; };
+    const bool onx = (double)ab(px - (xmin + (T)i * dx)) < small2;
+    const bool ony = (double)ab(py - (ymin + (T)j * dy)) < small2;
+    const bool onz = (double)ab(pz - (zmin + (T)k * dz)) < small2;
+#define TT(ii, jj, kk) Tn[((size_t)(kk) * nny + (jj)) * nnx + (ii)]
+    T tt;
+    if (onx && ony && onz) {
+        tt = TT(i, j, k);
+    } else if (onx && ony) {
+        T t1 = TT(i, j, k), t2 = TT(i, j, k + 1);
+        T w1 = (zmin + (T)(k + 1) * dz - pz) / dz, w2 = (pz - (zmin + (T)k * dz)) / dz;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onx && onz) {
+        T t1 = TT(i, j, k), t2 = TT(i, j + 1, k);
+        T w1 = (ymin + (T)(j + 1) * dy - py) / dy, w2 = (py - (ymin + (T)j * dy)) / dy;
+        tt = t1 * w1 + t2 * w2;
+    } else if (ony && onz) {
+        T t1 = TT(i, j, k), t2 = TT(i + 1, j, k);
+        T w1 = (xmin + (T)(i + 1) * dx - px) / dx, w2 = (px - (xmin + (T)i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onx) {
+        T t1 = TT(i, j, k), t2 = TT(i, j, k + 1), t3 = TT(i, j + 1, k), t4 = TT(i, j + 1, k + 1);
+        T w1 = (zmin + (T)(k + 1) * dz - pz) / dz, w2 = (pz - (zmin + (T)k * dz)) / dz;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (ymin + (T)(j + 1) * dy - py) / dy;
+        w2 = (py - (ymin + (T)j * dy)) / dy;
+        tt = t1 * w1 + t2 * w2;
+    } else if (ony) {
+        T t1 = TT(i, j, k), t2 = TT(i, j, k + 1), t3 = TT(i + 1, j, k), t4 = TT(i + 1, j, k + 1);
+        T w1 = (zmin + (T)(k + 1) * dz - pz) / dz, w2 = (pz - (zmin + (T)k * dz)) / dz;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (xmin + (T)(i + 1) * dx - px) / dx;
+        w2 = (px - (xmin + (T)i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onz) {
+        T t1 = TT(i, j, k), t2 = TT(i, j + 1, k), t3 = TT(i + 1, j, k), t4 = TT(i + 1, j + 1, k);
+        T w1 = (ymin + (T)(j + 1) * dy - py) / dy, w2 = (py - (ymin + (T)j * dy)) / dy;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (xmin + (T)(i + 1) * dx - px) / dx;
+        w2 = (px - (xmin + (T)i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else {
+        T t1 = TT(i, j, k), t2 = TT(i, j, k + 1), t3 = TT(i, j + 1, k), t4 = TT(i, j + 1, k + 1);
+        T t5 = TT(i + 1, j, k), t6 = TT(i + 1, j, k + 1), t7 = TT(i + 1, j + 1, k), t8 = TT(i + 1, j + 1, k + 1);
+        T w1 = (zmin + (T)(k + 1) * dz - pz) / dz, w2 = (pz - (zmin + (T)k * dz)) / dz;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        t3 = t5 * w1 + t6 * w2;
+        t4 = t7 * w1 + t8 * w2;
+        w1 = (ymin + (T)(j + 1) * dy - py) / dy;
+        w2 = (py - (ymin + (T)j * dy)) / dy;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (xmin + (T)(i + 1) * dx - px) / dx;
+        w2 = (px - (xmin + (T)i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    }
+#undef TT
+    out[r] = tt;
+}
+
+// Grid2Drn::getTraveltime (ttcr/Grid2Drn.h:359-414)
+template <typename T>
+__global__ void fsm_interp2d(const T* __restrict__ Tn, const T* __restrict__ pts, T* __restrict__ out, int n,
+                             int nnz, T dx, T dz, T xmin, T zmin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double small = 1.e-4;
+    const T px = pts[2 * r], pz = pts[2 * r + 1];
+    const uint32_t i = (uint32_t)(small + (double)((px - xmin) / dx));
+    const uint32_t j = (uint32_t)(small + (double)((pz - zmin) / dz));
+    auto ab = [](T v) { return v < 0 ? -v : v; };
+    const bool onx = (double)ab(px - (xmin + (T)i * dx)) < small;
+    const bool onz = (double)ab(pz - (zmin + (T)j * dz)) < small;
+    T tt;
+    if (onx && onz) {
+        tt = Tn[(size_t)i * nnz + j];
+    } else if (onx) {
+        T t1 = Tn[(size_t)i * nnz + j], t2 = Tn[(size_t)i * nnz + j + 1];
+        T w1 = (zmin + (T)(j + 1) * dz - pz) / dz, w2 = (pz - (zmin + (T)j * dz)) / dz;
+        tt = t1 * w1 + t2 * w2;
+    } else if (onz) {
+        T t1 = Tn[(size_t)i * nnz + j], t2 = Tn[(size_t)(i + 1) * nnz + j];
+        T w1 = (xmin + (T)(i + 1) * dx - px) / dx, w2 = (px - (xmin + (T)i * dx)) / dx;
+        tt = t1 * w1 + t2 * w2;
+    } else {
+        T t1 = Tn[(size_t)i * nnz + j], t2 = Tn[(size_t)(i + 1) * nnz + j];
+        T t3 = Tn[(size_t)i * nnz + j + 1], t4 = Tn[(size_t)(i + 1) * nnz + j + 1];
+        T w1 = (xmin + (T)(i + 1) * dx - px) / dx, w2 = (px - (xmin + (T)i * dx)) / dx;
+        t1 = t1 * w1 + t2 * w2;
+        t2 = t3 * w1 + t4 * w2;
+        w1 = (zmin + (T)(j + 1) * dz - pz) / dz;
+        w2 = (pz - (zmin + (T)j * dz)) / dz;
+        tt = t1 * w1 + t2 * w2;
+    }
+    out[r] = tt;
+}
+
+}  // namespace ttcr_amd

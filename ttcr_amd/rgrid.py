@@ -1,0 +1,594 @@
+"""ttcr_amd.rgrid -- the `Grid3d` / `Grid2d` subset of ttcrpy.rgrid for method='FSM',
+running on MI355X through the C ABI of include/ttcr_amd.h.
+
+Mirrors src/ttcrpy/rgrid.pyx of the reference (same names, argument meaning, return shapes
+and error behaviour) for the fast-sweeping path:
+
+  Grid3d factory          rgrid.pyx:5580-5620     Grid2d factory          rgrid.pyx:5646-5687
+  Grid3d_d.__cinit__      rgrid.pyx:155-282       Grid2d_d.__cinit__      rgrid.pyx:2859-2975
+  set_slowness            rgrid.pyx:532-569       (2-D) rgrid.pyx:3171-3205
+  raytrace                rgrid.pyx:828-1199      (2-D) rgrid.pyx:3804-4143
+  get_grid_traveltimes    rgrid.pyx:410-435       (2-D) rgrid.pyx:3102-3127
+
+What is not on the FSM hot path raises NotImplementedError (SPM/DSPM, compute_L/compute_M,
+return_rays) -- and so do weno=True and tt_from_rp=True until those rows of SURVEY.md
+section 8(f) are built.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_verbose = 0
+
+
+def set_verbose(v):
+    """set_verbose(v): mirror of rgrid.pyx:38-47 (messages are only printed by this wrapper)."""
+    global _verbose
+    _verbose = int(v)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _GridBase:
+    """State and helpers shared by the 3-D and 2-D wrappers."""
+
+    _dtype = np.float64
+    _ndim = 3
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._lib = None
+
+    # -- life cycle (rgrid.pyx:284-285)
+    def __del__(self):
+        try:
+            if self._lib is not None and self._h:
+                self._lib.ttcr_fsm_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def n_threads(self):
+        """int: number of threads (here: device-resident traveltime slots) for raytracing"""
+        return self._n_threads
+
+    def set_use_thread_pool(self, use_thread_pool):
+        """No-op: sources of one call are always swept concurrently on the device
+        (the reference's pool/blocks choice, ttcr/Grid3D.h:821-851, has no equivalent)."""
+        self._use_pool = bool(use_thread_pool)
+
+    def set_traveltime_from_raypath(self, traveltime_from_raypath):
+        if traveltime_from_raypath:
+            raise NotImplementedError("tt_from_rp=True (traveltime from raypath, ttcr/Grid3Drn.h:1103-1243) "
+                                      "is not built yet; use tt_from_rp=False")
+        self.tt_from_rp = False
+
+    def set_option(self, key, value):
+        """Backend knob (fixed_iters, max_batch, use_graph); no reference equivalent."""
+        _lib.check(self._lib.ttcr_fsm_set_option(self._h, key.encode(), float(value)))
+
+    def get_niter(self, thread_no=0):
+        """Sweep-iterations of the last solve in a slot (Grid3Drnfs::get_niter, ttcr/Grid3Drnfs.h:56)."""
+        a, b = C.c_int(), C.c_int()
+        _lib.check(self._lib.ttcr_fsm_get_niter(self._h, int(thread_no), C.byref(a), C.byref(b)))
+        return a.value
+
+    def timing(self):
+        """HIP-event timing of the last raytrace call (dict)."""
+        t = _lib.Timing()
+        _lib.check(self._lib.ttcr_fsm_last_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def _flat_tt(self, thread_no):
+        if thread_no >= self._n_threads:
+            raise ValueError('Thread number is larger than number of threads')
+        n = self.get_number_of_nodes()
+        out = np.empty(n, dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_get_tt(self._h, int(thread_no), _ptr(out), n))
+        return out
+
+    def tt_device_ptr(self, thread_no=0):
+        """Raw device address of a slot's traveltime field (for zero-copy consumers)."""
+        p = C.c_void_p()
+        _lib.check(self._lib.ttcr_fsm_get_tt_device(self._h, int(thread_no), C.byref(p)))
+        return p.value
+
+    # -- source / receiver bookkeeping shared by 3-D and 2-D raytrace()
+    def _split_sources(self, source, rcv, aggregate_src):
+        nd = self._ndim
+        if source.ndim != 2 or rcv.ndim != 2:
+            raise ValueError('source and rcv should be 2D arrays')
+        evID = None
+        if nd == 3 and source.shape[1] == 5:
+            src = source[:, 2:5]
+            t0 = source[:, 1]
+            evID = source[:, 0]
+            eid = np.sort(np.unique(evID))
+            nTx = len(eid)
+            Tx = None
+        elif source.shape[1] == nd:
+            src = source
+            _, ind = np.unique(source, axis=0, return_index=True)
+            Tx = source[np.sort(ind), :]  # keep the original order
+            t0 = np.zeros((Tx.shape[0],))
+            nTx = Tx.shape[0]
+        elif source.shape[1] == nd + 1:
+            src = source[:, 1:nd + 1]
+            _, ind = np.unique(source, axis=0, return_index=True)
+            tmp = source[np.sort(ind), :]
+            nTx = tmp.shape[0]
+            Tx = tmp[:, 1:nd + 1]
+            t0 = tmp[:, 0]
+        else:
+            if nd == 3:
+                raise ValueError('source should be either nsrc x 3, 4 or 5')
+            raise ValueError('source should be either nsrc x 2 or 3')
+        if src.shape[1] != nd or rcv.shape[1] != nd:
+            raise ValueError('src and rcv should be ndata x %d' % nd)
+        if self.is_outside(src):
+            raise ValueError('Source point outside grid')
+        if self.is_outside(rcv):
+            raise ValueError('Receiver outside grid')
+
+        vTx, vt0, vRx, iRx = [], [], [], []
+        if evID is None:
+            if nTx == 1:
+                vTx.append(src[0:1, :])
+                vt0.append(np.array([t0[0]]))
+                vRx.append(rcv)
+                iRx.append(np.arange(rcv.shape[0]))
+            elif aggregate_src:
+                vTx.append(Tx)
+                vt0.append(np.asarray(t0))
+                vRx.append(rcv)
+                iRx.append(np.arange(rcv.shape[0]))
+                nTx = 1
+            else:
+                if src.shape != rcv.shape:
+                    raise ValueError('src and rcv should be of equal size')
+                for n in range(nTx):
+                    ind = np.sum(Tx[n, :] == src, axis=1) == nd
+                    iRx.append(np.nonzero(ind)[0])
+                    vTx.append(Tx[n:n + 1, :])
+                    vt0.append(np.array([t0[n]]))
+                    vRx.append(rcv[ind, :])
+        else:
+            if src.shape != rcv.shape:
+                raise ValueError('src and rcv should be of equal size')
+            for n in range(nTx):
+                i0 = int(np.nonzero(evID == eid[n])[0][0])
+                vTx.append(src[i0:i0 + 1, :])
+                vt0.append(np.array([t0[i0]]))
+            for i in eid:
+                iRx.append(np.nonzero(evID == i)[0])
+            for n in range(nTx):
+                vRx.append(rcv[iRx[n], :])
+        return vTx, vt0, vRx, iRx
+
+    def _run(self, vTx, vt0, vRx, iRx, n_rcv, thread_no):
+        dt = self._dtype
+        nd = self._ndim
+        nTx = len(vTx)
+        tx = np.ascontiguousarray(np.vstack(vTx), dtype=dt)
+        t0 = np.ascontiguousarray(np.concatenate(vt0), dtype=dt)
+        rx = np.ascontiguousarray(np.vstack(vRx), dtype=dt).reshape(-1, nd)
+        tx_off = np.zeros(nTx + 1, dtype=np.int32)
+        rx_off = np.zeros(nTx + 1, dtype=np.int32)
+        tx_off[1:] = np.cumsum([len(t) for t in vTx])
+        rx_off[1:] = np.cumsum([len(r) for r in vRx])
+        out = np.empty(max(rx.shape[0], 1), dtype=dt)
+        if thread_no is not None and self._n_threads > 1:
+            assert nTx == 1  # "we should be here for just one event" (rgrid.pyx:1064-1066)
+            st = self._lib.ttcr_fsm_raytrace(self._h, int(thread_no), int(tx.shape[0]), _ptr(tx), _ptr(t0),
+                                             int(rx.shape[0]), _ptr(rx), _ptr(out))
+        else:
+            st = self._lib.ttcr_fsm_raytrace_multi(self._h, nTx, _ptr(tx_off), _ptr(tx), _ptr(t0), _ptr(rx_off),
+                                                   _ptr(rx), _ptr(out))
+        _lib.check(st)
+        tt = np.zeros((n_rcv,), dtype=dt)
+        for n in range(nTx):
+            tt[iRx[n]] = out[rx_off[n]:rx_off[n + 1]]
+        return tt
+
+
+# ======================================================================================= 3-D
+class _Grid3d(_GridBase):
+    """3-D rectilinear grid, fast-sweeping method on MI355X.
+
+    Constructor (same signature as ttcrpy's Grid3d_d / Grid3d_f):
+
+    Grid3d_x(x, y, z, n_threads=1, cell_slowness=1, method='FSM', tt_from_rp=1, interp_vel=0,
+             eps=1.e-5, maxit=50, weno=1, nsnx=5, nsny=5, nsnz=5, n_secondary=2, n_tertiary=2,
+             radius_factor_tertiary=3.0, translate_grid=False, fsm_gpu=False)
+
+    x, y, z are NODE coordinates (cells = size-1).  fsm_gpu is accepted and ignored: this
+    backend always runs on the GPU.  `device` (extra keyword) selects the HIP device.
+    """
+    _ndim = 3
+
+    def __init__(self, x, y, z, n_threads=1, cell_slowness=1, method='FSM', tt_from_rp=1, interp_vel=0,
+                 eps=1.e-5, maxit=50, weno=1, nsnx=5, nsny=5, nsnz=5, n_secondary=2, n_tertiary=2,
+                 radius_factor_tertiary=3.0, translate_grid=False, fsm_gpu=False, device=-1):
+        super().__init__()
+        dt = self._dtype
+        x = np.ascontiguousarray(x, dtype=dt).ravel()
+        y = np.ascontiguousarray(y, dtype=dt).ravel()
+        z = np.ascontiguousarray(z, dtype=dt).ravel()
+        if x.size < 2 or y.size < 2 or z.size < 2:
+            raise ValueError('x, y and z need at least two nodes')
+        self._x, self._y, self._z = x, y, z
+        # dx = x[1]-x[0] in the array's dtype, then widened (rgrid.pyx:170-172, :1878-1880)
+        self._dx = float(x[1] - x[0])
+        self._dy = float(y[1] - y[0])
+        self._dz = float(z[1] - z[0])
+        self.cell_slowness = bool(cell_slowness)
+        self._n_threads = int(n_threads)
+        self.tt_from_rp = bool(tt_from_rp)
+        self.interp_vel = bool(interp_vel)
+        self.eps = float(eps)
+        self.maxit = int(maxit)
+        self.weno = bool(weno)
+        self.nsnx, self.nsny, self.nsnz = int(nsnx), int(nsny), int(nsnz)
+        self.n_secondary, self.n_tertiary = int(n_secondary), int(n_tertiary)
+        self.radius_factor_tertiary = float(radius_factor_tertiary)
+        self.translate_grid = bool(translate_grid)
+        self.fsm_gpu = bool(fsm_gpu)
+        self.method = method
+        self._device = int(device)
+
+        if method == 'FSM':
+            if np.abs(self._dx - self._dy) > 0.000001 or np.abs(self._dx - self._dz) > 0.000001:
+                raise ValueError('FSM: Grid cells must be cubic')
+        elif method in ('SPM', 'DSPM'):
+            raise NotImplementedError("method '%s' is outside the MI355X FSM path (SURVEY.md section 8)" % method)
+        else:
+            raise ValueError('Method {0:s} undefined'.format(method))
+        if self.tt_from_rp:
+            raise NotImplementedError("tt_from_rp=True (traveltime from raypath, ttcr/Grid3Drn.h:1103-1243) "
+                                      "is not built yet; pass tt_from_rp=False")
+        self._lib = _lib.load()
+        st = self._lib.ttcr_fsm3d_create(C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
+                                         int(self.cell_slowness), x.size - 1, y.size - 1, z.size - 1, self._dx,
+                                         float(x[0]), float(y[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
+                                         self._n_threads, int(self.translate_grid), self._device)
+        _lib.check(st)
+
+    def __reduce__(self):
+        params = (self.n_threads, self.cell_slowness, self.method, self.tt_from_rp, self.interp_vel, self.eps,
+                  self.maxit, self.weno, self.nsnx, self.nsny, self.nsnz, self.n_secondary, self.n_tertiary,
+                  self.radius_factor_tertiary, self.translate_grid, self.fsm_gpu)
+        return (_rebuild3d, (type(self), self.x, self.y, self.z, params))
+
+    # -- properties (rgrid.pyx:303-364)
+    @property
+    def x(self):
+        """np.ndarray: node coordinates along x"""
+        return np.array(self._x)
+
+    @property
+    def y(self):
+        """np.ndarray: node coordinates along y"""
+        return np.array(self._y)
+
+    @property
+    def z(self):
+        """np.ndarray: node coordinates along z"""
+        return np.array(self._z)
+
+    @property
+    def dx(self):
+        return self._dx
+
+    @property
+    def dy(self):
+        return self._dy
+
+    @property
+    def dz(self):
+        return self._dz
+
+    @property
+    def shape(self):
+        """number of parameters along each dimension"""
+        if self.cell_slowness:
+            return (self._x.size - 1, self._y.size - 1, self._z.size - 1)
+        return (self._x.size, self._y.size, self._z.size)
+
+    @property
+    def nparams(self):
+        return int(np.prod(self.shape))
+
+    def get_number_of_nodes(self):
+        return self._x.size * self._y.size * self._z.size
+
+    def get_number_of_cells(self):
+        return (self._x.size - 1) * (self._y.size - 1) * (self._z.size - 1)
+
+    def ind(self, i, j, k):
+        return (i * self._y.size + j) * self._z.size + k
+
+    def indc(self, i, j, k):
+        return (i * (self._y.size - 1) + j) * (self._z.size - 1) + k
+
+    def is_outside(self, pts):
+        """True if at least one point is outside the grid (rgrid.pyx:487-505)"""
+        pts = np.asarray(pts)
+        return bool(np.min(pts[:, 0]) < self._x[0] or np.max(pts[:, 0]) > self._x[-1] or
+                    np.min(pts[:, 1]) < self._y[0] or np.max(pts[:, 1]) > self._y[-1] or
+                    np.min(pts[:, 2]) < self._z[0] or np.max(pts[:, 2]) > self._z[-1])
+
+    def get_grid_traveltimes(self, thread_no=0):
+        """traveltimes at the grid nodes, shape (nx, ny, nz)  (rgrid.pyx:410-435)"""
+        tt = self._flat_tt(thread_no)
+        return tt.reshape((self._x.size, self._y.size, self._z.size), order='F')
+
+    def get_slowness(self):
+        """NODE slowness held by the solver, shape (nx, ny, nz) of nodes."""
+        n = self.get_number_of_nodes()
+        out = np.empty(n, dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_get_slowness(self._h, _ptr(out), n))
+        return out.reshape((self._x.size, self._y.size, self._z.size), order='F')
+
+    def _to_flat_F(self, a, what):
+        nx, ny, nz = self.shape
+        a = np.asarray(a)
+        if a.size != nx * ny * nz:
+            raise ValueError('%s vector has wrong size' % what)
+        if a.ndim == 3:
+            if a.shape != (nx, ny, nz):
+                raise ValueError('%s has wrong shape' % what)
+            return a.flatten('F')
+        elif a.ndim == 1:
+            # C order in, x-fastest ('F') order to the solver (rgrid.pyx:562-565)
+            return a.reshape((nx, ny, nz)).flatten('F')
+        raise ValueError('%s must be 1D or 3D ndarray' % what)
+
+    def set_slowness(self, slowness):
+        """Assign slowness, shape (nx, ny, nz) or flattened in C order (rgrid.pyx:532-569)"""
+        s = np.ascontiguousarray(self._to_flat_F(slowness, 'Slowness'), dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_set_slowness(self._h, _ptr(s), s.size))
+
+    def set_velocity(self, velocity):
+        """Assign velocity (rgrid.pyx:571-608): slowness = 1/velocity"""
+        v = self._to_flat_F(velocity, 'velocity')
+        s = np.ascontiguousarray(1. / v, dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_set_slowness(self._h, _ptr(s), s.size))
+
+    def raytrace(self, source, rcv, slowness=None, thread_no=None, aggregate_src=False, compute_L=False,
+                 compute_M=False, return_rays=False):
+        """raytrace(source, rcv, slowness=None, thread_no=None, aggregate_src=False, ...) -> tt
+
+        Same contract as ttcrpy (rgrid.pyx:828-1199): source has 3 (xyz), 4 (t0,xyz) or 5
+        (evID,t0,xyz) columns; duplicate source rows are collapsed keeping first-occurrence
+        order; receivers are grouped per unique source; tt comes back in rcv order.
+        """
+        source = np.asarray(source)
+        rcv = np.asarray(rcv)
+        if source.ndim != 2 or rcv.ndim != 2:
+            raise ValueError('source and rcv should be 2D arrays')
+        if compute_L and compute_M:
+            raise ValueError('compute_L and compute_M are mutually exclusive')
+        if self.cell_slowness and compute_M:
+            raise NotImplementedError('compute_M not defined for grids with slowness defined for cells')
+        if compute_L and not self.cell_slowness:
+            raise NotImplementedError('compute_L defined only for grids with slowness defined for cells')
+        if compute_L:
+            raise NotImplementedError('compute_L defined for the FSM')
+        if compute_M or return_rays:
+            raise NotImplementedError('compute_M / return_rays (raypaths, ttcr/Grid3Drn.h:1247-2450) are not built yet')
+        vTx, vt0, vRx, iRx = self._split_sources(source, rcv, aggregate_src)
+        if slowness is not None:
+            self.set_slowness(slowness)
+        return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
+
+
+class Grid3d_d(_Grid3d):
+    """double-precision 3-D grid (ttcrpy Grid3d_d)"""
+    _dtype = np.float64
+
+
+class Grid3d_f(_Grid3d):
+    """single-precision 3-D grid (ttcrpy Grid3d_f)"""
+    _dtype = np.float32
+
+
+def _rebuild3d(cls, x, y, z, p):
+    return cls(x, y, z, *p)
+
+
+def Grid3d(x, y, z, n_threads=1, cell_slowness=1, method='FSM', tt_from_rp=1, interp_vel=0, eps=1.e-5, maxit=50,
+           weno=1, nsnx=5, nsny=5, nsnz=5, n_secondary=2, n_tertiary=2, radius_factor_tertiary=3.0,
+           translate_grid=False, fsm_gpu=False, dtype=np.float64, device=-1):
+    """Grid3d(x, y, z, ..., dtype=np.float64) -> Grid3d_d or Grid3d_f  (rgrid.pyx:5580-5620)"""
+    if np.dtype(dtype) == np.dtype(np.float64):
+        cls = Grid3d_d
+    elif np.dtype(dtype) == np.dtype(np.float32):
+        cls = Grid3d_f
+    else:
+        raise ValueError('dtype must be np.float32 or np.float64, got {}'.format(dtype))
+    return cls(x, y, z, n_threads, cell_slowness, method, tt_from_rp, interp_vel, eps, maxit, weno, nsnx, nsny, nsnz,
+               n_secondary, n_tertiary, radius_factor_tertiary, translate_grid, fsm_gpu, device=device)
+
+
+# ======================================================================================= 2-D
+class _Grid2d(_GridBase):
+    """2-D rectilinear grid, fast-sweeping method on MI355X.
+
+    Grid2d_x(x, z, n_threads=1, cell_slowness=1, method='SPM', aniso='iso', eps=1.e-5, maxit=50, weno=1,
+             rotated_template=0, nsnx=10, nsnz=10, n_secondary=3, n_tertiary=3,
+             radius_factor_tertiary=3.0, tt_from_rp=0, fsm_gpu=False)
+    (same signature as ttcrpy; only method='FSM', aniso='iso' is on this backend's path).
+    """
+    _ndim = 2
+
+    def __init__(self, x, z, n_threads=1, cell_slowness=1, method='SPM', aniso='iso', eps=1.e-5, maxit=50, weno=1,
+                 rotated_template=0, nsnx=10, nsnz=10, n_secondary=3, n_tertiary=3, radius_factor_tertiary=3.0,
+                 tt_from_rp=0, fsm_gpu=False, device=-1):
+        super().__init__()
+        dt = self._dtype
+        x = np.ascontiguousarray(x, dtype=dt).ravel()
+        z = np.ascontiguousarray(z, dtype=dt).ravel()
+        if x.size < 2 or z.size < 2:
+            raise ValueError('x and z need at least two nodes')
+        self._x, self._z = x, z
+        self._dx = float(x[1] - x[0])
+        self._dz = float(z[1] - z[0])
+        self.cell_slowness = bool(cell_slowness)
+        self._n_threads = int(n_threads)
+        self.eps = float(eps)
+        self.maxit = int(maxit)
+        self.weno = bool(weno)
+        self.rotated_template = bool(rotated_template)
+        self.nsnx, self.nsnz = int(nsnx), int(nsnz)
+        self.n_secondary, self.n_tertiary = int(n_secondary), int(n_tertiary)
+        self.radius_factor_tertiary = float(radius_factor_tertiary)
+        self.tt_from_rp = bool(tt_from_rp)
+        self.fsm_gpu = bool(fsm_gpu)
+        self.method = method
+        self.aniso = aniso
+        self._device = int(device)
+        if method in ('SPM', 'DSPM'):
+            raise NotImplementedError("method '%s' is outside the MI355X FSM path (SURVEY.md section 8)" % method)
+        if method != 'FSM':
+            raise ValueError('Method {0:s} undefined'.format(method))
+        if aniso != 'iso':
+            raise NotImplementedError('Anisotropic raytracing implemented only for SPM')
+        if self.tt_from_rp:
+            raise NotImplementedError("tt_from_rp=True is not built yet; pass tt_from_rp=False")
+        self._lib = _lib.load()
+        st = self._lib.ttcr_fsm2d_create(C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
+                                         int(self.cell_slowness), x.size - 1, z.size - 1, self._dx, self._dz,
+                                         float(x[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
+                                         int(self.rotated_template), self._n_threads, self._device)
+        _lib.check(st)
+
+    def __reduce__(self):
+        params = (self.n_threads, self.cell_slowness, self.method, self.aniso, self.eps, self.maxit, self.weno,
+                  self.rotated_template, self.nsnx, self.nsnz, self.n_secondary, self.n_tertiary,
+                  self.radius_factor_tertiary, self.tt_from_rp, self.fsm_gpu)
+        return (_rebuild2d, (type(self), self.x, self.z, params))
+
+    @property
+    def x(self):
+        return np.array(self._x)
+
+    @property
+    def z(self):
+        return np.array(self._z)
+
+    @property
+    def dx(self):
+        return self._dx
+
+    @property
+    def dz(self):
+        return self._dz
+
+    @property
+    def shape(self):
+        if self.cell_slowness:
+            return (self._x.size - 1, self._z.size - 1)
+        return (self._x.size, self._z.size)
+
+    @property
+    def nparams(self):
+        return int(np.prod(self.shape))
+
+    def get_number_of_nodes(self):
+        return self._x.size * self._z.size
+
+    def get_number_of_cells(self):
+        return (self._x.size - 1) * (self._z.size - 1)
+
+    def ind(self, i, j):
+        return i * self._z.size + j
+
+    def indc(self, i, j):
+        return i * (self._z.size - 1) + j
+
+    def is_outside(self, pts):
+        pts = np.asarray(pts)
+        return bool(np.min(pts[:, 0]) < self._x[0] or np.max(pts[:, 0]) > self._x[-1] or
+                    np.min(pts[:, 1]) < self._z[0] or np.max(pts[:, 1]) > self._z[-1])
+
+    def get_grid_traveltimes(self, thread_no=0):
+        """traveltimes at the grid nodes, shape (nx, nz)  (rgrid.pyx:3102-3127)"""
+        return self._flat_tt(thread_no).reshape((self._x.size, self._z.size))
+
+    def get_slowness(self):
+        n = self.get_number_of_nodes()
+        out = np.empty(n, dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_get_slowness(self._h, _ptr(out), n))
+        return out.reshape((self._x.size, self._z.size))
+
+    def _to_flat(self, a, what):
+        nx, nz = self.shape
+        a = np.asarray(a)
+        if a.size != nx * nz:
+            raise ValueError('%s vector has wrong size' % what)
+        if a.ndim == 2:
+            if a.shape != (nx, nz):
+                raise ValueError('%s has wrong shape' % what)
+            return a.flatten()
+        elif a.ndim == 1:
+            return a
+        raise ValueError('%s must be 1D or 2D ndarray' % what)
+
+    def set_slowness(self, slowness):
+        """Assign slowness, shape (nx, nz) or flattened in C order (rgrid.pyx:3171-3205)"""
+        s = np.ascontiguousarray(self._to_flat(slowness, 'Slowness'), dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_set_slowness(self._h, _ptr(s), s.size))
+
+    def set_velocity(self, velocity):
+        s = np.ascontiguousarray(1. / self._to_flat(velocity, 'velocity'), dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_set_slowness(self._h, _ptr(s), s.size))
+
+    def raytrace(self, source, rcv, slowness=None, xi=None, theta=None, Vp0=None, Vs0=None, delta=None,
+                 epsilon=None, gamma=None, thread_no=None, aggregate_src=False, compute_L=False, return_rays=False):
+        """raytrace(source, rcv, slowness=None, ..., thread_no=None, aggregate_src=False) -> tt
+        (rgrid.pyx:3804-4143): source has 2 (x,z) or 3 (t0,x,z) columns."""
+        source = np.asarray(source)
+        rcv = np.asarray(rcv)
+        if source.ndim != 2 or rcv.ndim != 2:
+            raise ValueError('source and rcv should be 2D arrays')
+        if any(v is not None for v in (xi, theta, Vp0, Vs0, delta, epsilon, gamma)):
+            raise NotImplementedError('Anisotropic raytracing implemented only for SPM')
+        if compute_L and not self.cell_slowness:
+            raise NotImplementedError('compute_L defined only for grids with slowness defined for cells')
+        if compute_L or return_rays:
+            raise NotImplementedError('compute_L / return_rays are not on the FSM hot path built here')
+        vTx, vt0, vRx, iRx = self._split_sources(source, rcv, aggregate_src)
+        if slowness is not None:
+            self.set_slowness(slowness)
+        return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
+
+
+class Grid2d_d(_Grid2d):
+    _dtype = np.float64
+
+
+class Grid2d_f(_Grid2d):
+    _dtype = np.float32
+
+
+def _rebuild2d(cls, x, z, p):
+    return cls(x, z, *p)
+
+
+def Grid2d(x, z, n_threads=1, cell_slowness=1, method='SPM', aniso='iso', eps=1.e-5, maxit=50, weno=1,
+           rotated_template=0, nsnx=10, nsnz=10, n_secondary=3, n_tertiary=3, radius_factor_tertiary=3.0,
+           tt_from_rp=0, fsm_gpu=False, dtype=np.float64, device=-1):
+    """Grid2d(x, z, ..., dtype=np.float64) -> Grid2d_d or Grid2d_f  (rgrid.pyx:5646-5687)"""
+    if np.dtype(dtype) == np.dtype(np.float64):
+        cls = Grid2d_d
+    elif np.dtype(dtype) == np.dtype(np.float32):
+        cls = Grid2d_f
+    else:
+        raise ValueError('dtype must be np.float32 or np.float64, got {}'.format(dtype))
+    return cls(x, z, n_threads, cell_slowness, method, aniso, eps, maxit, weno, rotated_template, nsnx, nsnz,
+               n_secondary, n_tertiary, radius_factor_tertiary, tt_from_rp, fsm_gpu, device=device)
