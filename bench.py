@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X FSM eikonal solver.
+
+Metric (BASELINE.json): Mnodes/s per sweep-iteration on a 512^3 fp32 grid, plus sources/s.
+Workload at every N (weak scaling): each GPU solves `--sources-per-gpu` (8) sources of the
+64 drawn by the reference's generator (mt19937_64(12345), tests/accuracy_grid3d.cpp:352-360)
+on the 512^3-node gradient model s = 1/(1 + 0.1 z) over [0,20]^3 km, fp32, first-order FSM
+(weno=False, tt_from_rp=False, eps=1e-5, maxit=50), 441 receivers (rcv.dat lattice): config[2]
+of BASELINE.json, i.e. 64 sources over 8 GPUs.  One "step" = one full solve (init + sweep
+iterations to convergence + receiver interpolation) of the rank's sources.  Inputs are
+resident in HBM before the timed region (slowness is broadcast over RCCL and handed to the
+solver as a device pointer); the receiver traveltimes are gathered to rank 0 over RCCL inside
+every step (a few KB).
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_NODE_ITER = 104.0  # 8 sweeps x 12 B + 8 B snapshot, fp32
+
+
+def gradient_slowness_f32(n, dx):
+    z = np.arange(n, dtype=np.float64) * dx
+    s = (1.0 / (1.0 + 0.1 * z)).astype(np.float32)
+    return s
+
+
+def cpu_baseline(n=256, n_src=3):
+    """The CPU restatement (oracle/, bit-exact vs the compiled reference) timed on this box's
+    host cores -- ONE core, like the reference's serial per-source sweep -- on a bounded sample
+    of the same workload: the same gradient model and source generator at n^3 nodes."""
+    import cases
+    from oracle import oracle as O
+
+    dx = 20.0 / (n - 1)
+    s = np.repeat(gradient_slowness_f32(n, dx), n * n)
+    srcs = cases.mt_sources(64)[:n_src]
+    t = time.perf_counter()
+    iters = 0
+    for p in srcs:
+        r = O.solve3d(np.float32, (n - 1,) * 3, dx, (0, 0, 0), s, [p])
+        iters += r["niter"]
+    el = time.perf_counter() - t
+    out = {"value": round(n ** 3 * iters / el / 1e6, 3), "unit": "Mnodes/s per sweep-iteration", "cores": 1,
+           "kind": "port",
+           "sample": f"{n_src} sources (first of the mt19937_64(12345) set) on the {n}^3-node gradient model, fp32, "
+                     f"{iters} sweep-iterations, {el:.1f} s on 1 of {os.cpu_count()} host cores"}
+    # the unmodified compiled reference, when its build travelled with the tree (kind would be "reference")
+    try:
+        if O.have_ref():
+            m = 129
+            dxm = 20.0 / (m - 1)
+            sm = np.repeat(gradient_slowness_f32(m, dxm), m * m)
+            t = time.perf_counter()
+            r = O.ref_solve3d(np.float32, (m - 1,) * 3, dxm, (0, 0, 0), sm, [srcs[0]])
+            el = time.perf_counter() - t
+            out["reference_value"] = round(m ** 3 * r["niter"] / el / 1e6, 3)
+            out["reference_sample"] = f"unmodified reference (oracle/_ref), 1 source on {m}^3 nodes, {el:.1f} s, 1 core"
+    except Exception as e:  # the baseline must never take the bench down
+        out["reference_error"] = str(e)[:200]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512, help="nodes per axis")
+    ap.add_argument("--sources-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-batch", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import cases
+    import ttcr_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.size
+    S = args.sources_per_gpu
+    dx = 20.0 / (n - 1)
+    x = np.arange(n, dtype=np.float64) * dx
+    grid = ttcr_amd.Grid3d(x, x, x, n_threads=S, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0,
+                           dtype=np.float32, device=local_rank)
+    if args.max_batch > 0:
+        grid.set_option("max_batch", args.max_batch)
+
+    # slowness: generated on rank 0 in HBM, broadcast over RCCL/xGMI, handed over as a device pointer
+    s_dev = torch.empty(n * n * n, dtype=torch.float32, device=dev)
+    if rank == 0:
+        sz = torch.from_numpy(gradient_slowness_f32(n, dx)).to(dev)
+        s_dev.copy_(sz.repeat_interleave(n * n))
+        del sz
+    if world > 1:
+        dist.broadcast(s_dev, src=0)
+    torch.cuda.synchronize()
+    grid.set_slowness_device(s_dev.data_ptr(), s_dev.numel())
+
+    all_src = cases.mt_sources(max(64, world * S))
+    my_src = all_src[rank * S:(rank + 1) * S]
+    rcv1 = cases.rcv_lattice3d()
+    # ttcrpy convention: one (source, receiver) row pair per datum
+    src_rows = np.repeat(my_src, rcv1.shape[0], axis=0)
+    rcv_rows = np.tile(rcv1, (S, 1))
+    n_nodes = n ** 3
+
+    gathered = [torch.empty(src_rows.shape[0], dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        tt = grid.raytrace(src_rows, rcv_rows)
+        tm = grid.timing()
+        if world > 1:
+            t_dev = torch.from_numpy(tt).to(dev)
+            dist.gather(t_dev, gathered, dst=0)
+        return tt, tm
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    sweep_ms = 0.0
+    launches = 0
+    node_iters = 0
+    for _ in range(args.steps):
+        tt, tm = step()
+        sweep_ms += tm["sweep_ms"]
+        launches += tm["kernel_launches"]
+        node_iters += tm["node_updates"] // 8
+    fence()
+    el = time.perf_counter() - t0
+    iters_per_src = [grid.get_niter(i) for i in range(S)]
+
+    stats = torch.tensor([el, sweep_ms, float(node_iters), float(launches)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        el_max, sweep_ms_max = float(mx[0]), float(mx[1])
+        node_iters_all = float(sm[2])
+    else:
+        el_max, sweep_ms_max, node_iters_all = el, sweep_ms, float(node_iters)
+
+    if rank == 0:
+        assert np.all(np.isfinite(tt)) and float(tt.max()) < 1e3, "non-physical traveltimes"
+        value = node_iters_all / el_max / 1e6
+        # roofline of the dominant kernel (fsm_sweep_tile), rank 0's launches: algorithmic bytes of
+        # the nodes one launch sequence sweeps / HIP-event time of those launches (ttcr_fsm_last_timing)
+        bytes_total = BYTES_PER_NODE_ITER * node_iters
+        achieved = bytes_total / (sweep_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mnodes/s per sweep-iteration (512^3 fp32 grid, first-order FSM)",
+            "value": round(value, 1),
+            "unit": "Mnodes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(el_max / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "sources_per_s": round(world * S * args.steps / el_max, 3),
+            "config": {"workload": f"Grid3d {n}^3 nodes gradient velocity, {S} sources per GPU ({world * S} total) "
+                                   f"of the mt19937_64(12345) set, 441 receivers, fp32, weno=False, tt_from_rp=False",
+                       "grid_nodes": n_nodes, "sources_per_gpu": S, "sweep_iterations_per_source": iters_per_src,
+                       "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, gather of traveltimes)"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "fsm_sweep_tile<float,16,16,16,true>",
+                         "algorithmic_bytes_per_node_per_sweep_iteration": BYTES_PER_NODE_ITER,
+                         "launches": int(launches), "avg_launch_us_hip_events": round(sweep_ms * 1e3 / max(launches, 1), 3),
+                         "algorithmic_bytes_per_launch": round(bytes_total / max(launches, 1), 1)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,8 @@ class GridT : public GridBase {
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
     DevBuf<uint32_t> d_mask;
     DevBuf<int> d_bbox, d_slots;
+    DevBuf<uint32_t> d_tiles;            // per launch w: the patches that have nodes in it
+    std::vector<int> tile_off, tile_cnt;  // offsets / counts into d_tiles
     DevBuf<double> d_change;
     DevBuf<InitPoint<T>> d_pts;
     double* h_change = nullptr;  // pinned
@@ -181,6 +183,33 @@ class GridT : public GridBase {
             n_launch = count_launches(C::BL);
         }
         geom.n_nodes = (uint32_t)n_nodes;
+        if (dim == 3) build_tile_lists(TileCfg<T, 3>::PJ, TileCfg<T, 3>::PK, TileCfg<T, 3>::BL);
+        else build_tile_lists(TileCfg<T, 2>::PJ, TileCfg<T, 2>::PK, TileCfg<T, 2>::BL);
+    }
+
+    // For every launch w of a sweep, the patches (TJ,TK) whose level window
+    // [BL*w - (TJ+TK)*(BL-1), +BL) contains nodes.  Direction-independent (oriented indices).
+    void build_tile_lists(int PJ, int PK, int BL) {
+        std::vector<uint32_t> all;
+        tile_off.assign(n_launch, 0);
+        tile_cnt.assign(n_launch, 0);
+        for (int w = 0; w < n_launch; ++w) {
+            tile_off[w] = (int)all.size();
+            // anti-diagonal order keeps tiles that share halo columns close in the list
+            for (int m = 0; m <= geom.npj + geom.npk - 2; ++m) {
+                const int L0 = BL * w - m * (BL - 1);
+                for (int TK = std::max(0, m - geom.npj + 1); TK <= std::min(m, geom.npk - 1); ++TK) {
+                    const int TJ = m - TK;
+                    const int j0 = TJ * PJ, k0 = TK * PK;
+                    const int jmaxp = std::min(j0 + PJ, geom.NJ) - 1, kmaxp = std::min(k0 + PK, geom.NK) - 1;
+                    if (L0 + BL - 1 < j0 + k0 || L0 > jmaxp + kmaxp + geom.NF - 1) continue;
+                    all.push_back((uint32_t)TJ | ((uint32_t)TK << 16));
+                }
+            }
+            tile_cnt[w] = (int)all.size() - tile_off[w];
+        }
+        d_tiles.reserve(std::max<size_t>(all.size(), 1));
+        HIP_CHECK(hipMemcpy(d_tiles.p, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
 
     ~GridT() override {
@@ -353,7 +382,7 @@ class GridT : public GridBase {
         a.dx = dx;
         a.dz = dz;
         a.variant = DIM == 3 ? 0 : (dx == dz ? 1 : 2);
-        const dim3 grid(geom.npj, geom.npk, batch), block(C::PJ * C::PK);
+        const dim3 block(C::PJ * C::PK);
         const int ndir = DIM == 3 ? 8 : 4;
         // 2-D direction order (i+,j+), (i-,j+), (i-,j-), (i+,j-)  (ttcr/Grid2Drn.h:717-751);
         // here F = z (the reference's j), J = x (the reference's i)
@@ -365,7 +394,10 @@ class GridT : public GridBase {
                 a.rj = RX2[d]; a.rf = RZ2[d]; a.rk = 0;
             }
             for (int w = 0; w < n_launch; ++w) {
+                if (tile_cnt[w] == 0) continue;
                 a.w = w;
+                a.tiles = d_tiles.p + tile_off[w];
+                const dim3 grid(tile_cnt[w], 1, batch);
                 fsm_sweep_tile<T, C::PJ, C::PK, C::BL, DIM == 3><<<grid, block, 0, stream>>>(a);
             }
         }

@@ -58,36 +58,33 @@ __device__ __forceinline__ double rmax(double a, double b) { return a < b ? b : 
 // inputs: the three axis minima (any order), node slowness s, cell size dx. Returns candidate t.
 __device__ __forceinline__ float update3(float ax, float ay, float az, float s, float dx) {
     // sort (std::swap network of :2936-2938; values only, so min/max is equivalent)
-    const float lo = rmin(rmin(ax, ay), az);
-    const float hi = rmax(rmax(ax, ay), az);
-    const float mid = rmax(rmin(ax, ay), rmin(rmax(ax, ay), az));
-    const float a1 = lo, a2 = mid, a3 = hi;
+    const float a1 = rmin(rmin(ax, ay), az);
+    const float a3 = rmax(rmax(ax, ay), az);
+    const float a2 = rmax(rmin(ax, ay), rmin(rmax(ax, ay), az));
     const float fh = s * dx;
-    float t = a1 + fh;
-    if (t > a2) {
-        const double d1 = a1, d2 = a2, dfh = fh;
-        // 2.*fh*fh - (a1-a2)*(a1-a2): product exact in double, (a1-a2)^2 rounded in float
-        const float df = a1 - a2;
-        const float df2 = df * df;
-        const double disc2 = __builtin_fma(2.0 * dfh, dfh, -(double)df2);
-        const float s12 = a1 + a2;
-        t = (float)(0.5 * ((double)s12 + __builtin_sqrt(disc2)));
-        if (t > a3) {
-            const double d3 = a3;
-            // -2.*a1*a1 + 2.*a1*a2 - 2.*a2*a2 + 2.*a1*a3 + 2.*a2*a3 - 2.*a3*a3 + 3.*fh*fh,
-            // left to right; every product is exact in double, each fma rounds once like the add
-            double r = (-2.0 * d1) * d1;
-            r = __builtin_fma(2.0 * d1, d2, r);
-            r = __builtin_fma(-2.0 * d2, d2, r);
-            r = __builtin_fma(2.0 * d1, d3, r);
-            r = __builtin_fma(2.0 * d2, d3, r);
-            r = __builtin_fma(-2.0 * d3, d3, r);
-            r = __builtin_fma(3.0 * dfh, dfh, r);
-            const float s123 = s12 + a3;
-            t = (float)((1. / 3.) * ((double)s123 + __builtin_sqrt(r)));
-        }
-    }
-    return t;
+    const float t1 = a1 + fh;
+    // The reference nests the 2-D and 3-D quadratics in `if`s; both are evaluated here
+    // unconditionally and selected afterwards (same values, same comparisons), so the two fp64
+    // sqrt chains are independent and overlap instead of running back to back.
+    const double d1 = a1, d2 = a2, d3 = a3, dfh = fh;
+    // 2.*fh*fh - (a1-a2)*(a1-a2): product exact in double, (a1-a2)^2 rounded in float
+    const float df = a1 - a2;
+    const float df2 = df * df;
+    const double disc2 = __builtin_fma(2.0 * dfh, dfh, -(double)df2);
+    // -2.*a1*a1 + 2.*a1*a2 - 2.*a2*a2 + 2.*a1*a3 + 2.*a2*a3 - 2.*a3*a3 + 3.*fh*fh, left to
+    // right; every product is exact in double, so each fma rounds once exactly like the add
+    double r = (-2.0 * d1) * d1;
+    r = __builtin_fma(2.0 * d1, d2, r);
+    r = __builtin_fma(-2.0 * d2, d2, r);
+    r = __builtin_fma(2.0 * d1, d3, r);
+    r = __builtin_fma(2.0 * d2, d3, r);
+    r = __builtin_fma(-2.0 * d3, d3, r);
+    r = __builtin_fma(3.0 * dfh, dfh, r);
+    const float s12 = a1 + a2;
+    const float s123 = s12 + a3;
+    const float t2 = (float)(0.5 * ((double)s12 + __builtin_sqrt(disc2)));
+    const float t3 = (float)((1. / 3.) * ((double)s123 + __builtin_sqrt(r)));
+    return t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
 }
 
 __device__ __forceinline__ double update3(double ax, double ay, double az, double s, double dx) {
@@ -168,6 +165,7 @@ struct SweepArgs {
     const int* bbox;          // [n_slots][6] natural-index bounding box of frozen nodes (lo/hi per F,J,K)
     double* change;           // [n_slots] L1 decrease accumulated over the iteration
     const int* slots;         // [batch] slot handled by blockIdx.z
+    const uint32_t* tiles;    // (TJ | TK<<16) of the patches that have nodes in launch w (blockIdx.x)
     SweepGeom g;
     uint32_t mask_words;
     T dx, dz;                 // cell size along J-axis(x)/F-axis(z) in 2-D; dx only in 3-D
@@ -190,7 +188,8 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
     __shared__ T St[NT * SS];
 
     const int tid = threadIdx.x;
-    const int TJ = blockIdx.x, TK = blockIdx.y;
+    const uint32_t tile = a.tiles[blockIdx.x];
+    const int TJ = tile & 0xffffu, TK = tile >> 16;
     const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
     const int j0 = TJ * PJ, k0 = TK * PK;
     const int jmaxp = (j0 + PJ < NJ ? j0 + PJ : NJ) - 1;
@@ -206,30 +205,40 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
     const T INF = real_traits<T>::inf();
     const int rf = a.rf, rj = a.rj, rk = a.rk;
 
-    // ---- stage the T tile: rows = columns (with halo), entries = levels L0-1 .. L0+BL
-    for (int f = tid; f < NROWS * NQ; f += NT) {
+    // ---- stage the T tile: rows = columns (with halo), entries = levels L0-1 .. L0+BL.
+    // All global loads are issued first (registers), then written to LDS, so the ~1 us HBM/L2
+    // latency is paid once per tile instead of once per element.
+    constexpr int TOT = NROWS * NQ;
+    constexpr int NLD = (TOT + NT - 1) / NT;
+    T tv[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int f = tid + it * NT;
         const int row = f / NQ, q = f - row * NQ;
         const int hj = row % RJ - 1;
         const int hk = IS3D ? row / RJ - 1 : 0;
         const bool halo_j = (hj < 0) | (hj >= PJ);
         const bool halo_k = IS3D && ((hk < 0) | (hk >= PK));
-        if (halo_j && halo_k) continue;  // corner rows are never read
-        // upwind halo rows are read at q-1 (q in 0..BL-1), downwind ones at q+1 (2..BL+1)
-        if (((hj < 0) | (hk < 0)) && q > BL - 1) continue;
-        if (((hj >= PJ) | (IS3D && hk >= PK)) && q < 2) continue;
+        // corner rows are never read; upwind halo rows are read at q-1 (q in 0..BL-1),
+        // downwind ones at q+1 (2..BL+1): do not touch what a concurrent tile may be writing
+        bool need = (f < TOT) & !(halo_j & halo_k);
+        need &= !((((hj < 0) | (hk < 0)) & (q > BL - 1)) | (((hj >= PJ) | (IS3D && hk >= PK)) & (q < 2)));
         const int jp = j0 + hj, kp = k0 + hk;
         const int ip = L0 - 1 + q - jp - kp;
         T v = INF;
-        if (jp >= 0 && jp < NJ && kp >= 0 && kp < NK && ip >= 0 && ip < NF) {
+        if (need && jp >= 0 && jp < NJ && kp >= 0 && kp < NK && ip >= 0 && ip < NF) {
             const int i = rf ? NF - 1 - ip : ip;
             const int j = rj ? NJ - 1 - jp : jp;
             const int k = rk ? NK - 1 - kp : kp;
             v = Tg[((uint32_t)k * NJ + j) * NF + i];
         }
-        Tt[row * RS + q] = v;
+        tv[it] = v;
     }
-    // ---- stage node slowness of the own columns, levels L0 .. L0+BL-1
-    for (int f = tid; f < NT * BL; f += NT) {
+    // ---- node slowness of the own columns, levels L0 .. L0+BL-1
+    T sv[BL];
+#pragma unroll
+    for (int it = 0; it < BL; ++it) {
+        const int f = tid + it * NT;
         const int c = f / BL, q = f - c * BL;
         const int jp = j0 + c % PJ, kp = k0 + c / PJ;
         const int ip = L0 + q - jp - kp;
@@ -240,7 +249,19 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
             const int k = rk ? NK - 1 - kp : kp;
             v = Sg[((uint32_t)k * NJ + j) * NF + i];
         }
-        St[c * SS + q] = v;
+        sv[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int f = tid + it * NT;
+        const int row = f / NQ, q = f - row * NQ;
+        if (f < TOT) Tt[row * RS + q] = tv[it];
+    }
+#pragma unroll
+    for (int it = 0; it < BL; ++it) {
+        const int f = tid + it * NT;
+        const int c = f / BL, q = f - c * BL;
+        St[c * SS + q] = sv[it];
     }
 
     // ---- does this tile touch the frozen (source) neighbourhood?  block-uniform test

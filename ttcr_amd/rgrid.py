@@ -72,6 +72,12 @@ class _GridBase:
         """Backend knob (fixed_iters, max_batch, use_graph); no reference equivalent."""
         _lib.check(self._lib.ttcr_fsm_set_option(self._h, key.encode(), float(value)))
 
+    def set_slowness_device(self, device_ptr, n):
+        """Assign slowness that is already resident in HBM on this grid's device: `device_ptr`
+        is a raw device address (e.g. torch_tensor.data_ptr()) of `n` values of the grid dtype in
+        the solver's flat order (3-D: x-fastest, 2-D: z-fastest).  No PCIe copy."""
+        _lib.check(self._lib.ttcr_fsm_set_slowness_device(self._h, C.c_void_p(int(device_ptr)), int(n)))
+
     def get_niter(self, thread_no=0):
         """Sweep-iterations of the last solve in a slot (Grid3Drnfs::get_niter, ttcr/Grid3Drnfs.h:56)."""
         a, b = C.c_int(), C.c_int()
