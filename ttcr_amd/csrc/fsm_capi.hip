@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <sstream>
@@ -105,11 +106,14 @@ class GridT : public GridBase {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
+    DevBuf<T> d_ssh;         // sheared copies of the node slowness, one per direction family
+    size_t ssh_stride = 0;   // elements per copy: NK * M * NJ
     DevBuf<uint32_t> d_mask;
     DevBuf<int> d_bbox, d_slots;
     DevBuf<uint32_t> d_tiles;            // per launch w: the patches that have nodes in it
     std::vector<int> tile_off, tile_cnt;  // offsets / counts into d_tiles
     DevBuf<double> d_change;
+    DevBuf<unsigned long long> d_prof;  // TTCR_FSM_PROF=1 debug phase timers
     DevBuf<InitPoint<T>> d_pts;
     double* h_change = nullptr;  // pinned
     int* h_slots = nullptr;      // pinned
@@ -165,6 +169,10 @@ class GridT : public GridBase {
         d_bbox.reserve(6 * (size_t)n_slots);
         d_slots.reserve(n_slots);
         d_change.reserve(n_slots);
+        if (std::getenv("TTCR_FSM_PROF")) {
+            d_prof.reserve(8);
+            HIP_CHECK(hipMemset(d_prof.p, 0, 8 * sizeof(unsigned long long)));
+        }
         HIP_CHECK(hipHostMalloc((void**)&h_change, sizeof(double) * n_slots));
         HIP_CHECK(hipHostMalloc((void**)&h_slots, sizeof(int) * n_slots));
         HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_slots * sizeof(T), stream));
@@ -183,6 +191,9 @@ class GridT : public GridBase {
             n_launch = count_launches(C::BL);
         }
         geom.n_nodes = (uint32_t)n_nodes;
+        geom.M = std::max(geom.NF, geom.NJ);
+        ssh_stride = (size_t)geom.NK * geom.M * geom.NJ;
+        d_ssh.reserve(ssh_stride * (dim == 3 ? 4 : 2));
         if (dim == 3) build_tile_lists(TileCfg<T, 3>::PJ, TileCfg<T, 3>::PK, TileCfg<T, 3>::BL);
         else build_tile_lists(TileCfg<T, 2>::PJ, TileCfg<T, 2>::PK, TileCfg<T, 2>::BL);
     }
@@ -245,6 +256,15 @@ class GridT : public GridBase {
                 fsm_cells_to_nodes3d<T><<<blocks, 256, 0, stream>>>(d_cells.p, d_s.p, (int)ncx, (int)ncy, (int)ncz);
             else
                 fsm_cells_to_nodes2d<T><<<blocks, 256, 0, stream>>>(d_cells.p, d_s.p, (int)ncx, (int)ncz);
+            HIP_CHECK(hipGetLastError());
+        }
+        // sheared copies (fsm_kernels.h: fsm_shear_slowness): family = F/J flips with K (3-D) or
+        // J (2-D) not flipped; a direction and its opposite share one copy
+        {
+            const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
+            const int nfam = dim == 3 ? 4 : 2;
+            for (int f = 0; f < nfam; ++f)
+                fsm_shear_slowness<T><<<blocks, 256, 0, stream>>>(d_s.p, d_ssh.p + (size_t)f * ssh_stride, geom, f & 1, (f >> 1) & 1);
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -372,12 +392,12 @@ class GridT : public GridBase {
         using C = TileCfg<T, DIM>;
         SweepArgs<T> a;
         a.tt = d_tt.p;
-        a.slowness = d_s.p;
         a.frozen = d_mask.p;
         a.bbox = d_bbox.p;
         a.change = d_change.p;
         a.slots = d_slots.p;
         a.g = geom;
+        a.prof = d_prof.p;
         a.mask_words = (uint32_t)mask_words;
         a.dx = dx;
         a.dz = dz;
@@ -388,11 +408,17 @@ class GridT : public GridBase {
         // here F = z (the reference's j), J = x (the reference's i)
         static const int RX2[4] = {0, 1, 1, 0}, RZ2[4] = {0, 0, 1, 1};
         for (int d = 0; d < ndir; ++d) {
+            int fam;
             if (DIM == 3) {
                 a.rf = d & 1; a.rj = (d >> 1) & 1; a.rk = (d >> 2) & 1;  // ttcr/Grid3Drn.h:2816-2899
+                a.rev = a.rk;
+                fam = (a.rf ^ a.rk) | ((a.rj ^ a.rk) << 1);
             } else {
                 a.rj = RX2[d]; a.rf = RZ2[d]; a.rk = 0;
+                a.rev = a.rj;
+                fam = a.rf ^ a.rj;
             }
+            a.s_sheared = d_ssh.p + (size_t)fam * ssh_stride;
             for (int w = 0; w < n_launch; ++w) {
                 if (tile_cnt[w] == 0) continue;
                 a.w = w;
@@ -499,6 +525,14 @@ class GridT : public GridBase {
         }
         HIP_CHECK(hipEventRecord(ev1, stream));
         HIP_CHECK(hipEventSynchronize(ev1));
+        if (d_prof.p) {
+            unsigned long long h[8];
+            HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemset(d_prof.p, 0, sizeof(h)));
+            const double nb_ = (double)std::max<unsigned long long>(h[4], 1);
+            std::fprintf(stderr, "[ttcr_amd prof] tiles %llu  per tile (us): setup %.2f  stage %.2f  march %.2f  writeback %.2f\n",
+                         h[4], h[0] * 0.01 / nb_, h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_);
+        }
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.sweep_ms += ms;

@@ -56,50 +56,57 @@ __device__ __forceinline__ double rmax(double a, double b) { return a < b ? b : 
 
 // ---- 3-D local solver: Grid3Drn::update_node, ttcr/Grid3Drn.h:2936-2956 -------------------
 // inputs: the three axis minima (any order), node slowness s, cell size dx. Returns candidate t.
-__device__ __forceinline__ float update3(float ax, float ay, float az, float s, float dx) {
-    // sort (std::swap network of :2936-2938; values only, so min/max is equivalent)
-    const float a1 = rmin(rmin(ax, ay), az);
-    const float a3 = rmax(rmax(ax, ay), az);
-    const float a2 = rmax(rmin(ax, ay), rmin(rmax(ax, ay), az));
+// `live`: lanes whose result is used.  When no live lane of the wavefront leaves the 1-D branch
+// (t1 <= a2: unreached regions, where every neighbour is still FLT_MAX, and grazing fronts) the
+// fp64 work is skipped for the whole wave -- a wave-uniform branch, values unchanged.
+__device__ __forceinline__ float update3(float ax, float ay, float az, float s, float dx, bool live) {
+    // sort (std::swap network of :2936-2938; values only, so min/max/med3 is equivalent)
+    const float a1 = __builtin_fminf(__builtin_fminf(ax, ay), az);
+    const float a3 = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+    const float a2 = __builtin_amdgcn_fmed3f(ax, ay, az);
     const float fh = s * dx;
     const float t1 = a1 + fh;
-    // The reference nests the 2-D and 3-D quadratics in `if`s; both are evaluated here
-    // unconditionally and selected afterwards (same values, same comparisons), so the two fp64
-    // sqrt chains are independent and overlap instead of running back to back.
-    const double d1 = a1, d2 = a2, d3 = a3, dfh = fh;
-    // 2.*fh*fh - (a1-a2)*(a1-a2): product exact in double, (a1-a2)^2 rounded in float
-    const float df = a1 - a2;
-    const float df2 = df * df;
-    const double disc2 = __builtin_fma(2.0 * dfh, dfh, -(double)df2);
-    // -2.*a1*a1 + 2.*a1*a2 - 2.*a2*a2 + 2.*a1*a3 + 2.*a2*a3 - 2.*a3*a3 + 3.*fh*fh, left to
-    // right; every product is exact in double, so each fma rounds once exactly like the add
-    double r = (-2.0 * d1) * d1;
-    r = __builtin_fma(2.0 * d1, d2, r);
-    r = __builtin_fma(-2.0 * d2, d2, r);
-    r = __builtin_fma(2.0 * d1, d3, r);
-    r = __builtin_fma(2.0 * d2, d3, r);
-    r = __builtin_fma(-2.0 * d3, d3, r);
-    r = __builtin_fma(3.0 * dfh, dfh, r);
-    const float s12 = a1 + a2;
-    const float s123 = s12 + a3;
-    const float t2 = (float)(0.5 * ((double)s12 + __builtin_sqrt(disc2)));
-    const float t3 = (float)((1. / 3.) * ((double)s123 + __builtin_sqrt(r)));
-    return t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
+    float t = t1;
+    if (__any(live && t1 > a2)) {
+        // The reference nests the 2-D and 3-D quadratics in `if`s; both are evaluated here and
+        // selected afterwards (same values, same comparisons), so the two fp64 sqrt chains are
+        // independent and overlap instead of running back to back.
+        const double d1 = a1, d2 = a2, d3 = a3, dfh = fh;
+        // 2.*fh*fh - (a1-a2)*(a1-a2): product exact in double, (a1-a2)^2 rounded in float
+        const float df = a1 - a2;
+        const float df2 = df * df;
+        const double disc2 = __builtin_fma(2.0 * dfh, dfh, -(double)df2);
+        // -2.*a1*a1 + 2.*a1*a2 - 2.*a2*a2 + 2.*a1*a3 + 2.*a2*a3 - 2.*a3*a3 + 3.*fh*fh, left to
+        // right; every product is exact in double, so each fma rounds once exactly like the add
+        double r = (-2.0 * d1) * d1;
+        r = __builtin_fma(2.0 * d1, d2, r);
+        r = __builtin_fma(-2.0 * d2, d2, r);
+        r = __builtin_fma(2.0 * d1, d3, r);
+        r = __builtin_fma(2.0 * d2, d3, r);
+        r = __builtin_fma(-2.0 * d3, d3, r);
+        r = __builtin_fma(3.0 * dfh, dfh, r);
+        const float s12 = a1 + a2;
+        const float s123 = s12 + a3;
+        const float t2 = (float)(0.5 * ((double)s12 + __builtin_sqrt(disc2)));
+        const float t3 = (float)((1. / 3.) * ((double)s123 + __builtin_sqrt(r)));
+        t = t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
+    }
+    return t;
 }
 
-__device__ __forceinline__ double update3(double ax, double ay, double az, double s, double dx) {
-    const double a1 = rmin(rmin(ax, ay), az);
-    const double a3 = rmax(rmax(ax, ay), az);
-    const double a2 = rmax(rmin(ax, ay), rmin(rmax(ax, ay), az));
+__device__ __forceinline__ double update3(double ax, double ay, double az, double s, double dx, bool live) {
+    const double a1 = __builtin_fmin(__builtin_fmin(ax, ay), az);
+    const double a3 = __builtin_fmax(__builtin_fmax(ax, ay), az);
+    const double a2 = __builtin_fmax(__builtin_fmin(ax, ay), __builtin_fmin(__builtin_fmax(ax, ay), az));
     const double fh = s * dx;
-    double t = a1 + fh;
-    if (t > a2) {
-        t = 0.5 * (a1 + a2 + __builtin_sqrt(2. * fh * fh - (a1 - a2) * (a1 - a2)));
-        if (t > a3) {
-            t = 1. / 3. * ((a1 + a2 + a3) + __builtin_sqrt(-2. * a1 * a1 + 2. * a1 * a2 - 2. * a2 * a2 +
-                                                            2. * a1 * a3 + 2. * a2 * a3 -
-                                                            2. * a3 * a3 + 3. * fh * fh));
-        }
+    const double t1 = a1 + fh;
+    double t = t1;
+    if (__any(live && t1 > a2)) {
+        const double t2 = 0.5 * (a1 + a2 + __builtin_sqrt(2. * fh * fh - (a1 - a2) * (a1 - a2)));
+        const double t3 = 1. / 3. * ((a1 + a2 + a3) + __builtin_sqrt(-2. * a1 * a1 + 2. * a1 * a2 - 2. * a2 * a2 +
+                                                                      2. * a1 * a3 + 2. * a2 * a3 -
+                                                                      2. * a3 * a3 + 3. * fh * fh));
+        t = t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
     }
     return t;
 }
@@ -154,13 +161,33 @@ __device__ __forceinline__ double update2_xz(double a, double b, double sn, doub
 struct SweepGeom {
     int NF, NJ, NK;        // node counts
     int npj, npk;          // patches along J and K
+    int M;                 // shear modulus = max(NF, NJ)
     uint32_t n_nodes;      // NF*NJ*NK
 };
+
+// Sheared slowness.  A thread marches along F but a wavefront is laid out along J, so at a given
+// level the 64 lanes of a wave read nodes that are NF-1 elements apart in the natural layout.
+// set_slowness therefore keeps, per direction family, a copy laid out as
+//     A[k'][(i'+j') mod M][j']        (oriented indices, M = max(NF,NJ))
+// in which the nodes of one level and one k' are contiguous in j': the per-level slowness load
+// of a wave is a coalesced row read straight into registers (no LDS staging, no transposition).
+// A direction and its opposite traverse the same array backwards, so 4 (3-D) / 2 (2-D) copies.
+template <typename T>
+__global__ void fsm_shear_slowness(const T* __restrict__ s, T* __restrict__ out, SweepGeom g, int rf, int rj) {
+    const size_t N = g.n_nodes;
+    for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < N; n += (size_t)gridDim.x * blockDim.x) {
+        const int i = n % g.NF, j = (n / g.NF) % g.NJ, k = n / ((size_t)g.NF * g.NJ);
+        const int ip = rf ? g.NF - 1 - i : i, jp = rj ? g.NJ - 1 - j : j;
+        int x = ip + jp;
+        x = x >= g.M ? x - g.M : x;
+        out[((size_t)k * g.M + x) * g.NJ + jp] = s[n];
+    }
+}
 
 template <typename T>
 struct SweepArgs {
     T* tt;                    // [n_slots][n_nodes] traveltime fields
-    const T* slowness;        // [n_nodes] node slowness
+    const T* s_sheared;       // sheared node slowness of this direction's family
     const uint32_t* frozen;   // [n_slots][mask_words] frozen bit per node
     const int* bbox;          // [n_slots][6] natural-index bounding box of frozen nodes (lo/hi per F,J,K)
     double* change;           // [n_slots] L1 decrease accumulated over the iteration
@@ -170,9 +197,22 @@ struct SweepArgs {
     uint32_t mask_words;
     T dx, dz;                 // cell size along J-axis(x)/F-axis(z) in 2-D; dx only in 3-D
     int rf, rj, rk;           // 1: axis swept in decreasing index
+    int rev;                  // 1: s_sheared is traversed backwards (opposite direction of its family)
     int w;                    // launch index within the sweep
     int variant;              // 0: 3-D, 1: 2-D square cells, 2: 2-D dx != dz
+    unsigned long long* prof; // debug (TTCR_FSM_PROF=1): per-phase wall-clock sums, else nullptr
 };
+
+// debug phase timer: 100 MHz constant clock, thread 0 of every block accumulates phase sums
+#define FSM_PROF_MARK(slot_)                                                      \
+    if (a.prof && tid == 0) {                                                     \
+        const unsigned long long now_ = wall_clock64();                           \
+        atomicAdd(a.prof + (slot_), now_ - prof_t);                               \
+        prof_t = now_;                                                            \
+    }
+
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
 
 template <typename T, int PJ, int PK, int BL, bool IS3D>
 __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
@@ -181,13 +221,12 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
     constexpr int NROWS = IS3D ? RJ * (PK + 2) : RJ;
     constexpr int NQ = BL + 2;                      // levels incl. halo
     constexpr int RS = NQ | 1;                      // odd LDS row stride (bank-conflict-free column reads)
-    constexpr int SS = BL | 1;
     static_assert(IS3D || PK == 1, "2-D uses PK = 1");
 
     __shared__ T Tt[NROWS * RS];
-    __shared__ T St[NT * SS];
 
     const int tid = threadIdx.x;
+    unsigned long long prof_t = a.prof ? wall_clock64() : 0ull;
     const uint32_t tile = a.tiles[blockIdx.x];
     const int TJ = tile & 0xffffu, TK = tile >> 16;
     const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
@@ -195,73 +234,80 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
     const int jmaxp = (j0 + PJ < NJ ? j0 + PJ : NJ) - 1;
     const int kmaxp = (k0 + PK < NK ? k0 + PK : NK) - 1;
     const int L0 = BL * a.w - (TJ + TK) * (BL - 1);
-    // levels at which this patch has nodes
+    // levels at which this patch has nodes (the host only lists such tiles; kept as a guard)
     if (L0 + BL - 1 < j0 + k0 || L0 > jmaxp + kmaxp + NF - 1) return;
 
     const int slot = a.slots[blockIdx.z];
     if (slot < 0) return;  // source already converged: its blocks are masked out of the batch
     T* __restrict__ Tg = a.tt + (size_t)slot * a.g.n_nodes;
-    const T* __restrict__ Sg = a.slowness;
     const T INF = real_traits<T>::inf();
     const int rf = a.rf, rj = a.rj, rk = a.rk;
 
+    // ---- this thread's column and the levels (q = 1..BL <-> level L0-1+q) at which it has a node
+    const int tj = tid % PJ, tk = tid / PJ;
+    const int jp = j0 + tj, kp = k0 + tk;
+    const bool col_ok = jp < NJ && kp < NK;
+    const int row = IS3D ? (tk + 1) * RJ + tj + 1 : tj + 1;
+    const int qoff = jp + kp - L0 + 1;                       // q at which i' == 0
+    const int qa = col_ok ? (qoff > 1 ? qoff : 1) : BL + 1;  // first / last active q
+    const int qb = qoff + NF - 1 < BL ? qoff + NF - 1 : BL;
+
+    // ---- node slowness of the own column, straight from the sheared copy into registers
+    T sv[BL];
+    {
+        const T* __restrict__ Sg = a.s_sheared;
+        const int M = a.g.M;
+        const int jx = a.rev ? NJ - 1 - jp : jp;
+        const int kx = a.rev ? NK - 1 - kp : kp;
+        const size_t base = (size_t)kx * M * NJ + jx;
+#pragma unroll
+        for (int q = 1; q <= BL; ++q) {
+            int x = L0 - 1 + q - kp;  // i' + j' at this level
+            x = a.rev ? NF + NJ - 2 - x : x;
+            x = x >= M ? x - M : x;
+            T v = 0;
+            if (q >= qa && q <= qb) v = Sg[base + (size_t)x * NJ];
+            sv[q - 1] = v;
+        }
+    }
+
+    FSM_PROF_MARK(0)  // setup + slowness loads issued
     // ---- stage the T tile: rows = columns (with halo), entries = levels L0-1 .. L0+BL.
-    // All global loads are issued first (registers), then written to LDS, so the ~1 us HBM/L2
-    // latency is paid once per tile instead of once per element.
+    // All global loads are issued first (registers), then written to LDS, so the HBM/L2 latency
+    // is paid once per tile instead of once per element.
     constexpr int TOT = NROWS * NQ;
     constexpr int NLD = (TOT + NT - 1) / NT;
-    T tv[NLD];
+    {
+        T tv[NLD];
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-        const int f = tid + it * NT;
-        const int row = f / NQ, q = f - row * NQ;
-        const int hj = row % RJ - 1;
-        const int hk = IS3D ? row / RJ - 1 : 0;
-        const bool halo_j = (hj < 0) | (hj >= PJ);
-        const bool halo_k = IS3D && ((hk < 0) | (hk >= PK));
-        // corner rows are never read; upwind halo rows are read at q-1 (q in 0..BL-1),
-        // downwind ones at q+1 (2..BL+1): do not touch what a concurrent tile may be writing
-        bool need = (f < TOT) & !(halo_j & halo_k);
-        need &= !((((hj < 0) | (hk < 0)) & (q > BL - 1)) | (((hj >= PJ) | (IS3D && hk >= PK)) & (q < 2)));
-        const int jp = j0 + hj, kp = k0 + hk;
-        const int ip = L0 - 1 + q - jp - kp;
-        T v = INF;
-        if (need && jp >= 0 && jp < NJ && kp >= 0 && kp < NK && ip >= 0 && ip < NF) {
-            const int i = rf ? NF - 1 - ip : ip;
-            const int j = rj ? NJ - 1 - jp : jp;
-            const int k = rk ? NK - 1 - kp : kp;
-            v = Tg[((uint32_t)k * NJ + j) * NF + i];
+        for (int it = 0; it < NLD; ++it) {
+            const int f = tid + it * NT;
+            const int r = f / NQ, q = f - r * NQ;
+            const int hj = r % RJ - 1;
+            const int hk = IS3D ? r / RJ - 1 : 0;
+            const bool halo_j = (hj < 0) | (hj >= PJ);
+            const bool halo_k = IS3D && ((hk < 0) | (hk >= PK));
+            // corner rows are never read; upwind halo rows are read at q-1 (q in 0..BL-1),
+            // downwind ones at q+1 (2..BL+1): do not touch what a concurrent tile may be writing
+            bool need = (f < TOT) & !(halo_j & halo_k);
+            need &= !((((hj < 0) | (hk < 0)) & (q > BL - 1)) | (((hj >= PJ) | (IS3D && hk >= PK)) & (q < 2)));
+            const int jq = j0 + hj, kq = k0 + hk;
+            const int ip = L0 - 1 + q - jq - kq;
+            T v = INF;
+            if (need && jq >= 0 && jq < NJ && kq >= 0 && kq < NK && ip >= 0 && ip < NF) {
+                const int i = rf ? NF - 1 - ip : ip;
+                const int j = rj ? NJ - 1 - jq : jq;
+                const int k = rk ? NK - 1 - kq : kq;
+                v = Tg[((uint32_t)k * NJ + j) * NF + i];
+            }
+            tv[it] = v;
         }
-        tv[it] = v;
-    }
-    // ---- node slowness of the own columns, levels L0 .. L0+BL-1
-    T sv[BL];
 #pragma unroll
-    for (int it = 0; it < BL; ++it) {
-        const int f = tid + it * NT;
-        const int c = f / BL, q = f - c * BL;
-        const int jp = j0 + c % PJ, kp = k0 + c / PJ;
-        const int ip = L0 + q - jp - kp;
-        T v = 0;
-        if (jp < NJ && kp < NK && ip >= 0 && ip < NF) {
-            const int i = rf ? NF - 1 - ip : ip;
-            const int j = rj ? NJ - 1 - jp : jp;
-            const int k = rk ? NK - 1 - kp : kp;
-            v = Sg[((uint32_t)k * NJ + j) * NF + i];
+        for (int it = 0; it < NLD; ++it) {
+            const int f = tid + it * NT;
+            const int r = f / NQ, q = f - r * NQ;
+            if (f < TOT) Tt[r * RS + q] = tv[it];
         }
-        sv[it] = v;
-    }
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-        const int f = tid + it * NT;
-        const int row = f / NQ, q = f - row * NQ;
-        if (f < TOT) Tt[row * RS + q] = tv[it];
-    }
-#pragma unroll
-    for (int it = 0; it < BL; ++it) {
-        const int f = tid + it * NT;
-        const int c = f / BL, q = f - c * BL;
-        St[c * SS + q] = sv[it];
     }
 
     // ---- does this tile touch the frozen (source) neighbourhood?  block-uniform test
@@ -277,50 +323,54 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
         near_src = !(fhi < bb[0] || flo > bb[1] || jhi < bb[2] || jlo > bb[3] || khi < bb[4] || klo > bb[5]);
     }
     const uint32_t* __restrict__ Fz = a.frozen + (size_t)slot * a.mask_words;
-
-    const int tj = tid % PJ, tk = tid / PJ;
-    const int jp = j0 + tj, kp = k0 + tk;
-    const bool col_ok = jp < NJ && kp < NK;
-    const int row = IS3D ? (tk + 1) * RJ + tj + 1 : tj + 1;
     const int jn = rj ? NJ - 1 - jp : jp;
     const int kn = rk ? NK - 1 - kp : kp;
     const uint32_t colbase = ((uint32_t)kn * NJ + jn) * NF;
     const T dx = a.dx, dz = a.dz;
     const int variant = a.variant;
-    double acc = 0.0;
+    T dec = 0;  // decrease of this thread's nodes in this tile
     bool changed = false;
 
     __syncthreads();
+    FSM_PROF_MARK(1)  // T tile staged
+
+    // own column: levels L0-1 .. L0+BL live in registers; LDS only carries values between columns
+    T own[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) own[q] = Tt[row * RS + q];
 
 #pragma unroll
     for (int q = 1; q <= BL; ++q) {
-        const int ip = L0 - 1 + q - jp - kp;
-        bool active = col_ok && ip >= 0 && ip < NF;
+        bool active = (q >= qa) & (q <= qb);
         if (near_src && active) {
+            const int ip = L0 - 1 + q - jp - kp;
             const uint32_t n = colbase + (rf ? NF - 1 - ip : ip);
             active = !((Fz[n >> 5] >> (n & 31)) & 1u);
         }
-        const T c = Tt[row * RS + q];
+        const T c = own[q];
         // axis minima: a missing neighbour is +inf in the tile == the reference's one-sided pick
-        const T af = rmin(Tt[row * RS + q - 1], Tt[row * RS + q + 1]);
-        const T aj = rmin(Tt[(row - 1) * RS + q - 1], Tt[(row + 1) * RS + q + 1]);
-        const T s = St[tid * SS + q - 1];
+        const T af = vmin(own[q - 1], own[q + 1]);
+        const T aj = vmin(Tt[(row - 1) * RS + q - 1], Tt[(row + 1) * RS + q + 1]);
+        const T s = sv[q - 1];
         T t;
         if (IS3D) {
-            const T ak = rmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
-            t = update3(ak, aj, af, s, dx);
+            const T ak = vmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
+            t = update3(ak, aj, af, s, dx, active);
         } else {
             // 2-D: J axis is x (a), F axis is z (b)
             t = variant == 1 ? update2(aj, af, s, dx) : update2_xz(aj, af, s, dx, dz);
         }
-        if (active && t < c) {
-            Tt[row * RS + q] = t;
-            acc += (double)(c - t);
-            changed = true;
-        }
+        const bool acc = active & (t < c);
+        const T nv = acc ? t : c;
+        dec += acc ? c - t : (T)0;
+        changed |= acc;
+        own[q] = nv;
+        Tt[row * RS + q] = nv;
         __syncthreads();
     }
 
+    FSM_PROF_MARK(2)  // level march
+    if (a.prof && tid == 0) atomicAdd(a.prof + 4, 1ull);
     // ---- write back (only when something in the tile changed)
     if (__syncthreads_or(changed)) {
         for (int f = tid; f < NT * BL; f += NT) {
@@ -337,9 +387,11 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
             }
         }
         // wavefront (64-lane) reduction of the decrease, one atomic per wave
+        double accd = (double)dec;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if ((tid & 63) == 0 && acc != 0.0) atomicAdd(a.change + slot, acc);
+        for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
+        if ((tid & 63) == 0 && accd != 0.0) atomicAdd(a.change + slot, accd);
+        FSM_PROF_MARK(3)  // write-back issued
     }
 }
 
@@ -352,7 +404,7 @@ __global__ void fsm_fill(T* p, size_t n, T v) {
 
 // Grid3Drcfs::setSlowness (ttcr/Grid3Drcfs.h:88-171) / Grid2Drcfs::setSlowness
 // (ttcr/Grid2Drcfs.h:98-138): node slowness = mean of the touching cells, summed in the
-// reference's order (see oracle/fsm_oracle_impl.h for the order analysis).
+// reference's order: k outer / j / i inner, except on the x-min/x-max faces where k is innermost.
 template <typename T>
 __global__ void fsm_cells_to_nodes3d(const T* __restrict__ sc, T* __restrict__ sn, int ncx, int ncy, int ncz) {
     const int nnx = ncx + 1, nny = ncy + 1, nnz = ncz + 1;
