@@ -20,6 +20,10 @@
 #include "../../include/ttcr_amd.h"
 #include "fsm_kernels.h"
 
+#ifndef FSM_CHUNK3
+#define FSM_CHUNK3 8
+#endif
+
 namespace ttcr_amd {
 
 static thread_local std::string g_last_error;
@@ -82,6 +86,7 @@ class GridBase {
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter;
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
+    int mode = 0;  // 0: one launch per tile wavefront, 1: persistent kernel (one launch per sweep)
     Timing timing;
 };
 
@@ -91,6 +96,8 @@ template <> struct TileCfg<float, 3> { static constexpr int PJ = 16, PK = 16, BL
 template <> struct TileCfg<double, 3> { static constexpr int PJ = 16, PK = 8, BL = 16; };
 template <> struct TileCfg<float, 2> { static constexpr int PJ = 128, PK = 1, BL = 32; };
 template <> struct TileCfg<double, 2> { static constexpr int PJ = 128, PK = 1, BL = 32; };
+// chunk length of the persistent kernel
+template <typename T, int DIM> struct ChunkCfg { static constexpr int C = DIM == 3 ? FSM_CHUNK3 : 16; };
 
 template <typename T>
 class GridT : public GridBase {
@@ -114,6 +121,10 @@ class GridT : public GridBase {
     std::vector<int> tile_off, tile_cnt;  // offsets / counts into d_tiles
     DevBuf<double> d_change;
     DevBuf<unsigned long long> d_prof;  // TTCR_FSM_PROF=1 debug phase timers
+    DevBuf<uint32_t> d_order;  // persistent kernel: patches in ticket order (anti-diagonal major)
+    DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
+    int n_patches = 0;
+    int* h_abort = nullptr;    // pinned
     DevBuf<InitPoint<T>> d_pts;
     double* h_change = nullptr;  // pinned
     int* h_slots = nullptr;      // pinned
@@ -122,7 +133,7 @@ class GridT : public GridBase {
     int n_launch = 0;  // launches per sweep direction
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    int graph_batch = 0;
+    int graph_batch = 0, graph_mode = -1;
 
     GridT(int dim_, bool cell_, uint32_t nx, uint32_t ny, uint32_t nz, double ddx, double ddz, double minx,
           double miny, double minz, double eps, int maxit, int nslots, bool translate_, int dev) {
@@ -175,6 +186,8 @@ class GridT : public GridBase {
         }
         HIP_CHECK(hipHostMalloc((void**)&h_change, sizeof(double) * n_slots));
         HIP_CHECK(hipHostMalloc((void**)&h_slots, sizeof(int) * n_slots));
+        HIP_CHECK(hipHostMalloc((void**)&h_abort, sizeof(int)));
+        *h_abort = 0;
         HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_slots * sizeof(T), stream));
 
         if (dim == 3) {
@@ -196,6 +209,68 @@ class GridT : public GridBase {
         d_ssh.reserve(ssh_stride * (dim == 3 ? 4 : 2));
         if (dim == 3) build_tile_lists(TileCfg<T, 3>::PJ, TileCfg<T, 3>::PK, TileCfg<T, 3>::BL);
         else build_tile_lists(TileCfg<T, 2>::PJ, TileCfg<T, 2>::PK, TileCfg<T, 2>::BL);
+        build_persistent_lists();
+        if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
+    }
+
+    // persistent kernel: ticket order = anti-diagonal m = TJ+TK major (a topological order of the
+    // patch dependencies), progress counters per (source slot in batch, patch)
+    void build_persistent_lists() {
+        std::vector<uint32_t> order;
+        for (int m = 0; m <= geom.npj + geom.npk - 2; ++m)
+            for (int TK = std::max(0, m - geom.npj + 1); TK <= std::min(m, geom.npk - 1); ++TK)
+                order.push_back((uint32_t)(m - TK) | ((uint32_t)TK << 16));
+        n_patches = (int)order.size();
+        d_order.reserve(order.size());
+        HIP_CHECK(hipMemcpy(d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        d_sync.reserve(2 + (size_t)n_patches * n_slots);
+    }
+
+    template <int DIM>
+    void launch_sweeps_persistent(int batch) {
+        using C = TileCfg<T, DIM>;
+        constexpr int CH = ChunkCfg<T, DIM>::C;
+        PersistArgs<T> pa;
+        SweepArgs<T>& a = pa.s;
+        a.tt = d_tt.p;
+        a.frozen = d_mask.p;
+        a.bbox = d_bbox.p;
+        a.change = d_change.p;
+        a.slots = d_slots.p;
+        a.tiles = nullptr;
+        a.g = geom;
+        a.prof = d_prof.p;
+        a.mask_words = (uint32_t)mask_words;
+        a.dx = dx;
+        a.dz = dz;
+        a.w = 0;
+        a.variant = DIM == 3 ? 0 : (dx == dz ? 1 : 2);
+        pa.order = d_order.p;
+        pa.sync = d_sync.p;
+        pa.n_patches = n_patches;
+        pa.batch = batch;
+        pa.timeout_ticks = 300000000ull;  // 3 s at 100 MHz
+        const dim3 block(C::PJ * C::PK), grid((unsigned)n_patches * batch);
+        const int ndir = DIM == 3 ? 8 : 4;
+        static const int RX2[4] = {0, 1, 1, 0}, RZ2[4] = {0, 0, 1, 1};
+        for (int d = 0; d < ndir; ++d) {
+            int fam;
+            if (DIM == 3) {
+                a.rf = d & 1; a.rj = (d >> 1) & 1; a.rk = (d >> 2) & 1;
+                a.rev = a.rk;
+                fam = (a.rf ^ a.rk) | ((a.rj ^ a.rk) << 1);
+            } else {
+                a.rj = RX2[d]; a.rf = RZ2[d]; a.rk = 0;
+                a.rev = a.rj;
+                fam = a.rf ^ a.rj;
+            }
+            a.s_sheared = d_ssh.p + (size_t)fam * ssh_stride;
+            // ticket + progress counters back to zero (the abort word [1] is sticky within an iteration)
+            HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
+            HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
+            fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3><<<grid, block, 0, stream>>>(pa);
+        }
+        HIP_CHECK(hipGetLastError());
     }
 
     // For every launch w of a sweep, the patches (TJ,TK) whose level window
@@ -229,6 +304,7 @@ class GridT : public GridBase {
         if (graph) (void)hipGraphDestroy(graph);
         if (h_change) (void)hipHostFree(h_change);
         if (h_slots) (void)hipHostFree(h_slots);
+        if (h_abort) (void)hipHostFree(h_abort);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -430,15 +506,23 @@ class GridT : public GridBase {
         HIP_CHECK(hipGetLastError());
     }
 
+    void issue_sweeps(int batch) {
+        if (mode == 1) {
+            if (dim == 3) launch_sweeps_persistent<3>(batch); else launch_sweeps_persistent<2>(batch);
+        } else {
+            if (dim == 3) launch_sweeps<3>(batch); else launch_sweeps<2>(batch);
+        }
+    }
+
     void run_iteration(int batch) {
         const int ndir = dim == 3 ? 8 : 4;
         if (use_graph) {
-            if (!graph_exec || graph_batch != batch) {
+            if (!graph_exec || graph_batch != batch || graph_mode != mode) {
                 if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
                 if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
                 HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 try {
-                    if (dim == 3) launch_sweeps<3>(batch); else launch_sweeps<2>(batch);
+                    issue_sweeps(batch);
                 } catch (...) {
                     hipGraph_t junk = nullptr;
                     (void)hipStreamEndCapture(stream, &junk);
@@ -448,12 +532,13 @@ class GridT : public GridBase {
                 HIP_CHECK(hipStreamEndCapture(stream, &graph));
                 HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
                 graph_batch = batch;
+                graph_mode = mode;
             }
             HIP_CHECK(hipGraphLaunch(graph_exec, stream));
         } else {
-            if (dim == 3) launch_sweeps<3>(batch); else launch_sweeps<2>(batch);
+            issue_sweeps(batch);
         }
-        timing.launches += (long long)ndir * n_launch;
+        timing.launches += mode == 1 ? (long long)ndir : (long long)ndir * n_launch;
     }
 
     // One batch: sources src_ids[b] solved concurrently, source b in slot slot_ids[b].
@@ -505,6 +590,7 @@ class GridT : public GridBase {
         const int ndir = dim == 3 ? 8 : 4;
         // the graph is built for a fixed z-extent; finished sources are masked with slot -1 ... but
         // a masked block still has to read slots[z], so keep the list compact and pad with -1.
+        if (mode == 1) HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 2 * sizeof(int), stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
         while (!active.empty() && it < maxit) {
             for (int b = 0; b < nb; ++b) h_slots[b] = b < (int)active.size() ? active[b] : -1;
@@ -512,7 +598,12 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
             run_iteration(nb);
             HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
+            if (mode == 1) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
+            if (mode == 1 && *h_abort) {
+                HIP_CHECK(hipMemsetAsync(d_sync.p + 1, 0, sizeof(int), stream));
+                throw DeviceError("persistent sweep kernel: a patch timed out waiting for its upwind neighbour");
+            }
             ++it;
             std::vector<int> next;
             for (int s : active) {
@@ -529,9 +620,15 @@ class GridT : public GridBase {
             unsigned long long h[8];
             HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
             HIP_CHECK(hipMemset(d_prof.p, 0, sizeof(h)));
-            const double nb_ = (double)std::max<unsigned long long>(h[4], 1);
-            std::fprintf(stderr, "[ttcr_amd prof] tiles %llu  per tile (us): setup %.2f  stage %.2f  march %.2f  writeback %.2f\n",
-                         h[4], h[0] * 0.01 / nb_, h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_);
+            if (mode == 1) {
+                const double nb_ = (double)std::max<unsigned long long>(h[7], 1);
+                std::fprintf(stderr, "[ttcr_amd prof] chunks %llu  per chunk (us): issue %.2f  wait %.2f  stage %.2f  march %.2f  publish %.2f\n",
+                             h[7], h[0] * 0.01 / nb_, h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_, h[4] * 0.01 / nb_);
+            } else {
+                const double nb_ = (double)std::max<unsigned long long>(h[4], 1);
+                std::fprintf(stderr, "[ttcr_amd prof] tiles %llu  per tile (us): setup %.2f  stage %.2f  march %.2f  writeback %.2f\n",
+                             h[4], h[0] * 0.01 / nb_, h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_);
+            }
         }
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -768,6 +865,7 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
         if (k == "fixed_iters") g->impl->fixed_iters = (int)value;
         else if (k == "max_batch") g->impl->max_batch = (int)value;
         else if (k == "use_graph") g->impl->use_graph = value != 0;
+        else if (k == "mode") g->impl->mode = (int)value;
         else throw ValueError("unknown option '" + k + "'");
     });
 }

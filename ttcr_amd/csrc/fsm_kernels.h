@@ -395,6 +395,345 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
     }
 }
 
+// ---- persistent sweep kernel: one launch per directional sweep -----------------------------
+// Same skewed pencil march, but a workgroup keeps its patch for the whole sweep and walks its
+// levels in chunks of C; the ordering between patches is carried by per-patch progress counters
+// in HBM instead of by kernel boundaries:
+//   * work units (patch, source) are handed out by an atomic ticket in an order that is a
+//     topological order of the patch dependencies (anti-diagonal m = TJ+TK first), so a unit only
+//     ever waits for units that already started -- no co-residency assumption, no deadlock;
+//   * a unit may run chunk [Lc, Lc+C) once both upwind patches have published every level
+//     <= Lc+C-2 (prog[patch] = number of final levels in HBM);
+//   * hand-off through HBM, MI355X_MICROARCH.md recipe R1 (XCD L2s are not coherent with each
+//     other, a CU's L1 is never refreshed by other CUs' stores): the columns a downstream patch
+//     reads are stored write-through (relaxed agent-scope atomic store = `global_store ... sc1`),
+//     every storing wave drains `s_waitcnt vmcnt(0)`, barrier, ONE lane stores the counter
+//     (relaxed, agent); the consumer polls that one word (relaxed, agent, one lane, s_sleep),
+//     barrier, then reads the upwind halo columns with sc1 loads (bypass L1).
+//   * every spin is bounded (wall clock); on time-out a global abort word makes every waiter
+//     leave, and the host turns it into an error.
+template <typename T>
+struct PersistArgs {
+    SweepArgs<T> s;           // w, tiles unused
+    const uint32_t* order;    // patches in ticket order (TJ | TK<<16), sorted by m = TJ+TK
+    int* sync;                // [0]: ticket counter, [1]: abort flag, [2 + z*n_patches + patch]: progress
+    int n_patches, batch;
+    unsigned long long timeout_ticks;  // 100 MHz wall-clock ticks
+};
+
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store((unsigned int*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int PJ, int PK, int C, bool IS3D>
+__global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs<T> pa) {
+    constexpr int NT = PJ * PK;
+    constexpr int RJ = PJ + 2;
+    constexpr int NROWS = IS3D ? RJ * (PK + 2) : RJ;
+    constexpr int NQ = C + 2;
+    constexpr int RS = NQ | 1;
+    constexpr int NUP = IS3D ? (PJ + PK) : 1;   // upwind halo columns
+    constexpr int NDH = IS3D ? (PJ + PK) : 1;   // downwind halo columns
+    // streaming map: C consecutive lanes walk the C new levels of one column, NT/C columns per pass
+    constexpr int RPI = NT / C;
+    constexpr int NOWN = C;                      // passes over the own columns (NT / RPI)
+    constexpr int NHI = (NDH + RPI - 1) / RPI;   // passes over the downwind halo columns
+    static_assert(NT % C == 0 && (IS3D || PK == 1), "tile shape");
+    const SweepArgs<T>& a = pa.s;
+
+    __shared__ T Tt[NROWS * RS];
+    __shared__ int s_ticket;
+
+    const int tid = threadIdx.x;
+    unsigned long long prof_t = a.prof ? wall_clock64() : 0ull;
+    if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
+    __syncthreads();
+    const int ticket = s_ticket;
+    const int pidx = ticket / pa.batch, z = ticket - pidx * pa.batch;
+    if (pidx >= pa.n_patches) return;
+    const uint32_t tile = pa.order[pidx];
+    const int TJ = tile & 0xffffu, TK = tile >> 16;
+    const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
+    const int npj = a.g.npj;
+    int* prog = pa.sync + 2 + (size_t)z * pa.n_patches;
+    int* my_prog = prog + (TK * npj + TJ);
+    const int slot = a.slots[z];
+    if (slot < 0) {  // converged source: nothing to do, but never leave a waiter hanging
+        if (tid == 0) __hip_atomic_store(my_prog, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int* up_j = TJ > 0 ? prog + (TK * npj + TJ - 1) : nullptr;
+    const int* up_k = (IS3D && TK > 0) ? prog + ((TK - 1) * npj + TJ) : nullptr;
+
+    const int j0 = TJ * PJ, k0 = TK * PK;
+    const int jmaxp = (j0 + PJ < NJ ? j0 + PJ : NJ) - 1;
+    const int kmaxp = (k0 + PK < NK ? k0 + PK : NK) - 1;
+    const int Ls = j0 + k0, Le = jmaxp + kmaxp + NF - 1;  // levels at which the patch has nodes
+    T* __restrict__ Tg = a.tt + (size_t)slot * a.g.n_nodes;
+    const T INF = real_traits<T>::inf();
+    const int rf = a.rf, rj = a.rj, rk = a.rk;
+    const int sf = rf ? -1 : 1;
+
+    // march identity of this thread: one column
+    const int tj = tid % PJ, tk = tid / PJ;
+    const int jp = j0 + tj, kp = k0 + tk;
+    const bool col_ok = jp < NJ && kp < NK;
+    const int row = IS3D ? (tk + 1) * RJ + tj + 1 : tj + 1;
+    const uint32_t colbase = ((uint32_t)(rk ? NK - 1 - kp : kp) * NJ + (rj ? NJ - 1 - jp : jp)) * NF;
+    const T dx = a.dx, dz = a.dz;
+    const int variant = a.variant;
+    const uint32_t* __restrict__ Fz = a.frozen + (size_t)slot * a.mask_words;
+    const int* bb = a.bbox + 6 * slot;
+    const T* __restrict__ Sg = a.s_sheared;
+    const int M = a.g.M;
+    const size_t sbase = (size_t)(a.rev ? NK - 1 - kp : kp) * M * NJ + (a.rev ? NJ - 1 - jp : jp);
+
+    // streaming identity: lane e = tid % C walks levels, rsub = tid / C picks the column of a pass
+    const int e = tid % C, rsub = tid / C;
+    // per pass: column (cj, ck), its natural row base and the constant part of i'
+    //   i' = L - j' - k'  with L = L0+1+e  ->  i' = L0 + ipb,  natural i = fb + sf*L0
+    int ipb[NOWN + NHI];
+    uint32_t abase[NOWN + NHI];  // natural row base + (rf ? NF-1-ipb : ipb)
+    int lrow[NOWN + NHI];        // LDS row of that column
+#pragma unroll
+    for (int it = 0; it < NOWN + NHI; ++it) {
+        int cj, ck;
+        bool ok = true;
+        if (it < NOWN) {
+            const int rid = rsub + RPI * it;
+            cj = rid % PJ;
+            ck = rid / PJ;
+        } else {
+            const int h = rsub + RPI * (it - NOWN);
+            ok = h < NDH;
+            if (IS3D) {
+                if (h < PK) { cj = PJ; ck = h; } else { cj = h - PK; ck = PK; }
+            } else {
+                cj = PJ; ck = 0;
+            }
+        }
+        const int jq = j0 + cj, kq = k0 + ck;
+        ok = ok && jq < NJ && kq < NK;
+        const int b = 1 + e - jq - kq;
+        ipb[it] = ok ? b : -(1 << 29);  // fails the range test below forever
+        const uint32_t rb = ((uint32_t)(rk ? NK - 1 - kq : kq) * NJ + (rj ? NJ - 1 - jq : jq)) * NF;
+        abase[it] = rb + (uint32_t)(rf ? NF - 1 - b : b);
+        lrow[it] = (IS3D ? (ck + 1) * RJ + cj + 1 : cj + 1) * RS + e + 2;
+    }
+    // upwind halo: one (column, level) per thread and pass; levels L0-1 .. L0+C-2 <-> tile q = 0..C-1
+    constexpr int NUPI = (NUP * C + NT - 1) / NT;
+    int uipb[NUPI];
+    uint32_t uabase[NUPI];
+    int ulrow[NUPI];
+#pragma unroll
+    for (int it = 0; it < NUPI; ++it) {
+        const int h = rsub + RPI * it;
+        int cj, ck;
+        bool ok = h < NUP;
+        if (IS3D) {
+            if (h < PK) { cj = -1; ck = h; } else { cj = h - PK; ck = -1; }
+        } else {
+            cj = -1; ck = 0;
+        }
+        const int jq = j0 + cj, kq = k0 + ck;
+        ok = ok && jq >= 0 && jq < NJ && kq >= 0 && kq < NK;
+        const int b = -1 + e - jq - kq;
+        uipb[it] = ok ? b : -(1 << 29);
+        const uint32_t rb = ((uint32_t)(rk ? NK - 1 - kq : kq) * NJ + (rj ? NJ - 1 - jq : jq)) * NF;
+        uabase[it] = rb + (uint32_t)(rf ? NF - 1 - b : b);
+        ulrow[it] = (h < NUP) ? (IS3D ? (ck + 1) * RJ + cj + 1 : cj + 1) * RS + e : -1;
+    }
+
+    // chunk starts are congruent to m = TJ+TK modulo C: an upwind patch then finishes exactly the
+    // levels we need (<= Lc+C-2) with the chunk it started one level before ours
+    const int m = TJ + TK;
+    int Lc = Ls - (((Ls - m) % C + C) % C);
+
+    // static inputs of a chunk starting at level L: slowness of the own column (levels L..L+C-1)
+    // and the not-yet-swept values at levels L+1..L+C of the own and downwind-halo columns
+    T sv[C], tv[NOWN + NHI];
+    auto issue_static = [&](int L) {
+        const int qoff = jp + kp - L + 1;
+        const int qa = col_ok ? (qoff > 1 ? qoff : 1) : C + 1;
+        const int qb = qoff + NF - 1 < C ? qoff + NF - 1 : C;
+        int x = L - kp;  // i' + j' at level L (q = 1)
+        x = a.rev ? NF + NJ - 2 - x : x;
+        x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
+        x = x < 0 ? x + M : x;
+#pragma unroll
+        for (int q = 1; q <= C; ++q) {
+            T v = 0;
+            if (q >= qa && q <= qb) v = Sg[sbase + (size_t)x * NJ];
+            sv[q - 1] = v;
+            if (a.rev) { x = x == 0 ? M - 1 : x - 1; } else { x = x + 1 == M ? 0 : x + 1; }
+        }
+        const int sL = sf * L;
+#pragma unroll
+        for (int it = 0; it < NOWN + NHI; ++it) {
+            T v = INF;
+            if ((unsigned)(L + ipb[it]) < (unsigned)NF) v = Tg[abase[it] + sL];
+            tv[it] = v;
+        }
+    };
+
+    T dec = 0;
+    T prev_last = INF;   // own column, level Lc-1 (result of the previous chunk)
+    T carry = INF;       // own column, level Lc (old value, loaded by the previous chunk)
+    bool first = true;
+    issue_static(Lc);
+    for (; Lc <= Le; Lc += C) {
+        const int L0 = Lc;
+        const int qoff = jp + kp - L0 + 1;
+        const int qa = col_ok ? (qoff > 1 ? qoff : 1) : C + 1;
+        const int qb = qoff + NF - 1 < C ? qoff + NF - 1 : C;
+        FSM_PROF_MARK(0)
+
+        // (1) wait until both upwind patches have published every level <= L0+C-2
+        if (tid == 0 && (up_j || up_k)) {
+            const int need = L0 + C - 1;
+            const unsigned long long t0 = wall_clock64();
+            int spins = 0;
+            for (;;) {
+                const int vj = up_j ? __hip_atomic_load(up_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                const int vk = up_k ? __hip_atomic_load(up_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                if (vj >= need && vk >= need) break;
+                if ((++spins & 63) == 0) {
+                    if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (wall_clock64() - t0 > pa.timeout_ticks) {
+                        __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();  // also: every read of the previous chunk's LDS tile is done
+        FSM_PROF_MARK(1)
+
+        // (2) upwind halo columns: fresh from HBM with sc1 loads (bypass L1)
+        T uv[NUPI];
+#pragma unroll
+        for (int it = 0; it < NUPI; ++it) {
+            T v = INF;
+            if ((unsigned)(L0 + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * L0));
+            uv[it] = v;
+        }
+        // (3) static part (prefetched) into LDS: levels L0+1..L0+C of own + downwind halo columns;
+        //     own column q = 0 / q = 1 come from the previous chunk (result / old value)
+#pragma unroll
+        for (int it = 0; it < NOWN + NHI; ++it)
+            if (it < NOWN || rsub + RPI * (it - NOWN) < NDH) Tt[lrow[it]] = tv[it];
+        if (first) {
+            // first chunk of the patch: level Lc-1 has no own nodes (+inf); level Lc is loaded here
+            T v = INF;
+            const int ip = L0 - jp - kp;
+            if (col_ok && (unsigned)ip < (unsigned)NF) v = Tg[colbase + (rf ? NF - 1 - ip : ip)];
+            carry = v;
+            first = false;
+        }
+        Tt[row * RS] = prev_last;
+        Tt[row * RS + 1] = carry;
+#pragma unroll
+        for (int it = 0; it < NUPI; ++it)
+            if (ulrow[it] >= 0) Tt[ulrow[it]] = uv[it];
+        __syncthreads();
+
+        bool near_src;
+        {
+            int ilo = L0 - jmaxp - kmaxp, ihi = L0 + C - 1 - j0 - k0;
+            ilo = ilo < 0 ? 0 : ilo;
+            ihi = ihi > NF - 1 ? NF - 1 : ihi;
+            const int flo = rf ? NF - 1 - ihi : ilo, fhi = rf ? NF - 1 - ilo : ihi;
+            const int jlo = rj ? NJ - 1 - jmaxp : j0, jhi = rj ? NJ - 1 - j0 : jmaxp;
+            const int klo = rk ? NK - 1 - kmaxp : k0, khi = rk ? NK - 1 - k0 : kmaxp;
+            near_src = !(fhi < bb[0] || flo > bb[1] || jhi < bb[2] || jlo > bb[3] || khi < bb[4] || klo > bb[5]);
+        }
+
+        T own[NQ];
+        own[0] = prev_last;
+        own[1] = carry;
+#pragma unroll
+        for (int q = 2; q < NQ; ++q) own[q] = Tt[row * RS + q];
+        T sc[C];
+#pragma unroll
+        for (int q = 0; q < C; ++q) sc[q] = sv[q];
+        FSM_PROF_MARK(2)
+
+        // (4) prefetch the next chunk's static inputs; they land during the march
+        if (Lc + C <= Le) issue_static(Lc + C);
+
+        bool changed = false;
+#pragma unroll
+        for (int q = 1; q <= C; ++q) {
+            bool active = (q >= qa) & (q <= qb);
+            if (near_src && active) {
+                const int ip = L0 - 1 + q - jp - kp;
+                const uint32_t n = colbase + (rf ? NF - 1 - ip : ip);
+                active = !((Fz[n >> 5] >> (n & 31)) & 1u);
+            }
+            const T c = own[q];
+            const T af = vmin(own[q - 1], own[q + 1]);
+            const T aj = vmin(Tt[(row - 1) * RS + q - 1], Tt[(row + 1) * RS + q + 1]);
+            T t;
+            if (IS3D) {
+                const T ak = vmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
+                t = update3(ak, aj, af, sc[q - 1], dx, active);
+            } else {
+                t = variant == 1 ? update2(aj, af, sc[q - 1], dx) : update2_xz(aj, af, sc[q - 1], dx, dz);
+            }
+            const bool acc = active & (t < c);
+            const T nv = acc ? t : c;
+            dec += acc ? c - t : (T)0;
+            changed |= acc;
+            own[q] = nv;
+            Tt[row * RS + q] = nv;
+            __syncthreads();
+        }
+        prev_last = own[C];
+        carry = own[C + 1];
+        FSM_PROF_MARK(3)
+        if (a.prof && tid == 0) atomicAdd(a.prof + 7, 1ull);
+
+        // (5) write back levels L0..L0+C-1 (tile q = 1..C); the columns a downstream patch reads
+        //     go out write-through (sc1)
+        if (__syncthreads_or(changed)) {
+#pragma unroll
+            for (int it = 0; it < NOWN; ++it) {
+                // same streaming map, one level earlier: level L0+e  <->  i' = L0 + ipb - 1
+                const int ipm = L0 + ipb[it] - 1;
+                if ((unsigned)ipm < (unsigned)NF) {
+                    const int rid = rsub + RPI * it;
+                    const int cj = rid % PJ, ck = rid / PJ;
+                    T* dst = Tg + (abase[it] + sf * (L0 - 1));
+                    const T v = Tt[lrow[it] - 1];
+                    if (cj == PJ - 1 || (IS3D && ck == PK - 1)) st_sc1(dst, v); else *dst = v;
+                }
+            }
+        }
+        // (6) publish: every wave drains its stores, barrier, one lane moves the counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(my_prog, Lc + C > Le ? 0x3fffffff : Lc + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FSM_PROF_MARK(4)
+    }
+
+    // L1 decrease of this unit: wavefront reduction, one atomic per wave
+    double accd = (double)dec;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
+    if ((tid & 63) == 0 && accd != 0.0) atomicAdd(a.change + slot, accd);
+}
+
 // ---- small kernels -------------------------------------------------------------------------
 
 template <typename T>
