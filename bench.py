@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--sources-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to "
+                    "exercise the multi-rank path on a single-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -96,11 +98,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    ndev = torch.cuda.device_count()
+    if args.backend != "nccl":
+        local_rank = local_rank % max(ndev, 1)  # test mode: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     n = args.size
     S = args.sources_per_gpu
@@ -118,7 +127,13 @@ def main():
         s_dev.copy_(sz.repeat_interleave(n * n))
         del sz
     if world > 1:
-        dist.broadcast(s_dev, src=0)
+        if args.backend == "nccl":
+            dist.broadcast(s_dev, src=0)
+        else:
+            tmp = s_dev.cpu()
+            dist.broadcast(tmp, src=0)
+            s_dev.copy_(tmp)
+            del tmp
     torch.cuda.synchronize()
     grid.set_slowness_device(s_dev.data_ptr(), s_dev.numel())
 
@@ -130,13 +145,13 @@ def main():
     rcv_rows = np.tile(rcv1, (S, 1))
     n_nodes = n ** 3
 
-    gathered = [torch.empty(src_rows.shape[0], dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+    gathered = [torch.empty(src_rows.shape[0], dtype=torch.float32, device=cdev) for _ in range(world)] if rank == 0 else None
 
     def step():
         tt = grid.raytrace(src_rows, rcv_rows)
         tm = grid.timing()
         if world > 1:
-            t_dev = torch.from_numpy(tt).to(dev)
+            t_dev = torch.from_numpy(tt).to(cdev)
             dist.gather(t_dev, gathered, dst=0)
         return tt, tm
 
@@ -162,7 +177,7 @@ def main():
     el = time.perf_counter() - t0
     iters_per_src = [grid.get_niter(i) for i in range(S)]
 
-    stats = torch.tensor([el, sweep_ms, float(node_iters), float(launches)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([el, sweep_ms, float(node_iters), float(launches)], dtype=torch.float64, device=cdev)
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -200,7 +215,7 @@ def main():
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, gather of traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "fsm_sweep_tile<float,16,16,16,true>",
+                         "kernel": "fsm_sweep_persistent<float,16,16,8,true>" if os.environ.get("TTCR_FSM_MODE", "1") != "0" else "fsm_sweep_tile<float,16,16,16,true>",
                          "algorithmic_bytes_per_node_per_sweep_iteration": BYTES_PER_NODE_ITER,
                          "launches": int(launches), "avg_launch_us_hip_events": round(sweep_ms * 1e3 / max(launches, 1), 3),
                          "algorithmic_bytes_per_launch": round(bytes_total / max(launches, 1), 1)},

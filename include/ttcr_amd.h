@@ -114,7 +114,10 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
 /* Tuning / measurement knobs (no reference equivalent):
  *   "fixed_iters"  > 0: run exactly that many sweep-iterations, ignore eps
  *   "max_batch"    sources swept concurrently by one launch sequence (default: n_slots)
- *   "use_graph"    1: replay the per-iteration launch sequence from a hipGraph (default 1) */
+ *   "use_graph"    1: replay the per-iteration launch sequence from a hipGraph (default 1)
+ *   "mode"         1: persistent sweep kernel, one launch per directional sweep, patches ordered by
+ *                     progress counters in HBM (default); 0: one launch per tile wavefront
+ *                  (env TTCR_FSM_MODE overrides the default at grid creation) */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 typedef struct {

@@ -12,6 +12,13 @@ from gpu_util import run_case
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=[1, 0], ids=["persistent", "wavefront-launches"], autouse=True)
+def sweep_mode(request, monkeypatch):
+    """every parity test runs with both sweep drivers (ttcr_fsm_set_option "mode")"""
+    monkeypatch.setenv("TTCR_FSM_MODE", str(request.param))
+    return request.param
+
 ALL = [(c, dt) for c in cases.cases3d() + cases.cases2d() for dt in (np.float32, np.float64)]
 IDS = [f"{c['name']}-{np.dtype(dt).name}" for c, dt in ALL]
 
@@ -46,3 +53,27 @@ def test_hip_matches_oracle_on_fresh_inputs(oracle, dt):
     assert r["niter"] == o["niter"]
     np.testing.assert_array_equal(r["tt"], o["tt"])
     np.testing.assert_array_equal(r["tt_rcv"], o["tt_rcv"])
+
+
+@pytest.mark.parametrize("kind", ["gradient129", "random97"])
+def test_hip_matches_oracle_medium_grids(oracle, kind):
+    """Hundreds of patches, several chunks per patch: exercises the inter-patch hand-off and the
+    wave-uniform fast paths of the local solver at scale (float32, bit-exact vs the oracle)."""
+    rng = np.random.default_rng(5)
+    if kind == "gradient129":
+        nn = (129, 129, 129)
+        dx = 20.0 / 128
+        s = cases.gradient3d(nn, dx)
+        src = np.array([[7.3, 11.2, 5.9]])
+    else:
+        nn = (97, 83, 91)
+        dx = 0.25
+        s = rng.uniform(0.2, 1.2, nn[0] * nn[1] * nn[2])
+        src = np.array([[3.3, 17.1, 9.02]])
+    nc = tuple(v - 1 for v in nn)
+    c = dict(name=kind, dim=3, ncells=nc, dx=dx, origin=(0.0, 0.0, 0.0), cell_slowness=False, slowness=s,
+             translate=False, src=src, t0=np.array([0.0]), rcv=np.array([[1.0, 2.0, 3.0]]))
+    r = run_case(c, np.float32)
+    o = oracle.solve3d(np.float32, nc, r["grid"].dx, c["origin"], s, src, rcv=c["rcv"])
+    assert r["niter"] == o["niter"]
+    np.testing.assert_array_equal(r["tt"], o["tt"])

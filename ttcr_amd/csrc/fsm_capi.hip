@@ -86,7 +86,7 @@ class GridBase {
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter;
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
-    int mode = 0;  // 0: one launch per tile wavefront, 1: persistent kernel (one launch per sweep)
+    int mode = 1;  // 1: persistent kernel, one launch per sweep (default); 0: one launch per tile wavefront
     Timing timing;
 };
 

@@ -56,6 +56,24 @@ __device__ __forceinline__ double rmax(double a, double b) { return a < b ? b : 
 
 // ---- 3-D local solver: Grid3Drn::update_node, ttcr/Grid3Drn.h:2936-2956 -------------------
 // inputs: the three axis minima (any order), node slowness s, cell size dx. Returns candidate t.
+// fp64 square root for the discriminants: the same Goldschmidt sequence the compiler emits for
+// llvm.sqrt.f64 (v_rsq_f64 seed, two refinements, correctly rounded) WITHOUT the 2^+-256 range
+// scaling, which only matters for inputs below 2^-767.  Our arguments are sums of exact products
+// of floats: either >= ~1e-90, or exactly 0 (handled), or negative / NaN (-> NaN, like sqrt()).
+__device__ __forceinline__ double sqrt_disc(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x == 0.0 ? x : g;
+}
+
 // `live`: lanes whose result is used.  When no live lane of the wavefront leaves the 1-D branch
 // (t1 <= a2: unreached regions, where every neighbour is still FLT_MAX, and grazing fronts) the
 // fp64 work is skipped for the whole wave -- a wave-uniform branch, values unchanged.
@@ -67,29 +85,44 @@ __device__ __forceinline__ float update3(float ax, float ay, float az, float s, 
     const float fh = s * dx;
     const float t1 = a1 + fh;
     float t = t1;
-    if (__any(live && t1 > a2)) {
-        // The reference nests the 2-D and 3-D quadratics in `if`s; both are evaluated here and
-        // selected afterwards (same values, same comparisons), so the two fp64 sqrt chains are
-        // independent and overlap instead of running back to back.
+    const bool beyond1d = live && t1 > a2;
+    if (__any(beyond1d)) {
         const double d1 = a1, d2 = a2, d3 = a3, dfh = fh;
-        // 2.*fh*fh - (a1-a2)*(a1-a2): product exact in double, (a1-a2)^2 rounded in float
-        const float df = a1 - a2;
-        const float df2 = df * df;
-        const double disc2 = __builtin_fma(2.0 * dfh, dfh, -(double)df2);
         // -2.*a1*a1 + 2.*a1*a2 - 2.*a2*a2 + 2.*a1*a3 + 2.*a2*a3 - 2.*a3*a3 + 3.*fh*fh, left to
-        // right; every product is exact in double, so each fma rounds once exactly like the add
-        double r = (-2.0 * d1) * d1;
-        r = __builtin_fma(2.0 * d1, d2, r);
-        r = __builtin_fma(-2.0 * d2, d2, r);
-        r = __builtin_fma(2.0 * d1, d3, r);
-        r = __builtin_fma(2.0 * d2, d3, r);
-        r = __builtin_fma(-2.0 * d3, d3, r);
-        r = __builtin_fma(3.0 * dfh, dfh, r);
+        // right.  Every product is exact in double, so fma(x,y,acc) rounds exactly like the
+        // reference's add; the common factor 2 of the first six terms is a power of two, so the
+        // chain is run on the halved terms (same roundings, scaled) and doubled in the last fma.
+        double r = -d1 * d1;
+        r = __builtin_fma(d1, d2, r);
+        r = __builtin_fma(-d2, d2, r);
+        r = __builtin_fma(d1, d3, r);
+        r = __builtin_fma(d2, d3, r);
+        r = __builtin_fma(-d3, d3, r);
+        r = __builtin_fma(r, 2.0, (3.0 * dfh) * dfh);
         const float s12 = a1 + a2;
         const float s123 = s12 + a3;
-        const float t2 = (float)(0.5 * ((double)s12 + __builtin_sqrt(disc2)));
-        const float t3 = (float)((1. / 3.) * ((double)s123 + __builtin_sqrt(r)));
-        t = t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
+        const float t3 = (float)((1. / 3.) * ((double)s123 + sqrt_disc(r)));
+        // Is the 2-D quadratic t2 needed at all?  The reference takes the 3-D value iff t1 > a2 and
+        // t2 > a3.  With u = a3-a1, v = a3-a2:  t2* > a3  <=>  fh^2 > u^2 + v^2 (exact arithmetic),
+        // and t2* - a3 >= (fh^2-u^2-v^2)/(3.42 fh).  The computed t2 differs from t2* by less than
+        // 2.5e-7 (|a1|+|a3|+fh) and the fp32 evaluation of fh^2-u^2-v^2 is off by < 5e-7 fh^2, so
+        //     fh^2 - u^2 - v^2  >  4e-6 fh (|a1|+|a3|+fh)        ("clearly 3-D")
+        // implies t1 > a2 and t2 > a3 with a > 2x margin (derivation: DESIGN.md section 4).  When
+        // every live lane is either 1-D or clearly 3-D the wave skips t2 and its fp64 sqrt.
+        const float u = a3 - a1, v = a3 - a2;
+        const float slack = fh * fh - (u * u + v * v);
+        const float thr = 4e-6f * fh * (__builtin_fabsf(a1) + __builtin_fabsf(a3) + fh);
+        const bool clear3 = slack > thr;
+        if (__any(beyond1d && !clear3)) {
+            // 2.*fh*fh - (a1-a2)*(a1-a2): fh*fh exact in double, (a1-a2)^2 rounded in float
+            const float df = a1 - a2;
+            const float df2 = df * df;
+            const double disc2 = __builtin_fma(dfh * dfh, 2.0, -(double)df2);
+            const float t2 = (float)(0.5 * ((double)s12 + sqrt_disc(disc2)));
+            t = t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
+        } else {
+            t = t1 > a2 ? t3 : t1;
+        }
     }
     return t;
 }
@@ -211,7 +244,13 @@ struct SweepArgs {
         prof_t = now_;                                                            \
     }
 
-__device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
+// v_min_f32 directly: llvm.minnum would first canonicalise both (loaded) operands for signalling
+// NaNs, one extra VALU op each; the traveltime fields never hold NaNs.
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
 
 template <typename T, int PJ, int PK, int BL, bool IS3D>
