@@ -117,7 +117,10 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "use_graph"    1: replay the per-iteration launch sequence from a hipGraph (default 1)
  *   "mode"         1: persistent sweep kernel, one launch per directional sweep, patches ordered by
  *                     progress counters in HBM (default); 0: one launch per tile wavefront
- *                  (env TTCR_FSM_MODE overrides the default at grid creation) */
+ *                  (env TTCR_FSM_MODE overrides the default at grid creation)
+ *   "skip"         1: persistent kernel skips chunks whose read set (bricks of 16^3 nodes, tracked
+ *                     by last-change sweep number) did not change since their last evaluation --
+ *                     exact, results and iteration counts are unchanged (default); 0: evaluate all */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 typedef struct {
@@ -125,6 +128,8 @@ typedef struct {
     double total_ms;        /* wall time of the last raytrace call (host clock, incl. copies)  */
     long long kernel_launches; /* sweep-tile kernel launches in the last call                  */
     long long node_updates;    /* nodes * 8 (or 4) * iterations, summed over sources           */
+    long long evaluated_updates; /* node updates actually evaluated (chunks whose inputs did not
+                                    change since their last evaluation are skipped, exactly)   */
     int iterations;         /* max sweep-iterations over the sources of the last call          */
     int n_sources;
 } ttcr_fsm_timing;

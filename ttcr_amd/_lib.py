@@ -22,7 +22,8 @@ _I = C.c_int
 
 class Timing(C.Structure):
     _fields_ = [("sweep_ms", C.c_double), ("total_ms", C.c_double), ("kernel_launches", C.c_longlong),
-                ("node_updates", C.c_longlong), ("iterations", C.c_int), ("n_sources", C.c_int)]
+                ("node_updates", C.c_longlong), ("evaluated_updates", C.c_longlong), ("iterations", C.c_int),
+                ("n_sources", C.c_int)]
 
 
 SYMBOLS = {

@@ -68,7 +68,7 @@ struct DevBuf {
 
 struct Timing {
     double sweep_ms = 0, total_ms = 0;
-    long long launches = 0, node_updates = 0;
+    long long launches = 0, node_updates = 0, evaluated_updates = 0;
     int iterations = 0, n_sources = 0;
 };
 
@@ -86,6 +86,7 @@ class GridBase {
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter;
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
+    int skip = 1;  // persistent kernel: skip chunks whose read set did not change (exact)
     int mode = 1;  // 1: persistent kernel, one launch per sweep (default); 0: one launch per tile wavefront
     Timing timing;
 };
@@ -125,6 +126,13 @@ class GridT : public GridBase {
     DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
+    DevBuf<int> d_stamp;       // dirty-brick stamps [n_slots][nbf*nbj*nbk]
+    DevBuf<int> d_iter;        // current iteration index (read by the captured kernels)
+    DevBuf<unsigned long long> d_evals;  // [n_slots] node updates actually evaluated
+    int* h_iter = nullptr;     // pinned
+    unsigned long long* h_evals = nullptr;  // pinned
+    int nbf = 0, nbj = 0, nbk = 0;
+    size_t n_bricks = 0;
     DevBuf<InitPoint<T>> d_pts;
     double* h_change = nullptr;  // pinned
     int* h_slots = nullptr;      // pinned
@@ -188,6 +196,8 @@ class GridT : public GridBase {
         HIP_CHECK(hipHostMalloc((void**)&h_slots, sizeof(int) * n_slots));
         HIP_CHECK(hipHostMalloc((void**)&h_abort, sizeof(int)));
         *h_abort = 0;
+        HIP_CHECK(hipHostMalloc((void**)&h_iter, sizeof(int)));
+        HIP_CHECK(hipHostMalloc((void**)&h_evals, sizeof(unsigned long long) * n_slots));
         HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_slots * sizeof(T), stream));
 
         if (dim == 3) {
@@ -210,6 +220,14 @@ class GridT : public GridBase {
         if (dim == 3) build_tile_lists(TileCfg<T, 3>::PJ, TileCfg<T, 3>::PK, TileCfg<T, 3>::BL);
         else build_tile_lists(TileCfg<T, 2>::PJ, TileCfg<T, 2>::PK, TileCfg<T, 2>::BL);
         build_persistent_lists();
+        nbf = (geom.NF + FSM_BRICK - 1) / FSM_BRICK;
+        nbj = (geom.NJ + FSM_BRICK - 1) / FSM_BRICK;
+        nbk = (geom.NK + FSM_BRICK - 1) / FSM_BRICK;
+        n_bricks = (size_t)nbf * nbj * nbk;
+        d_stamp.reserve(n_bricks * n_slots);
+        d_iter.reserve(1);
+        d_evals.reserve(n_slots);
+        if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
     }
 
@@ -250,6 +268,12 @@ class GridT : public GridBase {
         pa.n_patches = n_patches;
         pa.batch = batch;
         pa.timeout_ticks = 300000000ull;  // 3 s at 100 MHz
+        pa.stamp = d_stamp.p;
+        pa.iter_ptr = d_iter.p;
+        pa.evals = d_evals.p;
+        pa.nbf = nbf; pa.nbj = nbj; pa.nbk = nbk;
+        pa.ndir = DIM == 3 ? 8 : 4;
+        pa.skip = skip;
         const dim3 block(C::PJ * C::PK), grid((unsigned)n_patches * batch);
         const int ndir = DIM == 3 ? 8 : 4;
         static const int RX2[4] = {0, 1, 1, 0}, RZ2[4] = {0, 0, 1, 1};
@@ -265,6 +289,7 @@ class GridT : public GridBase {
                 fam = a.rf ^ a.rj;
             }
             a.s_sheared = d_ssh.p + (size_t)fam * ssh_stride;
+            pa.dir = d;
             // ticket + progress counters back to zero (the abort word [1] is sticky within an iteration)
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
@@ -305,6 +330,8 @@ class GridT : public GridBase {
         if (h_change) (void)hipHostFree(h_change);
         if (h_slots) (void)hipHostFree(h_slots);
         if (h_abort) (void)hipHostFree(h_abort);
+        if (h_iter) (void)hipHostFree(h_iter);
+        if (h_evals) (void)hipHostFree(h_evals);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -517,7 +544,7 @@ class GridT : public GridBase {
     void run_iteration(int batch) {
         const int ndir = dim == 3 ? 8 : 4;
         if (use_graph) {
-            if (!graph_exec || graph_batch != batch || graph_mode != mode) {
+            if (!graph_exec || graph_batch != batch || graph_mode != mode * 2 + skip) {
                 if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
                 if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
                 HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -532,7 +559,7 @@ class GridT : public GridBase {
                 HIP_CHECK(hipStreamEndCapture(stream, &graph));
                 HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
                 graph_batch = batch;
-                graph_mode = mode;
+                graph_mode = mode * 2 + skip;
             }
             HIP_CHECK(hipGraphLaunch(graph_exec, stream));
         } else {
@@ -577,6 +604,9 @@ class GridT : public GridBase {
             ia.nnz = ncz + 1;
             ia.dx = dx; ia.dz = dz; ia.xmin = xmin; ia.ymin = ymin; ia.zmin = zmin;
             ia.dim = dim;
+            HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)slot * n_bricks, 0xFF, n_bricks * sizeof(int), stream));
+            ia.stamp = d_stamp.p + (size_t)slot * n_bricks;
+            ia.nbf = nbf; ia.nbj = nbj; ia.nbk = nbk;
             fsm_init_source<T><<<1, 128, 0, stream>>>(ia);
             niter[slot] = 0;
         }
@@ -591,11 +621,14 @@ class GridT : public GridBase {
         // the graph is built for a fixed z-extent; finished sources are masked with slot -1 ... but
         // a masked block still has to read slots[z], so keep the list compact and pad with -1.
         if (mode == 1) HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 2 * sizeof(int), stream));
+        HIP_CHECK(hipMemsetAsync(d_evals.p, 0, sizeof(unsigned long long) * n_slots, stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
         while (!active.empty() && it < maxit) {
             for (int b = 0; b < nb; ++b) h_slots[b] = b < (int)active.size() ? active[b] : -1;
             HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * nb, hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
+            *h_iter = it;
+            HIP_CHECK(hipMemcpyAsync(d_iter.p, h_iter, sizeof(int), hipMemcpyHostToDevice, stream));
             run_iteration(nb);
             HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
             if (mode == 1) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -634,6 +667,12 @@ class GridT : public GridBase {
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.sweep_ms += ms;
         timing.iterations = std::max(timing.iterations, it);
+        if (mode == 1) {
+            HIP_CHECK(hipMemcpy(h_evals, d_evals.p, sizeof(unsigned long long) * n_slots, hipMemcpyDeviceToHost));
+            for (int s2 : slot_ids) timing.evaluated_updates += (long long)h_evals[s2];
+        } else {
+            timing.evaluated_updates = timing.node_updates;
+        }
     }
 
     void interp(int slot, int n, const void* pts, void* out) override {
@@ -866,6 +905,7 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
         else if (k == "max_batch") g->impl->max_batch = (int)value;
         else if (k == "use_graph") g->impl->use_graph = value != 0;
         else if (k == "mode") g->impl->mode = (int)value;
+        else if (k == "skip") g->impl->skip = (int)value;
         else throw ValueError("unknown option '" + k + "'");
     });
 }
@@ -877,6 +917,7 @@ int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out) {
         out->total_ms = t.total_ms;
         out->kernel_launches = t.launches;
         out->node_updates = t.node_updates;
+        out->evaluated_updates = t.evaluated_updates;
         out->iterations = t.iterations;
         out->n_sources = t.n_sources;
     });

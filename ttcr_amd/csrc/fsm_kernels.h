@@ -39,6 +39,9 @@
 
 namespace ttcr_amd {
 
+// edge of the bricks (natural coordinates) whose last-change sweep number is tracked
+constexpr int FSM_BRICK = 16;
+
 template <typename T> struct real_traits;
 template <> struct real_traits<float> {
     static __host__ __device__ constexpr float max() { return 3.402823466e+38f; }
@@ -458,7 +461,16 @@ struct PersistArgs {
     int* sync;                // [0]: ticket counter, [1]: abort flag, [2 + z*n_patches + patch]: progress
     int n_patches, batch;
     unsigned long long timeout_ticks;  // 100 MHz wall-clock ticks
+    // dirty-brick tracking (exact skipping of chunks that cannot change anything)
+    int* stamp;               // [n_slots][nbf*nbj*nbk] global sweep number of the last change in a brick, -1: never
+    const int* iter_ptr;      // device word: index of the current iteration
+    unsigned long long* evals;  // [n_slots] node updates actually evaluated
+    int nbf, nbj, nbk;        // bricks of FSM_BRICK^3 nodes (natural coordinates)
+    int dir, ndir;            // direction index within the iteration, directions per iteration
+    int skip;                 // 0: evaluate every chunk
 };
+
+
 
 __device__ __forceinline__ float ld_sc1(const float* p) {
     return __uint_as_float(__hip_atomic_load((const unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -486,11 +498,13 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     constexpr int RPI = NT / C;
     constexpr int NOWN = C;                      // passes over the own columns (NT / RPI)
     constexpr int NHI = (NDH + RPI - 1) / RPI;   // passes over the downwind halo columns
-    static_assert(NT % C == 0 && (IS3D || PK == 1), "tile shape");
+    static_assert(NT % C == 0 && (IS3D || PK == 1) && C <= FSM_BRICK, "tile shape");
     const SweepArgs<T>& a = pa.s;
 
     __shared__ T Tt[NROWS * RS];
     __shared__ int s_ticket;
+    __shared__ int s_skip;
+    __shared__ int s_chg[64];  // bricks of the read set changed by this chunk
 
     const int tid = threadIdx.x;
     unsigned long long prof_t = a.prof ? wall_clock64() : 0ull;
@@ -624,11 +638,34 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         }
     };
 
+    // dirty-brick tracking: sigma = global sweep number (1-based); the same chunk was last evaluated
+    // at sigma - ndir.  If no brick of its read set changed at or after that sweep (or ever, in the
+    // first iteration) the chunk would reproduce the values that are already there: skip it.
+    const int sigma = pa.skip ? pa.ndir * pa.iter_ptr[0] + pa.dir + 1 : 0;
+    const int thr = sigma - pa.ndir > 0 ? sigma - pa.ndir : 0;
+    int* __restrict__ stamp = pa.stamp + (size_t)slot * pa.nbf * pa.nbj * pa.nbk;
+    // natural J / K extent of the read set (own + halo columns), fixed for the whole patch
+    int rs_jlo, rs_jhi, rs_klo, rs_khi;
+    {
+        const int ja = j0 - 1 < 0 ? 0 : j0 - 1, jb = jmaxp + 1 > NJ - 1 ? NJ - 1 : jmaxp + 1;
+        const int ka = k0 - 1 < 0 ? 0 : k0 - 1, kb = kmaxp + 1 > NK - 1 ? NK - 1 : kmaxp + 1;
+        rs_jlo = (rj ? NJ - 1 - jb : ja) / FSM_BRICK;
+        rs_jhi = (rj ? NJ - 1 - ja : jb) / FSM_BRICK;
+        rs_klo = (rk ? NK - 1 - kb : ka) / FSM_BRICK;
+        rs_khi = (rk ? NK - 1 - ka : kb) / FSM_BRICK;
+    }
+    const int rs_nj = rs_jhi - rs_jlo + 1, rs_nk = rs_khi - rs_klo + 1;
+    const int my_bj = (rj ? NJ - 1 - jp : jp) / FSM_BRICK - rs_jlo;
+    const int my_bk = (rk ? NK - 1 - kp : kp) / FSM_BRICK - rs_klo;
+    unsigned long long nevals = 0;
+
     T dec = 0;
     T prev_last = INF;   // own column, level Lc-1 (result of the previous chunk)
     T carry = INF;       // own column, level Lc (old value, loaded by the previous chunk)
-    bool first = true;
-    issue_static(Lc);
+    bool have_prev = false;   // prev_last / carry are valid (the previous chunk was evaluated)
+    bool quiet = true;        // the previous chunk was skipped or changed nothing
+    int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
+    if (!pa.skip) { issue_static(Lc); pref_for = Lc; }
     for (; Lc <= Le; Lc += C) {
         const int L0 = Lc;
         const int qoff = jp + kp - L0 + 1;
@@ -655,8 +692,55 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
                 __builtin_amdgcn_s_sleep(2);
             }
         }
+        // (1b) read set of this chunk in bricks: F range from the levels, J/K from the patch
+        int rs_flo, rs_nf;
+        {
+            int ia = L0 - 1 - jmaxp - kmaxp, ib = L0 + C - j0 - k0;
+            ia = ia < 0 ? 0 : ia;
+            ib = ib > NF - 1 ? NF - 1 : ib;
+            rs_flo = (rf ? NF - 1 - ib : ia) / FSM_BRICK;
+            rs_nf = (rf ? NF - 1 - ia : ib) / FSM_BRICK - rs_flo + 1;
+        }
+        // The stamps are only consulted when the neighbourhood looks quiet (first chunk, previous
+        // chunk skipped or evaluated without a change); next to an advancing front the chunk is
+        // simply evaluated -- always correct, and no check latency on the busy path.
+        if (pa.skip && !quiet) {
+            if (tid < 64) s_chg[tid] = 0;
+            if (tid == 0) s_skip = 0;
+        } else if (pa.skip) {
+            if (tid < 64) {
+                const int nb = rs_nf * rs_nj * rs_nk;  // <= 4*3*3
+                int mx = -1;
+                for (int b = tid; b < nb; b += 64) {
+                    const int bf = rs_flo + b % rs_nf, bj = rs_jlo + (b / rs_nf) % rs_nj, bk = rs_klo + b / (rs_nf * rs_nj);
+                    const int v = __hip_atomic_load(stamp + ((size_t)bk * pa.nbj + bj) * pa.nbf + bf, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    mx = v > mx ? v : mx;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int o = __shfl_xor(mx, off, 64);
+                    mx = o > mx ? o : mx;
+                }
+                if (tid == 0) s_skip = mx < thr;
+                s_chg[tid] = 0;
+            }
+        } else if (tid == 0) {
+            s_skip = 0;
+        }
         __syncthreads();  // also: every read of the previous chunk's LDS tile is done
         FSM_PROF_MARK(1)
+        if (s_skip) {
+            // nothing in the read set changed since this chunk was last evaluated: no-op
+            have_prev = false;
+            quiet = true;
+            __syncthreads();  // s_skip is rewritten by the next chunk
+            if (tid == 0)
+                __hip_atomic_store(my_prog, Lc + C > Le ? 0x3fffffff : Lc + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (pref_for != L0) issue_static(L0);
+        nevals += (qb >= qa) ? (unsigned)(qb - qa + 1) : 0u;
 
         // (2) upwind halo columns: fresh from HBM with sc1 loads (bypass L1)
         T uv[NUPI];
@@ -671,13 +755,16 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
 #pragma unroll
         for (int it = 0; it < NOWN + NHI; ++it)
             if (it < NOWN || rsub + RPI * (it - NOWN) < NDH) Tt[lrow[it]] = tv[it];
-        if (first) {
-            // first chunk of the patch: level Lc-1 has no own nodes (+inf); level Lc is loaded here
-            T v = INF;
+        if (!have_prev) {
+            // first chunk of the patch, or the previous chunk was skipped: levels L0-1 and L0 of the
+            // own column come from HBM (they are current: a skipped chunk changes nothing)
+            T v0 = INF, v1 = INF;
             const int ip = L0 - jp - kp;
-            if (col_ok && (unsigned)ip < (unsigned)NF) v = Tg[colbase + (rf ? NF - 1 - ip : ip)];
-            carry = v;
-            first = false;
+            if (col_ok && (unsigned)ip < (unsigned)NF) v1 = Tg[colbase + (rf ? NF - 1 - ip : ip)];
+            if (col_ok && (unsigned)(ip - 1) < (unsigned)NF) v0 = Tg[colbase + (rf ? NF - ip : ip - 1)];
+            prev_last = v0;
+            carry = v1;
+            have_prev = true;
         }
         Tt[row * RS] = prev_last;
         Tt[row * RS + 1] = carry;
@@ -708,8 +795,21 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         FSM_PROF_MARK(2)
 
         // (4) prefetch the next chunk's static inputs; they land during the march
-        if (Lc + C <= Le) issue_static(Lc + C);
+        if (Lc + C <= Le) { issue_static(Lc + C); pref_for = Lc + C; }
 
+        // brick (along F) of this thread's node at level q: it crosses at most one brick border
+        // inside the chunk, at q = q_split
+        int my_bf0, q_split;
+        {
+            const int ip1 = L0 - jp - kp;                 // i' at q = 1
+            const int i1 = rf ? NF - 1 - ip1 : ip1;       // natural i at q = 1; moves by sf per level
+            const int b0 = (i1 >= 0 ? i1 : 0) / FSM_BRICK;
+            my_bf0 = b0 - rs_flo;
+            // first q at which the brick index changes
+            const int rem = rf ? (i1 - b0 * FSM_BRICK) + 1 : (b0 + 1) * FSM_BRICK - i1;
+            q_split = 1 + rem;
+        }
+        bool chg_a = false, chg_b = false;
         bool changed = false;
 #pragma unroll
         for (int q = 1; q <= C; ++q) {
@@ -733,18 +833,29 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
             const T nv = acc ? t : c;
             dec += acc ? c - t : (T)0;
             changed |= acc;
+            chg_a |= acc & (q < q_split);
+            chg_b |= acc & (q >= q_split);
             own[q] = nv;
             Tt[row * RS + q] = nv;
             __syncthreads();
         }
         prev_last = own[C];
         carry = own[C + 1];
+        if (pa.skip) {
+            // mark the bricks this thread changed (LDS flags, then one atomicMax per brick)
+            const int base = (my_bk * rs_nj + my_bj) * rs_nf;
+            const int ba = my_bf0, bb2 = my_bf0 + (rf ? -1 : 1);
+            if (chg_a && ba >= 0 && ba < rs_nf) s_chg[base + ba] = 1;
+            if (chg_b && bb2 >= 0 && bb2 < rs_nf) s_chg[base + bb2] = 1;
+        }
         FSM_PROF_MARK(3)
         if (a.prof && tid == 0) atomicAdd(a.prof + 7, 1ull);
 
         // (5) write back levels L0..L0+C-1 (tile q = 1..C); the columns a downstream patch reads
         //     go out write-through (sc1)
-        if (__syncthreads_or(changed)) {
+        const bool any_changed = __syncthreads_or(changed);
+        quiet = !any_changed;
+        if (any_changed) {
 #pragma unroll
             for (int it = 0; it < NOWN; ++it) {
                 // same streaming map, one level earlier: level L0+e  <->  i' = L0 + ipb - 1
@@ -755,6 +866,17 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
                     T* dst = Tg + (abase[it] + sf * (L0 - 1));
                     const T v = Tt[lrow[it] - 1];
                     if (cj == PJ - 1 || (IS3D && ck == PK - 1)) st_sc1(dst, v); else *dst = v;
+                }
+            }
+        }
+        // (5b) stamp the changed bricks with this sweep's number (after the barrier above, the LDS
+        //      flags of all threads are visible); ordered before the counter by the drain below
+        if (pa.skip && tid < 64) {
+            const int nb = rs_nf * rs_nj * rs_nk;
+            for (int b = tid; b < nb; b += 64) {
+                if (s_chg[b]) {
+                    const int bf = rs_flo + b % rs_nf, bj = rs_jlo + (b / rs_nf) % rs_nj, bk = rs_klo + b / (rs_nf * rs_nj);
+                    atomicMax(stamp + ((size_t)bk * pa.nbj + bj) * pa.nbf + bf, sigma);
                 }
             }
         }
@@ -771,6 +893,9 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
     if ((tid & 63) == 0 && accd != 0.0) atomicAdd(a.change + slot, accd);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nevals += __shfl_down(nevals, off, 64);
+    if ((tid & 63) == 0 && nevals) atomicAdd(pa.evals + slot, nevals);
 }
 
 // ---- small kernels -------------------------------------------------------------------------
@@ -865,6 +990,8 @@ struct InitArgs {
     int nnx, nny, nnz;     // 2-D: nnx, nnz, nny = 1
     T dx, dz, xmin, ymin, zmin;
     int dim;
+    int* stamp;            // slot's dirty-brick stamps (all -1 on entry); bricks of the source box get 0
+    int nbf, nbj, nbk;     // brick counts along the sweep kernel's F, J, K axes
 };
 
 template <typename T>
@@ -938,6 +1065,12 @@ __global__ void fsm_init_source(const InitArgs<T> a) {
             a.bbox[0] = lo[0]; a.bbox[1] = hi[0]; a.bbox[2] = lo[1]; a.bbox[3] = hi[1]; a.bbox[4] = lo[2]; a.bbox[5] = hi[2];
         } else {  // F = z, J = x, K = none
             a.bbox[0] = lo[2]; a.bbox[1] = hi[2]; a.bbox[2] = lo[0]; a.bbox[3] = hi[0]; a.bbox[4] = 0; a.bbox[5] = 0;
+        }
+        if (a.stamp) {
+            for (int bk = a.bbox[4] / FSM_BRICK; bk <= a.bbox[5] / FSM_BRICK; ++bk)
+                for (int bj = a.bbox[2] / FSM_BRICK; bj <= a.bbox[3] / FSM_BRICK; ++bj)
+                    for (int bf = a.bbox[0] / FSM_BRICK; bf <= a.bbox[1] / FSM_BRICK; ++bf)
+                        a.stamp[((size_t)bk * a.nbj + bj) * a.nbf + bf] = 0;
         }
     }
 }
