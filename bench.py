@@ -168,11 +168,13 @@ def main():
     sweep_ms = 0.0
     launches = 0
     node_iters = 0
+    evaluated = 0
     for _ in range(args.steps):
         tt, tm = step()
         sweep_ms += tm["sweep_ms"]
         launches += tm["kernel_launches"]
         node_iters += tm["node_updates"] // 8
+        evaluated += tm["evaluated_updates"]
     fence()
     el = time.perf_counter() - t0
     iters_per_src = [grid.get_niter(i) for i in range(S)]
@@ -193,8 +195,11 @@ def main():
         value = node_iters_all / el_max / 1e6
         # roofline of the dominant kernel (fsm_sweep_tile), rank 0's launches: algorithmic bytes of
         # the nodes one launch sequence sweeps / HIP-event time of those launches (ttcr_fsm_last_timing)
-        bytes_total = BYTES_PER_NODE_ITER * node_iters
+        # Chunks whose inputs provably did not change since their last evaluation are skipped
+        # (exact); only the node updates that were really evaluated are priced, at 104/8 B each.
+        bytes_total = BYTES_PER_NODE_ITER / 8.0 * evaluated
         achieved = bytes_total / (sweep_ms * 1e-3) / 1e9
+        nominal = BYTES_PER_NODE_ITER * node_iters / (sweep_ms * 1e-3) / 1e9
         out = {
             "metric": "Mnodes/s per sweep-iteration (512^3 fp32 grid, first-order FSM)",
             "value": round(value, 1),
@@ -215,8 +220,10 @@ def main():
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, gather of traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "fsm_sweep_persistent<float,16,16,8,true>" if os.environ.get("TTCR_FSM_MODE", "1") != "0" else "fsm_sweep_tile<float,16,16,16,true>",
+                         "kernel": "fsm_sweep_persistent<float,16,16,8,true,%s>" % ("true" if os.environ.get("TTCR_FSM_SKIP", "0") == "1" else "false") if os.environ.get("TTCR_FSM_MODE", "1") != "0" else "fsm_sweep_tile<float,16,16,16,true>",
                          "algorithmic_bytes_per_node_per_sweep_iteration": BYTES_PER_NODE_ITER,
+                         "evaluated_fraction": round(evaluated / max(node_iters * 8, 1), 4),
+                         "nominal_GBs_all_updates": round(nominal, 1),
                          "launches": int(launches), "avg_launch_us_hip_events": round(sweep_ms * 1e3 / max(launches, 1), 3),
                          "algorithmic_bytes_per_launch": round(bytes_total / max(launches, 1), 1)},
         }

@@ -120,7 +120,7 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  (env TTCR_FSM_MODE overrides the default at grid creation)
  *   "skip"         1: persistent kernel skips chunks whose read set (bricks of 16^3 nodes, tracked
  *                     by last-change sweep number) did not change since their last evaluation --
- *                     exact, results and iteration counts are unchanged (default); 0: evaluate all */
+ *                     exact, results and iteration counts are unchanged; 0: evaluate every chunk (default) */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 typedef struct {

@@ -13,11 +13,14 @@ from gpu_util import run_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 0], ids=["persistent", "wavefront-launches"], autouse=True)
+@pytest.fixture(params=[(1, 0), (1, 1), (0, 0)], ids=["persistent", "persistent+skip", "wavefront-launches"],
+                autouse=True)
 def sweep_mode(request, monkeypatch):
-    """every parity test runs with both sweep drivers (ttcr_fsm_set_option "mode")"""
-    monkeypatch.setenv("TTCR_FSM_MODE", str(request.param))
+    """every parity test runs with each sweep driver (ttcr_fsm_set_option "mode" / "skip")"""
+    monkeypatch.setenv("TTCR_FSM_MODE", str(request.param[0]))
+    monkeypatch.setenv("TTCR_FSM_SKIP", str(request.param[1]))
     return request.param
+
 
 ALL = [(c, dt) for c in cases.cases3d() + cases.cases2d() for dt in (np.float32, np.float64)]
 IDS = [f"{c['name']}-{np.dtype(dt).name}" for c, dt in ALL]

@@ -86,7 +86,7 @@ class GridBase {
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter;
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
-    int skip = 1;  // persistent kernel: skip chunks whose read set did not change (exact)
+    int skip = 0;  // persistent kernel: 1 = skip chunks whose read set did not change (exact); see DESIGN.md
     int mode = 1;  // 1: persistent kernel, one launch per sweep (default); 0: one launch per tile wavefront
     Timing timing;
 };
@@ -293,7 +293,10 @@ class GridT : public GridBase {
             // ticket + progress counters back to zero (the abort word [1] is sticky within an iteration)
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
-            fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3><<<grid, block, 0, stream>>>(pa);
+            if (skip)
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true><<<grid, block, 0, stream>>>(pa);
+            else
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false><<<grid, block, 0, stream>>>(pa);
         }
         HIP_CHECK(hipGetLastError());
     }

@@ -485,7 +485,7 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
     __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int PJ, int PK, int C, bool IS3D>
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP>
 __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs<T> pa) {
     constexpr int NT = PJ * PK;
     constexpr int RJ = PJ + 2;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     // dirty-brick tracking: sigma = global sweep number (1-based); the same chunk was last evaluated
     // at sigma - ndir.  If no brick of its read set changed at or after that sweep (or ever, in the
     // first iteration) the chunk would reproduce the values that are already there: skip it.
-    const int sigma = pa.skip ? pa.ndir * pa.iter_ptr[0] + pa.dir + 1 : 0;
+    const int sigma = SKIP ? pa.ndir * pa.iter_ptr[0] + pa.dir + 1 : 0;
     const int thr = sigma - pa.ndir > 0 ? sigma - pa.ndir : 0;
     int* __restrict__ stamp = pa.stamp + (size_t)slot * pa.nbf * pa.nbj * pa.nbk;
     // natural J / K extent of the read set (own + halo columns), fixed for the whole patch
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     bool have_prev = false;   // prev_last / carry are valid (the previous chunk was evaluated)
     bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
-    if (!pa.skip) { issue_static(Lc); pref_for = Lc; }
+    if (!SKIP) { issue_static(Lc); pref_for = Lc; }
     for (; Lc <= Le; Lc += C) {
         const int L0 = Lc;
         const int qoff = jp + kp - L0 + 1;
@@ -704,10 +704,10 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         // The stamps are only consulted when the neighbourhood looks quiet (first chunk, previous
         // chunk skipped or evaluated without a change); next to an advancing front the chunk is
         // simply evaluated -- always correct, and no check latency on the busy path.
-        if (pa.skip && !quiet) {
+        if (SKIP && !quiet) {
             if (tid < 64) s_chg[tid] = 0;
             if (tid == 0) s_skip = 0;
-        } else if (pa.skip) {
+        } else if (SKIP) {
             if (tid < 64) {
                 const int nb = rs_nf * rs_nj * rs_nk;  // <= 4*3*3
                 int mx = -1;
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         }
         prev_last = own[C];
         carry = own[C + 1];
-        if (pa.skip) {
+        if (SKIP) {
             // mark the bricks this thread changed (LDS flags, then one atomicMax per brick)
             const int base = (my_bk * rs_nj + my_bj) * rs_nf;
             const int ba = my_bf0, bb2 = my_bf0 + (rf ? -1 : 1);
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         }
         // (5b) stamp the changed bricks with this sweep's number (after the barrier above, the LDS
         //      flags of all threads are visible); ordered before the counter by the drain below
-        if (pa.skip && tid < 64) {
+        if (SKIP && tid < 64) {
             const int nb = rs_nf * rs_nj * rs_nk;
             for (int b = tid; b < nb; b += 64) {
                 if (s_chg[b]) {
