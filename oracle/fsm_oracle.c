@@ -12,14 +12,17 @@
 #define SFX(name) name##_f32
 #define FABS(x) fabsf(x)
 #define REAL_MAX FLT_MAX
+#define REAL_EPS FLT_EPSILON
 #include "fsm_oracle_impl.h"
 #undef REAL
 #undef SFX
 #undef FABS
 #undef REAL_MAX
+#undef REAL_EPS
 
 #define REAL double
 #define SFX(name) name##_f64
 #define FABS(x) fabs(x)
 #define REAL_MAX DBL_MAX
+#define REAL_EPS DBL_EPSILON
 #include "fsm_oracle_impl.h"

@@ -24,14 +24,16 @@ extern "C" {
     int fsm_outside3d_##S(const fsm_grid3d_##S* g, int n, const REAL* p);                            \
     void fsm_cells_to_nodes3d_##S(size_t ncx, size_t ncy, size_t ncz, const REAL* sc, REAL* sn);     \
     int fsm_solve3d_##S(const fsm_grid3d_##S* g, const REAL* s, int n_src, const REAL* src,          \
-                        const REAL* t0, REAL eps, int maxit, REAL* T, REAL* change_hist);            \
+                        const REAL* t0, REAL eps, int maxit, int weno, REAL* T, REAL* change_hist,   \
+                        int* niterw_out);                                                            \
     REAL fsm_interp3d_##S(const fsm_grid3d_##S* g, const REAL* T, REAL px, REAL py, REAL pz);        \
     void fsm_grid2d_init_##S(fsm_grid2d_##S* g, uint32_t ncx, uint32_t ncz, REAL dx, REAL dz,        \
                              REAL xmin, REAL zmin);                                                  \
     int fsm_outside2d_##S(const fsm_grid2d_##S* g, int n, const REAL* p);                            \
     void fsm_cells_to_nodes2d_##S(size_t ncx, size_t ncz, const REAL* sc, REAL* sn);                 \
     int fsm_solve2d_##S(const fsm_grid2d_##S* g, const REAL* s, int n_src, const REAL* src,          \
-                        const REAL* t0, REAL eps, int maxit, REAL* T, REAL* change_hist);            \
+                        const REAL* t0, REAL eps, int maxit, int weno, REAL* T, REAL* change_hist,   \
+                        int* niterw_out);                                                            \
     REAL fsm_interp2d_##S(const fsm_grid2d_##S* g, const REAL* T, REAL px, REAL pz);
 
 FSM_ORACLE_DECL(float, f32)

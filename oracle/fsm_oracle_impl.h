@@ -201,6 +201,99 @@ static void SFX(init3d)(const SFX(fsm_grid3d) * g, const REAL* s, REAL* T, unsig
     }
 }
 
+
+/* --------------------------------------------------------------- WENO3 ---- */
+/* Grid3Drn::weno3_upwind, ttcr/Grid3Drn.h:3047-3075 (forward / backward one-sided third-order
+ * WENO value); the 2-D code (ttcr/Grid2Drn.h:1078-1125) inlines the same expressions.  Every
+ * named intermediate is a T1; the double literals make the right-hand sides double. */
+static REAL SFX(weno_fwd)(REAL v1, REAL v2, REAL v3, REAL v4, REAL h) {
+    const REAL eps = REAL_EPS;
+    const REAL num = (v4 - 2.0 * v3 + v2);
+    const REAL den = (v3 - 2.0 * v2 + v1);
+    const REAL r = (eps + num * num) / (eps + den * den);
+    const REAL w = 1.0 / (1.0 + 2.0 * r * r);
+    const REAL ap = (1.0 - w) * (v3 - v1) / (2.0 * h) + w * (-v4 + 4.0 * v3 - 3.0 * v2) / (2.0 * h);
+    return v2 + h * ap;
+}
+static REAL SFX(weno_bwd)(REAL v0, REAL v1, REAL v2, REAL v3, REAL h) {
+    const REAL eps = REAL_EPS;
+    const REAL num = (v2 - 2.0 * v1 + v0);
+    const REAL den = (v3 - 2.0 * v2 + v1);
+    const REAL r = (eps + num * num) / (eps + den * den);
+    const REAL w = 1.0 / (1.0 + 2.0 * r * r);
+    const REAL am = (1.0 - w) * (v3 - v1) / (2.0 * h) + w * (3.0 * v2 - 4.0 * v1 + v0) / (2.0 * h);
+    return v2 - h * am;
+}
+
+/* One axis of update_node_weno3 (ttcr/Grid3Drn.h:3084-3196 for k, :3199-3313 j, :3316-3430 i;
+ * 2-D ttcr/Grid2Drn.h:1076-1128): T points at the node, st is the stride along the axis, idx the
+ * node's index on that axis, n the last index (cells), h the spacing.
+ *   idx == 0    : first-order, T[+1]          idx == n   : first-order, T[-1]
+ *   idx == 1    : min(weno_fwd, T[-1])        idx == n-1 : min(weno_bwd, T[+1])
+ *   otherwise   : min(weno_fwd, weno_bwd)     (a<t ? a : t  selects, NaN-transparent like the reference) */
+static REAL SFX(weno_axis)(const REAL* T, ptrdiff_t st, size_t idx, size_t n, REAL h) {
+    REAL a, t;
+    if (idx == 0) {
+        a = T[st];
+    } else if (idx == 1) {
+        a = SFX(weno_fwd)(T[-st], T[0], T[st], T[2 * st], h);
+        t = T[-st];
+        a = a < t ? a : t;
+    } else if (idx == n) {
+        a = T[-st];
+    } else if (idx == n - 1) {
+        a = SFX(weno_bwd)(T[-2 * st], T[-st], T[0], T[st], h);
+        t = T[st];
+        a = a < t ? a : t;
+    } else {
+        a = SFX(weno_fwd)(T[-st], T[0], T[st], T[2 * st], h);
+        t = SFX(weno_bwd)(T[-2 * st], T[-st], T[0], T[st], h);
+        a = a < t ? a : t;
+    }
+    return a;
+}
+
+/* Grid3Drn::update_node_weno3, ttcr/Grid3Drn.h:3078-3484 */
+static void SFX(update_node3d_weno)(REAL* T, const REAL* s, REAL dx, size_t nnx, size_t nny, size_t nnz,
+                                    size_t i, size_t j, size_t k) {
+    const size_t n = (k * nny + j) * nnx + i;
+    REAL a1 = SFX(weno_axis)(T + n, (ptrdiff_t)(nnx * nny), k, nnz - 1, dx);
+    REAL a2 = SFX(weno_axis)(T + n, (ptrdiff_t)nnx, j, nny - 1, dx);
+    REAL a3 = SFX(weno_axis)(T + n, 1, i, nnx - 1, dx);
+    REAL t;
+    if (a1 > a2) { REAL w = a1; a1 = a2; a2 = w; }
+    if (a1 > a3) { REAL w = a1; a1 = a3; a3 = w; }
+    if (a2 > a3) { REAL w = a2; a2 = a3; a3 = w; }
+    REAL fh = s[n] * dx;
+    t = a1 + fh;
+    if (t > a2) {
+        t = 0.5 * (a1 + a2 + sqrt(2. * fh * fh - (a1 - a2) * (a1 - a2)));
+        if (t > a3) {
+            t = 1. / 3. * ((a1 + a2 + a3) + sqrt(-2. * a1 * a1 + 2. * a1 * a2 - 2. * a2 * a2 + 2. * a1 * a3 +
+                                                 2. * a2 * a3 - 2. * a3 * a3 + 3. * fh * fh));
+        }
+    }
+    if (t < T[n]) T[n] = t;
+}
+
+/* Grid3Drn::sweep_weno3, ttcr/Grid3Drn.h:2962-3044: same 8 directions as sweep */
+static void SFX(sweep3d_weno)(REAL* T, const REAL* s, const unsigned char* frozen, REAL dx, size_t nnx,
+                              size_t nny, size_t nnz) {
+    for (int dir = 0; dir < 8; ++dir) {
+        const int ri = dir & 1, rj = (dir >> 1) & 1, rk = (dir >> 2) & 1;
+        for (size_t kk = 0; kk < nnz; ++kk) {
+            const size_t k = rk ? nnz - 1 - kk : kk;
+            for (size_t jj = 0; jj < nny; ++jj) {
+                const size_t j = rj ? nny - 1 - jj : jj;
+                for (size_t ii = 0; ii < nnx; ++ii) {
+                    const size_t i = ri ? nnx - 1 - ii : ii;
+                    if (!frozen[(k * nny + j) * nnx + i]) SFX(update_node3d_weno)(T, s, dx, nnx, nny, nnz, i, j, k);
+                }
+            }
+        }
+    }
+}
+
 /* Grid3Drn ctor (ttcr/Grid3Drn.h:67-78) + Grid3Drnfs ctor (ttcr/Grid3Drnfs.h:39-50)
  * + translateOrigin handling of buildGridNodes (ttcr/Grid3Drn.h:362-372). */
 void SFX(fsm_grid3d_init)(SFX(fsm_grid3d) * g, uint32_t ncx, uint32_t ncy, uint32_t ncz, REAL dx,
@@ -277,24 +370,25 @@ void SFX(fsm_cells_to_nodes3d)(size_t ncx, size_t ncy, size_t ncz, const REAL* s
             }
 }
 
-/* Driver loop of Grid3Drnfs::raytrace (ttcr/Grid3Drnfs.h:84-155), weno3 == false
- * branch (:137-153), preceded by reinit (:92-94) and initFSM (:97-100).
+/* Driver loop of Grid3Drnfs::raytrace (ttcr/Grid3Drnfs.h:84-155): weno3 == false branch
+ * (:137-153) or the two-stage weno3 branch (:104-136: first-order sweeps to convergence, then
+ * sweep_weno3 to convergence, frozen box npts = 2), preceded by reinit (:92-94) and initFSM (:97-100).
  * eps is the per-node tolerance; the ctor scales it by the node count (:49).
  * src are in grid coordinates (origin already subtracted when translated).
  * change_hist (optional, length maxit) receives the L1 change of every iteration.
  * Returns niter. */
 int SFX(fsm_solve3d)(const SFX(fsm_grid3d) * g, const REAL* s, int n_src, const REAL* src,
-                     const REAL* t0, REAL eps, int maxit, REAL* T, REAL* change_hist) {
+                     const REAL* t0, REAL eps, int maxit, int weno, REAL* T, REAL* change_hist, int* niterw_out) {
     const size_t N = g->nnx * g->nny * g->nnz;
     REAL epsilon = eps;
     epsilon *= (REAL)N;
     unsigned char* frozen = (unsigned char*)calloc(N, 1);
     REAL* times = (REAL*)malloc(N * sizeof(REAL));
     for (size_t n = 0; n < N; ++n) T[n] = REAL_MAX;
-    SFX(init3d)(g, s, T, frozen, n_src, src, t0, 1);
+    SFX(init3d)(g, s, T, frozen, n_src, src, t0, weno ? 2 : 1);
     for (size_t n = 0; n < N; ++n) times[n] = T[n];
     REAL change = REAL_MAX;
-    int niter = 0;
+    int niter = 0, niterw = 0;
     while (change >= epsilon && niter < maxit) {
         SFX(sweep3d)(T, s, frozen, g->dx, g->nnx, g->nny, g->nnz);
         change = 0.0;
@@ -306,6 +400,21 @@ int SFX(fsm_solve3d)(const SFX(fsm_grid3d) * g, const REAL* s, int n_src, const 
         if (change_hist) change_hist[niter] = change;
         niter++;
     }
+    if (weno) { /* second stage, ttcr/Grid3Drnfs.h:125-136 */
+        change = REAL_MAX;
+        while (change >= epsilon && niterw < maxit) {
+            SFX(sweep3d_weno)(T, s, frozen, g->dx, g->nnx, g->nny, g->nnz);
+            change = 0.0;
+            for (size_t n = 0; n < N; ++n) {
+                REAL dt = FABS(times[n] - T[n]);
+                change += dt;
+                times[n] = T[n];
+            }
+            if (change_hist) change_hist[maxit + niterw] = change;
+            niterw++;
+        }
+    }
+    if (niterw_out) *niterw_out = niterw;
     free(times);
     free(frozen);
     return niter;
@@ -486,6 +595,56 @@ static void SFX(sweep2d)(REAL* T, const REAL* s, const unsigned char* frozen, RE
     }
 }
 
+
+/* Grid2Drn::update_node_weno3 (ttcr/Grid2Drn.h:1061-1213, dx == dz) and update_node_weno3_xz
+ * (:1217-1356): WENO axis values with the axis spacing, then the first-order local solver. */
+static void SFX(update_node2d_weno)(REAL* T, const REAL* s, REAL dx, REAL dz, int xz, size_t nnx, size_t nnz,
+                                    size_t i, size_t j) {
+    const size_t n = i * nnz + j;
+    REAL a = SFX(weno_axis)(T + n, (ptrdiff_t)nnz, i, nnx - 1, dx);
+    REAL b = SFX(weno_axis)(T + n, 1, j, nnz - 1, xz ? dz : dx);
+    REAL t;
+    if (!xz) {
+        REAL fh = s[n] * dx;
+        if (FABS(a - b) >= fh)
+            t = (a < b ? a : b) + fh;
+        else
+            t = 0.5 * (a + b + sqrt(2. * fh * fh - (a - b) * (a - b)));
+    } else {
+        const REAL sn = s[n];
+        if (a < b && ((b - a) / dx) > sn) {
+            t = a + sn * dx;
+        } else if (a > b && ((a - b) / dz) > sn) {
+            t = b + sn * dz;
+        } else {
+            REAL dx2 = dx * dx;
+            REAL dz2 = dz * dz;
+            REAL s2 = sn * sn;
+            t = (b * dx2 + a * dz2) / (dx2 + dz2) +
+                sqrt((2.0 * a * b * dx2 * dz2 - a * a * dx2 * dz2 - b * b * dx2 * dz2 + dx2 * dx2 * dz2 * s2 +
+                      dx2 * dz2 * dz2 * s2) /
+                     ((dx2 + dz2) * (dx2 + dz2)));
+        }
+    }
+    if (t < T[n]) T[n] = t;
+}
+
+/* Grid2Drn::sweep_weno3 / sweep_weno3_xz, ttcr/Grid2Drn.h:838-917 */
+static void SFX(sweep2d_weno)(REAL* T, const REAL* s, const unsigned char* frozen, REAL dx, REAL dz, int xz,
+                              size_t nnx, size_t nnz) {
+    static const int RI[4] = {0, 1, 1, 0};
+    static const int RJ[4] = {0, 0, 1, 1};
+    for (int dir = 0; dir < 4; ++dir) {
+        for (size_t ii = 0; ii < nnx; ++ii) {
+            const size_t i = RI[dir] ? nnx - 1 - ii : ii;
+            for (size_t jj = 0; jj < nnz; ++jj) {
+                const size_t j = RJ[dir] ? nnz - 1 - jj : jj;
+                if (!frozen[i * nnz + j]) SFX(update_node2d_weno)(T, s, dx, dz, xz, nnx, nnz, i, j);
+            }
+        }
+    }
+}
+
 /* Node2Dn::getDistance, ttcr/Node2Dn.h:134-136 */
 static REAL SFX(dist2d)(REAL x, REAL z, REAL px, REAL pz) {
     return (REAL)sqrt((x - px) * (x - px) + (z - pz) * (z - pz));
@@ -575,17 +734,17 @@ void SFX(fsm_cells_to_nodes2d)(size_t ncx, size_t ncz, const REAL* sc, REAL* sn)
 /* Grid2Drnfs::raytrace driver, ttcr/Grid2Drnfs.h:198-299, weno3 == false,
  * rotated_template == false branch (:277-297). */
 int SFX(fsm_solve2d)(const SFX(fsm_grid2d) * g, const REAL* s, int n_src, const REAL* src,
-                     const REAL* t0, REAL eps, int maxit, REAL* T, REAL* change_hist) {
+                     const REAL* t0, REAL eps, int maxit, int weno, REAL* T, REAL* change_hist, int* niterw_out) {
     const size_t N = g->nnx * g->nnz;
     REAL epsilon = eps;
     epsilon *= (REAL)N;
     unsigned char* frozen = (unsigned char*)calloc(N, 1);
     REAL* times = (REAL*)malloc(N * sizeof(REAL));
     for (size_t n = 0; n < N; ++n) T[n] = REAL_MAX;
-    SFX(init2d)(g, s, T, frozen, n_src, src, t0, 1);
+    SFX(init2d)(g, s, T, frozen, n_src, src, t0, weno ? 2 : 1);
     for (size_t n = 0; n < N; ++n) times[n] = T[n];
     REAL change = REAL_MAX;
-    int niter = 0;
+    int niter = 0, niterw = 0;
     const int xz = !(g->dx == g->dz);
     while (change >= epsilon && niter < maxit) {
         SFX(sweep2d)(T, s, frozen, g->dx, g->dz, xz, g->nnx, g->nnz);
@@ -598,6 +757,21 @@ int SFX(fsm_solve2d)(const SFX(fsm_grid2d) * g, const REAL* s, int n_src, const 
         if (change_hist) change_hist[niter] = change;
         niter++;
     }
+    if (weno) { /* ttcr/Grid2Drnfs.h:236-275 */
+        change = REAL_MAX;
+        while (change >= epsilon && niterw < maxit) {
+            SFX(sweep2d_weno)(T, s, frozen, g->dx, g->dz, xz, g->nnx, g->nnz);
+            change = 0.0;
+            for (size_t n = 0; n < N; ++n) {
+                REAL dt = FABS(times[n] - T[n]);
+                change += dt;
+                times[n] = T[n];
+            }
+            if (change_hist) change_hist[maxit + niterw] = change;
+            niterw++;
+        }
+    }
+    if (niterw_out) *niterw_out = niterw;
     free(times);
     free(frozen);
     return niter;

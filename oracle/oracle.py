@@ -101,8 +101,9 @@ def _prep_pts(dt, pts, ncol):
 
 
 def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-            cell_slowness=False, translate=False, rcv=None):
-    """Restatement of Grid3Drnfs / Grid3Drcfs ::raytrace (weno=False, tt_from_rp=False).
+            cell_slowness=False, translate=False, rcv=None, weno=False):
+    """Restatement of Grid3Drnfs / Grid3Drcfs ::raytrace (tt_from_rp=False; weno selects the
+    two-stage first-order + WENO3 driver).
 
     ncells = (ncx, ncy, ncz) CELL counts, as in the reference constructors.
     Returns dict(tt=flat node field, niter, change=per-iteration L1 change, tt_rcv).
@@ -133,10 +134,12 @@ def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=5
     if getattr(L, "fsm_outside3d_" + sfx)(C.byref(g), C.c_int(nsrc), _p(src)):
         raise RuntimeError("Error: Point outside grid.")
     T = np.empty(nn, dtype=dt)
-    hist = np.zeros(maxit, dtype=dt)
+    hist = np.zeros(2 * maxit, dtype=dt)
+    nw = C.c_int(0)
     niter = getattr(L, "fsm_solve3d_" + sfx)(C.byref(g), _p(sn), C.c_int(nsrc), _p(src), _p(t0), ct(eps),
-                                             C.c_int(maxit), _p(T), _p(hist))
-    out = dict(tt=T, niter=int(niter), change=hist[:niter].copy(), node_slowness=sn)
+                                             C.c_int(maxit), C.c_int(int(weno)), _p(T), _p(hist), C.byref(nw))
+    out = dict(tt=T, niter=int(niter), niterw=int(nw.value), change=hist[:niter].copy(),
+               changew=hist[maxit:maxit + nw.value].copy(), node_slowness=sn)
     if rcv is not None:
         r = _prep_pts(dt, rcv, 3).copy()
         if translate:
@@ -186,8 +189,8 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
 
 
 def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-            cell_slowness=False, rcv=None):
-    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (weno=False, rotated_template=False)."""
+            cell_slowness=False, rcv=None, weno=False):
+    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (rotated_template=False)."""
     dt = np.dtype(dtype)
     sfx, ct, _, G2 = _TYPES[dt]
     L = lib()
@@ -210,10 +213,12 @@ def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, max
     if getattr(L, "fsm_outside2d_" + sfx)(C.byref(g), C.c_int(nsrc), _p(src)):
         raise RuntimeError("Error: Point outside grid.")
     T = np.empty(nn, dtype=dt)
-    hist = np.zeros(maxit, dtype=dt)
+    hist = np.zeros(2 * maxit, dtype=dt)
+    nw = C.c_int(0)
     niter = getattr(L, "fsm_solve2d_" + sfx)(C.byref(g), _p(sn), C.c_int(nsrc), _p(src), _p(t0), ct(eps),
-                                             C.c_int(maxit), _p(T), _p(hist))
-    out = dict(tt=T, niter=int(niter), change=hist[:niter].copy(), node_slowness=sn)
+                                             C.c_int(maxit), C.c_int(int(weno)), _p(T), _p(hist), C.byref(nw))
+    out = dict(tt=T, niter=int(niter), niterw=int(nw.value), change=hist[:niter].copy(),
+               changew=hist[maxit:maxit + nw.value].copy(), node_slowness=sn)
     if rcv is not None:
         r = _prep_pts(dt, rcv, 2)
         f = getattr(L, "fsm_interp2d_" + sfx)

@@ -123,6 +123,12 @@ def rcv_lattice3d(length=20.0, n=21):
     return np.stack([np.zeros(Y.size), Y.ravel(), Z.ravel()], axis=1)
 
 
+def weno_ok(c):
+    """Cases used for the WENO3 stage: every axis needs >= 3 cells (the reference's stencil reads
+    idx+2 at idx == 1 unconditionally, ttcr/Grid3Drn.h:3086-3092), kept small for the fixture file."""
+    return min(c["ncells"]) >= 3 and int(np.prod(np.array(c["ncells"]) + 1)) <= 20000
+
+
 # ------------------------------------------------------------------ case matrix
 # Every case: dict(name, dim, ncells, dx[,dz], origin, slowness (float64), cell_slowness,
 #                  src (n,dim), t0 (n,), rcv (m,dim), translate)

@@ -7,6 +7,8 @@ For every case of tests/cases.py and both dtypes the file holds the reference's 
   <case>/<dtype>/tt       full node traveltime field (Grid3Drn::getTT, flat, x-fastest / z-fastest)
   <case>/<dtype>/niter    get_niter()
   <case>/<dtype>/tt_rcv   Grid3Drn::getTraveltime at the case's receivers (tt_from_rp = false)
+  <case>/<dtype>/weno_*   the same four outputs (+ niterw) of the two-stage weno=True solve, for the
+                          cases of cases.weno_ok()
 and the inputs  <case>/slowness (float64; cast to the dtype under test), so that the
 vectors do not depend on numpy's random generator staying stable.
 """
@@ -43,6 +45,19 @@ def main():
             out[key + "/niter"] = np.int32(r["niter"])
             out[key + "/tt_rcv"] = r["tt_rcv"]
             print(key, "niter", r["niter"])
+            if cases.weno_ok(c):
+                # two-stage solve with the third-order WENO stage (weno=True, the ttcrpy default)
+                if c["dim"] == 3:
+                    r = O.ref_solve3d(dt, c["ncells"], c["dx"], c["origin"], c["slowness"], c["src"], c["t0"],
+                                      cell_slowness=c["cell_slowness"], translate=c["translate"], rcv=c["rcv"], weno=True)
+                else:
+                    r = O.ref_solve2d(dt, c["ncells"], c["dx"], c["dz"], c["origin"], c["slowness"], c["src"],
+                                      c["t0"], cell_slowness=c["cell_slowness"], rcv=c["rcv"], weno=True)
+                out[key + "/weno_tt"] = r["tt"]
+                out[key + "/weno_niter"] = np.int32(r["niter"])
+                out[key + "/weno_niterw"] = np.int32(r["niterw"])
+                out[key + "/weno_tt_rcv"] = r["tt_rcv"]
+                print(key, "weno niter", r["niter"], r["niterw"])
     path = os.path.join(HERE, "fsm_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -23,16 +23,20 @@ SMALL = [c for c in cases.cases3d() + cases.cases2d() if np.prod(np.array(c["nce
 
 @pytest.mark.parametrize("c", SMALL, ids=[c["name"] for c in SMALL])
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-def test_restatement_bit_exact_vs_reference(O, c, dt):
+@pytest.mark.parametrize("weno", [False, True], ids=["first-order", "weno3"])
+def test_restatement_bit_exact_vs_reference(O, c, dt, weno):
+    if weno and not cases.weno_ok(c):
+        pytest.skip("grid too thin for the WENO stencil")
     if c["dim"] == 3:
-        kw = dict(dtype=dt, ncells=c["ncells"], dx=c["dx"], origin=c["origin"], slowness=c["slowness"],
+        kw = dict(dtype=dt, ncells=c["ncells"], dx=c["dx"], origin=c["origin"], slowness=c["slowness"], weno=weno,
                   src=c["src"], t0=c["t0"], cell_slowness=c["cell_slowness"], translate=c["translate"], rcv=c["rcv"])
         a, b = O.solve3d(**kw), O.ref_solve3d(**kw)
     else:
         kw = dict(dtype=dt, ncells=c["ncells"], dx=c["dx"], dz=c["dz"], origin=c["origin"], slowness=c["slowness"],
-                  src=c["src"], t0=c["t0"], cell_slowness=c["cell_slowness"], rcv=c["rcv"])
+                  src=c["src"], t0=c["t0"], cell_slowness=c["cell_slowness"], rcv=c["rcv"], weno=weno)
         a, b = O.solve2d(**kw), O.ref_solve2d(**kw)
     assert a["niter"] == b["niter"]
+    assert a["niterw"] == b["niterw"]
     np.testing.assert_array_equal(a["tt"], b["tt"])
     np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
 
