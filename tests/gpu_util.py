@@ -4,7 +4,7 @@ import numpy as np
 import ttcr_amd
 
 
-def grid_from_case(c, dt, n_threads=1):
+def grid_from_case(c, dt, n_threads=1, weno=0):
     nc = c["ncells"]
     o = c["origin"]
     if c["dim"] == 3:
@@ -12,7 +12,7 @@ def grid_from_case(c, dt, n_threads=1):
         y = o[1] + np.arange(nc[1] + 1) * c["dx"]
         z = o[2] + np.arange(nc[2] + 1) * c["dx"]
         g = ttcr_amd.Grid3d(x, y, z, n_threads=n_threads, cell_slowness=c["cell_slowness"], method="FSM",
-                            tt_from_rp=0, weno=0, translate_grid=c["translate"], dtype=dt)
+                            tt_from_rp=0, weno=weno, translate_grid=c["translate"], dtype=dt)
         shape = g.shape
         # fixtures hold the solver's flat order (x-fastest); the wrapper takes (nx,ny,nz) arrays
         s = np.asarray(c["slowness"], dtype=np.float64).reshape(shape, order="F")
@@ -20,7 +20,7 @@ def grid_from_case(c, dt, n_threads=1):
         x = o[0] + np.arange(nc[0] + 1) * c["dx"]
         z = o[1] + np.arange(nc[1] + 1) * c["dz"]
         g = ttcr_amd.Grid2d(x, z, n_threads=n_threads, cell_slowness=c["cell_slowness"], method="FSM",
-                            tt_from_rp=0, weno=0, dtype=dt)
+                            tt_from_rp=0, weno=weno, dtype=dt)
         s = np.asarray(c["slowness"], dtype=np.float64).reshape(g.shape)
     return g, s
 
@@ -30,11 +30,11 @@ def source_array(c):
     return np.hstack([np.asarray(c["t0"], dtype=np.float64)[:, None], c["src"]])
 
 
-def run_case(c, dt):
-    g, s = grid_from_case(c, dt)
+def run_case(c, dt, weno=0):
+    g, s = grid_from_case(c, dt, weno=weno)
     tt_rcv = g.raytrace(source_array(c), c["rcv"], slowness=s, aggregate_src=True)
     if c["dim"] == 3:
         field = g.get_grid_traveltimes().flatten("F")
     else:
         field = g.get_grid_traveltimes().ravel()
-    return dict(tt=field, tt_rcv=tt_rcv, niter=g.get_niter(0), grid=g)
+    return dict(tt=field, tt_rcv=tt_rcv, niter=g.get_niter(0), niterw=g.get_niterw(0), grid=g)

@@ -39,6 +39,21 @@ def test_hip_matches_golden_bit_exact(golden, c, dt):
     np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/tt_rcv"])
 
 
+WENO = [(c, dt) for c, dt in ALL if cases.weno_ok(c)]
+
+
+@pytest.mark.parametrize("c,dt", WENO, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in WENO])
+def test_hip_weno_matches_golden_bit_exact(golden, c, dt):
+    """weno=True (the ttcrpy default): first-order sweeps then WENO3 sweeps, both iteration counts"""
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    c = dict(c, slowness=golden[f"{c['name']}/slowness"])
+    r = run_case(c, dt, weno=1)
+    assert r["niter"] == int(golden[key + "/weno_niter"])
+    assert r["niterw"] == int(golden[key + "/weno_niterw"])
+    np.testing.assert_array_equal(r["tt"], golden[key + "/weno_tt"])
+    np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/weno_tt_rcv"])
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_hip_matches_oracle_on_fresh_inputs(oracle, dt):
     """inputs that are NOT in the golden file: random slowness, random off-node source"""
@@ -79,4 +94,30 @@ def test_hip_matches_oracle_medium_grids(oracle, kind):
     r = run_case(c, np.float32)
     o = oracle.solve3d(np.float32, nc, r["grid"].dx, c["origin"], s, src, rcv=c["rcv"])
     assert r["niter"] == o["niter"]
+    np.testing.assert_array_equal(r["tt"], o["tt"])
+
+
+@pytest.mark.parametrize("kind", ["gradient3d_49x41x45", "layers2d_300x210", "gradient2d_xz_290x180"])
+def test_hip_weno_matches_oracle_multi_patch(oracle, kind):
+    """WENO stage across several patches per axis (2-column halos exchanged between workgroups)."""
+    if kind.startswith("gradient3d"):
+        nn = (49, 41, 45)
+        dx = 0.4
+        nc = tuple(v - 1 for v in nn)
+        s = cases.gradient3d(nn, dx)
+        c = dict(name=kind, dim=3, ncells=nc, dx=dx, origin=(0.0, 0.0, 0.0), cell_slowness=False, slowness=s,
+                 translate=False, src=np.array([[7.3, 11.2, 5.9]]), t0=np.array([0.0]), rcv=np.array([[1.0, 2.0, 3.0]]))
+        r = run_case(c, np.float32, weno=1)
+        o = oracle.solve3d(np.float32, nc, r["grid"].dx, c["origin"], s, c["src"], rcv=c["rcv"], weno=True)
+    else:
+        xz = "xz" in kind
+        nn = (290, 180) if xz else (300, 210)
+        dx, dz = (0.1, 0.15) if xz else (0.1, 0.1)
+        nc = tuple(v - 1 for v in nn)
+        s = cases.gradient2d(nn, dz) if xz else np.tile(1.0 / (1.0 + 0.1 * np.floor(np.arange(nn[1]) * dz)), nn[0])
+        c = dict(name=kind, dim=2, ncells=nc, dx=dx, dz=dz, origin=(0.0, 0.0), cell_slowness=False, slowness=s,
+                 translate=False, src=np.array([[7.31, 11.27]]), t0=np.array([0.0]), rcv=np.array([[1.0, 2.0]]))
+        r = run_case(c, np.float32, weno=1)
+        o = oracle.solve2d(np.float32, nc, r["grid"].dx, r["grid"].dz, c["origin"], s, c["src"], rcv=c["rcv"], weno=True)
+    assert (r["niter"], r["niterw"]) == (o["niter"], o["niterw"])
     np.testing.assert_array_equal(r["tt"], o["tt"])

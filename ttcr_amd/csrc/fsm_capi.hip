@@ -84,7 +84,8 @@ class GridBase {
     virtual void interp(int slot, int n, const void* pts, void* out) = 0;
     int dim = 3, dtype = 0, n_slots = 1, device = 0;
     size_t n_nodes = 0, n_cells = 0;
-    std::vector<int> niter;
+    std::vector<int> niter, niterw;
+    bool weno = false;
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
     int skip = 0;  // persistent kernel: 1 = skip chunks whose read set did not change (exact); see DESIGN.md
     int mode = 1;  // 1: persistent kernel, one launch per sweep (default); 0: one launch per tile wavefront
@@ -139,9 +140,10 @@ class GridT : public GridBase {
     size_t mask_words = 0;
     SweepGeom geom;
     int n_launch = 0;  // launches per sweep direction
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_batch = 0, graph_mode = -1;
+    // one captured launch sequence per stage (first-order / WENO3)
+    hipGraph_t graphs[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_execs[2] = {nullptr, nullptr};
+    int graph_batches[2] = {0, 0}, graph_modes[2] = {-1, -1};
 
     GridT(int dim_, bool cell_, uint32_t nx, uint32_t ny, uint32_t nz, double ddx, double ddz, double minx,
           double miny, double minz, double eps, int maxit, int nslots, bool translate_, int dev) {
@@ -175,6 +177,7 @@ class GridT : public GridBase {
         nitermax = maxit;
         n_slots = nslots;
         niter.assign(n_slots, 0);
+        niterw.assign(n_slots, 0);
         max_batch = n_slots;
         device = dev;
         HIP_CHECK(hipSetDevice(device));
@@ -244,7 +247,7 @@ class GridT : public GridBase {
         d_sync.reserve(2 + (size_t)n_patches * n_slots);
     }
 
-    template <int DIM>
+    template <int DIM, int H>
     void launch_sweeps_persistent(int batch) {
         using C = TileCfg<T, DIM>;
         constexpr int CH = ChunkCfg<T, DIM>::C;
@@ -294,9 +297,9 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
             if (skip)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true><<<grid, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H><<<grid, block, 0, stream>>>(pa);
             else
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false><<<grid, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H><<<grid, block, 0, stream>>>(pa);
         }
         HIP_CHECK(hipGetLastError());
     }
@@ -328,8 +331,10 @@ class GridT : public GridBase {
 
     ~GridT() override {
         (void)hipSetDevice(device);
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        if (graph) (void)hipGraphDestroy(graph);
+        for (int i = 0; i < 2; ++i) {
+            if (graph_execs[i]) (void)hipGraphExecDestroy(graph_execs[i]);
+            if (graphs[i]) (void)hipGraphDestroy(graphs[i]);
+        }
         if (h_change) (void)hipHostFree(h_change);
         if (h_slots) (void)hipHostFree(h_slots);
         if (h_abort) (void)hipHostFree(h_abort);
@@ -536,9 +541,14 @@ class GridT : public GridBase {
         HIP_CHECK(hipGetLastError());
     }
 
+    int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
+    bool persistent_now() const { return mode == 1 || stage == 1; }
+
     void issue_sweeps(int batch) {
-        if (mode == 1) {
-            if (dim == 3) launch_sweeps_persistent<3>(batch); else launch_sweeps_persistent<2>(batch);
+        if (stage == 1) {
+            if (dim == 3) launch_sweeps_persistent<3, 2>(batch); else launch_sweeps_persistent<2, 2>(batch);
+        } else if (mode == 1) {
+            if (dim == 3) launch_sweeps_persistent<3, 1>(batch); else launch_sweeps_persistent<2, 1>(batch);
         } else {
             if (dim == 3) launch_sweeps<3>(batch); else launch_sweeps<2>(batch);
         }
@@ -547,7 +557,10 @@ class GridT : public GridBase {
     void run_iteration(int batch) {
         const int ndir = dim == 3 ? 8 : 4;
         if (use_graph) {
-            if (!graph_exec || graph_batch != batch || graph_mode != mode * 2 + skip) {
+            hipGraph_t& graph = graphs[stage];
+            hipGraphExec_t& graph_exec = graph_execs[stage];
+            const int key = mode * 2 + skip;
+            if (!graph_exec || graph_batches[stage] != batch || graph_modes[stage] != key) {
                 if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
                 if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
                 HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -561,14 +574,14 @@ class GridT : public GridBase {
                 }
                 HIP_CHECK(hipStreamEndCapture(stream, &graph));
                 HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
-                graph_batch = batch;
-                graph_mode = mode * 2 + skip;
+                graph_batches[stage] = batch;
+                graph_modes[stage] = key;
             }
             HIP_CHECK(hipGraphLaunch(graph_exec, stream));
         } else {
             issue_sweeps(batch);
         }
-        timing.launches += mode == 1 ? (long long)ndir : (long long)ndir * n_launch;
+        timing.launches += persistent_now() ? (long long)ndir : (long long)ndir * n_launch;
     }
 
     // One batch: sources src_ids[b] solved concurrently, source b in slot slot_ids[b].
@@ -601,7 +614,7 @@ class GridT : public GridBase {
             ia.bbox = d_bbox.p + 6 * (size_t)slot;
             ia.pts = d_pts.p + first[b];
             ia.n_pts = tx_off[src_ids[b] + 1] - tx_off[src_ids[b]];
-            ia.npts = 1;
+            ia.npts = weno ? 2 : 1;  // frozen box of the WENO solver (ttcr/Grid3Drnfs.h:98-100)
             ia.nnx = ncx + 1;
             ia.nny = dim == 3 ? ncy + 1 : 1;
             ia.nnz = ncz + 1;
@@ -612,44 +625,58 @@ class GridT : public GridBase {
             ia.nbf = nbf; ia.nbj = nbj; ia.nbk = nbk;
             fsm_init_source<T><<<1, 128, 0, stream>>>(ia);
             niter[slot] = 0;
+            niterw[slot] = 0;
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(stream));  // pts vector goes out of scope below; also surfaces errors early
 
-        // driver loop of Grid3Drnfs::raytrace (ttcr/Grid3Drnfs.h:137-153), per source
-        std::vector<int> active(slot_ids);
+        // driver loop of Grid3Drnfs::raytrace, per source: first-order sweeps until the L1 change
+        // drops below eps*N (ttcr/Grid3Drnfs.h:137-153); with weno3 a second loop of WENO sweeps with
+        // the change reset (:104-136).  A source that converges leaves the batch (slot -1).
         const int maxit = fixed_iters > 0 ? fixed_iters : nitermax;
-        int it = 0;
         const int ndir = dim == 3 ? 8 : 4;
-        // the graph is built for a fixed z-extent; finished sources are masked with slot -1 ... but
-        // a masked block still has to read slots[z], so keep the list compact and pad with -1.
-        if (mode == 1) HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 2 * sizeof(int), stream));
+        if (persistent_now() || weno) HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 2 * sizeof(int), stream));
         HIP_CHECK(hipMemsetAsync(d_evals.p, 0, sizeof(unsigned long long) * n_slots, stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
-        while (!active.empty() && it < maxit) {
-            for (int b = 0; b < nb; ++b) h_slots[b] = b < (int)active.size() ? active[b] : -1;
-            HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * nb, hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
-            *h_iter = it;
-            HIP_CHECK(hipMemcpyAsync(d_iter.p, h_iter, sizeof(int), hipMemcpyHostToDevice, stream));
-            run_iteration(nb);
-            HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
-            if (mode == 1) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            if (mode == 1 && *h_abort) {
-                HIP_CHECK(hipMemsetAsync(d_sync.p + 1, 0, sizeof(int), stream));
-                throw DeviceError("persistent sweep kernel: a patch timed out waiting for its upwind neighbour");
+        int it_total = 0;  // global iteration index: sweep numbers for the dirty-brick stamps
+        for (stage = 0; stage < (weno ? 2 : 1); ++stage) {
+            std::vector<int> active(slot_ids);
+            int it = 0;
+            while (!active.empty() && it < maxit) {
+                for (int b = 0; b < nb; ++b) h_slots[b] = b < (int)active.size() ? active[b] : -1;
+                HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * nb, hipMemcpyHostToDevice, stream));
+                HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
+                *h_iter = it_total;
+                HIP_CHECK(hipMemcpyAsync(d_iter.p, h_iter, sizeof(int), hipMemcpyHostToDevice, stream));
+                run_iteration(nb);
+                HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
+                if (persistent_now()) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                if (persistent_now() && *h_abort) {
+                    HIP_CHECK(hipMemsetAsync(d_sync.p + 1, 0, sizeof(int), stream));
+                    stage = 0;
+                    throw DeviceError("persistent sweep kernel: a patch timed out waiting for its upwind neighbour");
+                }
+                ++it;
+                ++it_total;
+                std::vector<int> next;
+                for (int s2 : active) {
+                    (stage == 0 ? niter : niterw)[s2] = it;
+                    timing.node_updates += (long long)n_nodes * ndir;
+                    const bool go_on = fixed_iters > 0 ? true : (h_change[s2] >= (double)epsilon);
+                    if (go_on) next.push_back(s2);
+                }
+                active.swap(next);
             }
-            ++it;
-            std::vector<int> next;
-            for (int s : active) {
-                niter[s] = it;
-                timing.node_updates += (long long)n_nodes * ndir;
-                const bool go_on = fixed_iters > 0 ? true : (h_change[s] >= (double)epsilon);
-                if (go_on) next.push_back(s);
+            timing.iterations = std::max(timing.iterations, it_total);
+            // the stamps of the first-order stage say nothing about the WENO stencil: start clean
+            if (stage == 0 && weno && skip) {
+                for (int s2 : slot_ids)
+                    HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)s2 * n_bricks, 0x7f, n_bricks * sizeof(int), stream));
             }
-            active.swap(next);
         }
+        const bool was_persistent = mode == 1 || weno;
+        stage = 0;
         HIP_CHECK(hipEventRecord(ev1, stream));
         HIP_CHECK(hipEventSynchronize(ev1));
         if (d_prof.p) {
@@ -669,8 +696,7 @@ class GridT : public GridBase {
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.sweep_ms += ms;
-        timing.iterations = std::max(timing.iterations, it);
-        if (mode == 1) {
+        if (was_persistent) {
             HIP_CHECK(hipMemcpy(h_evals, d_evals.p, sizeof(unsigned long long) * n_slots, hipMemcpyDeviceToHost));
             for (int s2 : slot_ids) timing.evaluated_updates += (long long)h_evals[s2];
         } else {
@@ -823,13 +849,15 @@ int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
         if (ncx < 1 || ncy < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
         if (n_slots < 1) throw ValueError("n_slots must be >= 1");
         if (!(dx > 0)) throw ValueError("dx must be positive");
-        if (weno) throw Unsupported("weno=True (third-order WENO stage, ttcr/Grid3Drn.h:2962-3484) is not built yet; use weno=False");
+        if (weno && (ncx < 3 || ncy < 3 || ncz < 3))
+            throw ValueError("weno=True needs at least 3 cells per axis (the reference's stencil reads idx+2 at idx == 1, ttcr/Grid3Drn.h:3086-3092)");
         const int dev = pick_device(device);
         auto g = std::make_unique<ttcr_fsm_grid>();
         if (dtype == TTCR_F32)
             g->impl.reset(new GridT<float>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev));
         else
             g->impl.reset(new GridT<double>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev));
+        g->impl->weno = weno != 0;
         *out = g.release();
     });
 }
@@ -843,7 +871,7 @@ int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
         if (ncx < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
         if (n_slots < 1) throw ValueError("n_slots must be >= 1");
         if (!(dx > 0) || !(dz > 0)) throw ValueError("dx and dz must be positive");
-        if (weno) throw Unsupported("weno=True (third-order WENO stage, ttcr/Grid2Drn.h:838-917) is not built yet; use weno=False");
+        if (weno && (ncx < 3 || ncz < 3)) throw ValueError("weno=True needs at least 3 cells per axis");
         if (rotated_template) throw Unsupported("rotated_template=True (sweep45, ttcr/Grid2Drn.h:756-794) is not built yet");
         const int dev = pick_device(device);
         auto g = std::make_unique<ttcr_fsm_grid>();
@@ -851,6 +879,7 @@ int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
             g->impl.reset(new GridT<float>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev));
         else
             g->impl.reset(new GridT<double>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev));
+        g->impl->weno = weno != 0;
         *out = g.release();
     });
 }
@@ -894,7 +923,7 @@ int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw) {
     return guarded([&] {
         if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
         if (niter) *niter = g->impl->niter[slot];
-        if (niterw) *niterw = 0;
+        if (niterw) *niterw = g->impl->niterw[slot];
     });
 }
 int ttcr_fsm_n_slots(const ttcr_fsm_grid* g) { return g->impl->n_slots; }

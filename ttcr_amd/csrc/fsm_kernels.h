@@ -485,20 +485,137 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
     __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP>
+// ---- third-order WENO stage (second stage of the reference's default solver) ------------
+// Grid3Drn::weno3_upwind (ttcr/Grid3Drn.h:3047-3075) / the inlined 2-D form (ttcr/Grid2Drn.h:
+// 1078-1125).  Every named intermediate of the reference is a T1 and its double literals make the
+// right-hand sides double: reproduced operation by operation (no fused shortcuts: the divisions
+// are IEEE divisions).  v1..v4 / v0..v3 are in NATURAL index order along the axis.
+__device__ __forceinline__ float weno_fwd(float v1, float v2, float v3, float v4, float h) {
+    const float eps = 1.1920928955078125e-07f;
+    const float num = (float)(((double)v4 - 2.0 * (double)v3) + (double)v2);
+    const float den = (float)(((double)v3 - 2.0 * (double)v2) + (double)v1);
+    const float r = (eps + num * num) / (eps + den * den);
+    const float w = (float)(1.0 / (1.0 + (2.0 * (double)r) * (double)r));
+    const float d31 = v3 - v1;
+    const double h2 = 2.0 * (double)h;
+    const double ap = ((1.0 - (double)w) * (double)d31) / h2 +
+                      ((double)w * ((-(double)v4 + 4.0 * (double)v3) - 3.0 * (double)v2)) / h2;
+    return v2 + h * (float)ap;
+}
+__device__ __forceinline__ float weno_bwd(float v0, float v1, float v2, float v3, float h) {
+    const float eps = 1.1920928955078125e-07f;
+    const float num = (float)(((double)v2 - 2.0 * (double)v1) + (double)v0);
+    const float den = (float)(((double)v3 - 2.0 * (double)v2) + (double)v1);
+    const float r = (eps + num * num) / (eps + den * den);
+    const float w = (float)(1.0 / (1.0 + (2.0 * (double)r) * (double)r));
+    const float d31 = v3 - v1;
+    const double h2 = 2.0 * (double)h;
+    const double am = ((1.0 - (double)w) * (double)d31) / h2 +
+                      ((double)w * ((3.0 * (double)v2 - 4.0 * (double)v1) + (double)v0)) / h2;
+    return v2 - h * (float)am;
+}
+__device__ __forceinline__ double weno_fwd(double v1, double v2, double v3, double v4, double h) {
+    const double eps = 2.220446049250313e-16;
+    const double num = (v4 - 2.0 * v3 + v2);
+    const double den = (v3 - 2.0 * v2 + v1);
+    const double r = (eps + num * num) / (eps + den * den);
+    const double w = 1.0 / (1.0 + 2.0 * r * r);
+    const double ap = (1.0 - w) * (v3 - v1) / (2.0 * h) + w * (-v4 + 4.0 * v3 - 3.0 * v2) / (2.0 * h);
+    return v2 + h * ap;
+}
+__device__ __forceinline__ double weno_bwd(double v0, double v1, double v2, double v3, double h) {
+    const double eps = 2.220446049250313e-16;
+    const double num = (v2 - 2.0 * v1 + v0);
+    const double den = (v3 - 2.0 * v2 + v1);
+    const double r = (eps + num * num) / (eps + den * den);
+    const double w = 1.0 / (1.0 + 2.0 * r * r);
+    const double am = (1.0 - w) * (v3 - v1) / (2.0 * h) + w * (3.0 * v2 - 4.0 * v1 + v0) / (2.0 * h);
+    return v2 - h * am;
+}
+
+// One axis of update_node_weno3 (ttcr/Grid3Drn.h:3084-3196): m2..p2 are the values at natural
+// offsets -2..+2 along the axis, idx the node's natural index, n the last index.
+template <typename T>
+__device__ __forceinline__ T weno_axis(T m2, T m1, T c, T p1, T p2, int idx, int n, T h) {
+    T a, t;
+    if (idx == 0) {
+        a = p1;
+    } else if (idx == 1) {
+        a = weno_fwd(m1, c, p1, p2, h);
+        t = m1;
+        a = a < t ? a : t;
+    } else if (idx == n) {
+        a = m1;
+    } else if (idx == n - 1) {
+        a = weno_bwd(m2, m1, c, p1, h);
+        t = p1;
+        a = a < t ? a : t;
+    } else {
+        a = weno_fwd(m1, c, p1, p2, h);
+        t = weno_bwd(m2, m1, c, p1, h);
+        a = a < t ? a : t;
+    }
+    return a;
+}
+
+// Local solver of the WENO stage: the reference's literal compare/swap network and nested ifs
+// (ttcr/Grid3Drn.h:3432-3452) -- WENO axis values may be NaN/inf next to unreached nodes, and
+// min/max/med3 would not propagate them the way the swaps do.  Discriminants as in update3.
+__device__ __forceinline__ float solve3_literal(float a1, float a2, float a3, float fh) {
+    if (a1 > a2) { const float w = a1; a1 = a2; a2 = w; }
+    if (a1 > a3) { const float w = a1; a1 = a3; a3 = w; }
+    if (a2 > a3) { const float w = a2; a2 = a3; a3 = w; }
+    float t = a1 + fh;
+    if (t > a2) {
+        const double d1 = a1, d2 = a2, dfh = fh;
+        const float df = a1 - a2;
+        const float df2 = df * df;
+        t = (float)(0.5 * ((double)(a1 + a2) + __builtin_sqrt(__builtin_fma(dfh * dfh, 2.0, -(double)df2))));
+        if (t > a3) {
+            const double d3 = a3;
+            double r = (-2.0 * d1) * d1;
+            r = __builtin_fma(2.0 * d1, d2, r);
+            r = __builtin_fma(-2.0 * d2, d2, r);
+            r = __builtin_fma(2.0 * d1, d3, r);
+            r = __builtin_fma(2.0 * d2, d3, r);
+            r = __builtin_fma(-2.0 * d3, d3, r);
+            r = __builtin_fma(3.0 * dfh, dfh, r);
+            t = (float)((1. / 3.) * ((double)((a1 + a2) + a3) + __builtin_sqrt(r)));
+        }
+    }
+    return t;
+}
+__device__ __forceinline__ double solve3_literal(double a1, double a2, double a3, double fh) {
+    if (a1 > a2) { const double w = a1; a1 = a2; a2 = w; }
+    if (a1 > a3) { const double w = a1; a1 = a3; a3 = w; }
+    if (a2 > a3) { const double w = a2; a2 = a3; a3 = w; }
+    double t = a1 + fh;
+    if (t > a2) {
+        t = 0.5 * (a1 + a2 + __builtin_sqrt(2. * fh * fh - (a1 - a2) * (a1 - a2)));
+        if (t > a3) {
+            t = 1. / 3. * ((a1 + a2 + a3) + __builtin_sqrt(-2. * a1 * a1 + 2. * a1 * a2 - 2. * a2 * a2 + 2. * a1 * a3 +
+                                                            2. * a2 * a3 - 2. * a3 * a3 + 3. * fh * fh));
+        }
+    }
+    return t;
+}
+
+// ---- persistent sweep kernel, halo width H (1: first-order stage, 2: WENO3 stage) -----------
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H>
 __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs<T> pa) {
     constexpr int NT = PJ * PK;
-    constexpr int RJ = PJ + 2;
-    constexpr int NROWS = IS3D ? RJ * (PK + 2) : RJ;
-    constexpr int NQ = C + 2;
+    constexpr int RJ = PJ + 2 * H;
+    constexpr int NROWS = IS3D ? RJ * (PK + 2 * H) : RJ;
+    constexpr int NQ = C + 2 * H;               // tile levels: L0-H .. L0+C+H-1  <->  q = 0 .. NQ-1
     constexpr int RS = NQ | 1;
-    constexpr int NUP = IS3D ? (PJ + PK) : 1;   // upwind halo columns
-    constexpr int NDH = IS3D ? (PJ + PK) : 1;   // downwind halo columns
-    // streaming map: C consecutive lanes walk the C new levels of one column, NT/C columns per pass
+    constexpr int NUP = IS3D ? H * (PJ + PK) : H;   // upwind halo columns
+    constexpr int NDH = IS3D ? H * (PJ + PK) : H;   // downwind halo columns
+    // streaming map: C consecutive lanes walk C consecutive levels of one column, NT/C columns per pass
     constexpr int RPI = NT / C;
     constexpr int NOWN = C;                      // passes over the own columns (NT / RPI)
     constexpr int NHI = (NDH + RPI - 1) / RPI;   // passes over the downwind halo columns
-    static_assert(NT % C == 0 && (IS3D || PK == 1) && C <= FSM_BRICK, "tile shape");
+    constexpr int NUPI = (NUP + RPI - 1) / RPI;  // passes over the upwind halo columns
+    static_assert(NT % C == 0 && (IS3D || PK == 1) && C <= FSM_BRICK && (H == 1 || H == 2), "tile shape");
     const SweepArgs<T>& a = pa.s;
 
     __shared__ T Tt[NROWS * RS];
@@ -540,8 +657,10 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     const int tj = tid % PJ, tk = tid / PJ;
     const int jp = j0 + tj, kp = k0 + tk;
     const bool col_ok = jp < NJ && kp < NK;
-    const int row = IS3D ? (tk + 1) * RJ + tj + 1 : tj + 1;
-    const uint32_t colbase = ((uint32_t)(rk ? NK - 1 - kp : kp) * NJ + (rj ? NJ - 1 - jp : jp)) * NF;
+    const int row = IS3D ? (tk + H) * RJ + tj + H : tj + H;
+    const int jn = rj ? NJ - 1 - jp : jp;   // natural J / K index of the column
+    const int kn = rk ? NK - 1 - kp : kp;
+    const uint32_t colbase = ((uint32_t)kn * NJ + jn) * NF;
     const T dx = a.dx, dz = a.dz;
     const int variant = a.variant;
     const uint32_t* __restrict__ Fz = a.frozen + (size_t)slot * a.mask_words;
@@ -550,13 +669,20 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     const int M = a.g.M;
     const size_t sbase = (size_t)(a.rev ? NK - 1 - kp : kp) * M * NJ + (a.rev ? NJ - 1 - jp : jp);
 
+    // LDS row (without the level) of the column at patch-relative (cj, ck), halo included
+    auto lds_row = [&](int cj, int ck) { return (IS3D ? (ck + H) * RJ + cj + H : cj + H) * RS; };
+    // natural row base of the column at oriented (jq, kq)
+    auto nat_row = [&](int jq, int kq) {
+        return ((uint32_t)(rk ? NK - 1 - kq : kq) * NJ + (rj ? NJ - 1 - jq : jq)) * NF;
+    };
+
     // streaming identity: lane e = tid % C walks levels, rsub = tid / C picks the column of a pass
     const int e = tid % C, rsub = tid / C;
-    // per pass: column (cj, ck), its natural row base and the constant part of i'
-    //   i' = L - j' - k'  with L = L0+1+e  ->  i' = L0 + ipb,  natural i = fb + sf*L0
+    // static passes: levels L0+H+e of the own and downwind-halo columns  <->  tile q = e + 2H
+    //   i' = L - j' - k' = L0 + ipb,  natural index = abase + sf*L0
     int ipb[NOWN + NHI];
-    uint32_t abase[NOWN + NHI];  // natural row base + (rf ? NF-1-ipb : ipb)
-    int lrow[NOWN + NHI];        // LDS row of that column
+    uint32_t abase[NOWN + NHI];
+    int lrow[NOWN + NHI];
 #pragma unroll
     for (int it = 0; it < NOWN + NHI; ++it) {
         int cj, ck;
@@ -569,21 +695,19 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
             const int h = rsub + RPI * (it - NOWN);
             ok = h < NDH;
             if (IS3D) {
-                if (h < PK) { cj = PJ; ck = h; } else { cj = h - PK; ck = PK; }
+                if (h < H * PK) { cj = PJ + h / PK; ck = h % PK; } else { cj = (h - H * PK) % PJ; ck = PK + (h - H * PK) / PJ; }
             } else {
-                cj = PJ; ck = 0;
+                cj = PJ + h; ck = 0;
             }
         }
         const int jq = j0 + cj, kq = k0 + ck;
         ok = ok && jq < NJ && kq < NK;
-        const int b = 1 + e - jq - kq;
-        ipb[it] = ok ? b : -(1 << 29);  // fails the range test below forever
-        const uint32_t rb = ((uint32_t)(rk ? NK - 1 - kq : kq) * NJ + (rj ? NJ - 1 - jq : jq)) * NF;
-        abase[it] = rb + (uint32_t)(rf ? NF - 1 - b : b);
-        lrow[it] = (IS3D ? (ck + 1) * RJ + cj + 1 : cj + 1) * RS + e + 2;
+        const int b = H + e - jq - kq;
+        ipb[it] = ok ? b : -(1 << 29);  // fails the range test forever
+        abase[it] = nat_row(jq, kq) + (uint32_t)(rf ? NF - 1 - b : b);
+        lrow[it] = lds_row(cj, ck) + e + 2 * H;
     }
-    // upwind halo: one (column, level) per thread and pass; levels L0-1 .. L0+C-2 <-> tile q = 0..C-1
-    constexpr int NUPI = (NUP * C + NT - 1) / NT;
+    // upwind halo passes: levels L0-1+e (tile q = e + H - 1), every level <= L0+C-2 is published
     int uipb[NUPI];
     uint32_t uabase[NUPI];
     int ulrow[NUPI];
@@ -593,17 +717,45 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         int cj, ck;
         bool ok = h < NUP;
         if (IS3D) {
-            if (h < PK) { cj = -1; ck = h; } else { cj = h - PK; ck = -1; }
+            if (h < H * PK) { cj = -1 - h / PK; ck = h % PK; } else { cj = (h - H * PK) % PJ; ck = -1 - (h - H * PK) / PJ; }
         } else {
-            cj = -1; ck = 0;
+            cj = -1 - h; ck = 0;
         }
         const int jq = j0 + cj, kq = k0 + ck;
         ok = ok && jq >= 0 && jq < NJ && kq >= 0 && kq < NK;
         const int b = -1 + e - jq - kq;
         uipb[it] = ok ? b : -(1 << 29);
-        const uint32_t rb = ((uint32_t)(rk ? NK - 1 - kq : kq) * NJ + (rj ? NJ - 1 - jq : jq)) * NF;
-        uabase[it] = rb + (uint32_t)(rf ? NF - 1 - b : b);
-        ulrow[it] = (h < NUP) ? (IS3D ? (ck + 1) * RJ + cj + 1 : cj + 1) * RS + e : -1;
+        uabase[it] = nat_row(jq >= 0 ? jq : 0, kq >= 0 ? kq : 0) + (uint32_t)(rf ? NF - 1 - b : b);
+        ulrow[it] = (h < NUP) ? lds_row(cj, ck) + e + H - 1 : -1;
+    }
+    // H == 2 only: the entries the uniform windows miss -- level L0+1 (q = 3) of the downwind
+    // columns at distance 1 (read at q+1 by the last column and at q+2 by the one before), and
+    // level L0-2 (q = 0) of BOTH upwind columns (column -1 is read at q-2 by the second column)
+    int xipb = -(1 << 29), xlrow = -1;
+    uint32_t xabase = 0;
+    bool x_up = false;
+    if (H == 2) {
+        constexpr int NX1 = IS3D ? (PJ + PK) : 1;
+        static_assert(H != 2 || 3 * NX1 <= NT, "extras fit one pass");
+        if (tid < 3 * NX1) {
+            const bool up = tid >= NX1;
+            const int dist = tid >= 2 * NX1 ? 2 : 1;   // upwind: distance 1 or 2; downwind: 1
+            const int h = tid % NX1;
+            int cj, ck;
+            if (IS3D) {
+                if (h < PK) { cj = up ? -dist : PJ; ck = h; } else { cj = h - PK; ck = up ? -dist : PK; }
+            } else {
+                cj = up ? -dist : PJ; ck = 0;
+            }
+            const int jq = j0 + cj, kq = k0 + ck;
+            const bool ok = jq >= 0 && jq < NJ && kq >= 0 && kq < NK;
+            const int lev = up ? -2 : 1;               // level relative to L0
+            const int b = lev - jq - kq;
+            xipb = ok ? b : -(1 << 29);
+            xabase = nat_row(jq >= 0 ? jq : 0, kq >= 0 ? kq : 0) + (uint32_t)(rf ? NF - 1 - b : b);
+            xlrow = lds_row(cj, ck) + lev + H;
+            x_up = up;
+        }
     }
 
     // chunk starts are congruent to m = TJ+TK modulo C: an upwind patch then finishes exactly the
@@ -612,21 +764,21 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     int Lc = Ls - (((Ls - m) % C + C) % C);
 
     // static inputs of a chunk starting at level L: slowness of the own column (levels L..L+C-1)
-    // and the not-yet-swept values at levels L+1..L+C of the own and downwind-halo columns
+    // and the not-yet-swept values at levels L+H..L+C+H-1 of the own and downwind-halo columns
     T sv[C], tv[NOWN + NHI];
     auto issue_static = [&](int L) {
-        const int qoff = jp + kp - L + 1;
-        const int qa = col_ok ? (qoff > 1 ? qoff : 1) : C + 1;
-        const int qb = qoff + NF - 1 < C ? qoff + NF - 1 : C;
-        int x = L - kp;  // i' + j' at level L (q = 1)
+        const int eoff = jp + kp - L;  // e at which i' == 0
+        const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;
+        const int eb = eoff + NF - 1 < C - 1 ? eoff + NF - 1 : C - 1;
+        int x = L - kp;  // i' + j' at level L
         x = a.rev ? NF + NJ - 2 - x : x;
         x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
         x = x < 0 ? x + M : x;
 #pragma unroll
-        for (int q = 1; q <= C; ++q) {
+        for (int q = 0; q < C; ++q) {
             T v = 0;
-            if (q >= qa && q <= qb) v = Sg[sbase + (size_t)x * NJ];
-            sv[q - 1] = v;
+            if (q >= ea && q <= eb) v = Sg[sbase + (size_t)x * NJ];
+            sv[q] = v;
             if (a.rev) { x = x == 0 ? M - 1 : x - 1; } else { x = x + 1 == M ? 0 : x + 1; }
         }
         const int sL = sf * L;
@@ -647,30 +799,33 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     // natural J / K extent of the read set (own + halo columns), fixed for the whole patch
     int rs_jlo, rs_jhi, rs_klo, rs_khi;
     {
-        const int ja = j0 - 1 < 0 ? 0 : j0 - 1, jb = jmaxp + 1 > NJ - 1 ? NJ - 1 : jmaxp + 1;
-        const int ka = k0 - 1 < 0 ? 0 : k0 - 1, kb = kmaxp + 1 > NK - 1 ? NK - 1 : kmaxp + 1;
+        const int ja = j0 - H < 0 ? 0 : j0 - H, jb = jmaxp + H > NJ - 1 ? NJ - 1 : jmaxp + H;
+        const int ka = k0 - H < 0 ? 0 : k0 - H, kb = kmaxp + H > NK - 1 ? NK - 1 : kmaxp + H;
         rs_jlo = (rj ? NJ - 1 - jb : ja) / FSM_BRICK;
         rs_jhi = (rj ? NJ - 1 - ja : jb) / FSM_BRICK;
         rs_klo = (rk ? NK - 1 - kb : ka) / FSM_BRICK;
         rs_khi = (rk ? NK - 1 - ka : kb) / FSM_BRICK;
     }
     const int rs_nj = rs_jhi - rs_jlo + 1, rs_nk = rs_khi - rs_klo + 1;
-    const int my_bj = (rj ? NJ - 1 - jp : jp) / FSM_BRICK - rs_jlo;
-    const int my_bk = (rk ? NK - 1 - kp : kp) / FSM_BRICK - rs_klo;
+    const int my_bj = jn / FSM_BRICK - rs_jlo;
+    const int my_bk = kn / FSM_BRICK - rs_klo;
     unsigned long long nevals = 0;
 
     T dec = 0;
-    T prev_last = INF;   // own column, level Lc-1 (result of the previous chunk)
-    T carry = INF;       // own column, level Lc (old value, loaded by the previous chunk)
-    bool have_prev = false;   // prev_last / carry are valid (the previous chunk was evaluated)
+    // own column carried from the previous chunk: results at levels L0-H..L0-1, then the old values
+    // at levels L0..L0+H-1
+    T carry[2 * H];
+#pragma unroll
+    for (int q = 0; q < 2 * H; ++q) carry[q] = INF;
+    bool have_prev = false;   // carry[] is valid (the previous chunk was evaluated)
     bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
     if (!SKIP) { issue_static(Lc); pref_for = Lc; }
     for (; Lc <= Le; Lc += C) {
         const int L0 = Lc;
-        const int qoff = jp + kp - L0 + 1;
-        const int qa = col_ok ? (qoff > 1 ? qoff : 1) : C + 1;
-        const int qb = qoff + NF - 1 < C ? qoff + NF - 1 : C;
+        const int eoff = jp + kp - L0;
+        const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;       // active levels e = ea..eb
+        const int eb = eoff + NF - 1 < C - 1 ? eoff + NF - 1 : C - 1;
         FSM_PROF_MARK(0)
 
         // (1) wait until both upwind patches have published every level <= L0+C-2
@@ -695,7 +850,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         // (1b) read set of this chunk in bricks: F range from the levels, J/K from the patch
         int rs_flo, rs_nf;
         {
-            int ia = L0 - 1 - jmaxp - kmaxp, ib = L0 + C - j0 - k0;
+            int ia = L0 - H - jmaxp - kmaxp, ib = L0 + C - 1 + H - j0 - k0;
             ia = ia < 0 ? 0 : ia;
             ib = ib > NF - 1 ? NF - 1 : ib;
             rs_flo = (rf ? NF - 1 - ib : ia) / FSM_BRICK;
@@ -740,7 +895,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
             continue;
         }
         if (pref_for != L0) issue_static(L0);
-        nevals += (qb >= qa) ? (unsigned)(qb - qa + 1) : 0u;
+        nevals += (eb >= ea) ? (unsigned)(eb - ea + 1) : 0u;
 
         // (2) upwind halo columns: fresh from HBM with sc1 loads (bypass L1)
         T uv[NUPI];
@@ -750,27 +905,34 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
             if ((unsigned)(L0 + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * L0));
             uv[it] = v;
         }
-        // (3) static part (prefetched) into LDS: levels L0+1..L0+C of own + downwind halo columns;
-        //     own column q = 0 / q = 1 come from the previous chunk (result / old value)
+        T xv = INF;
+        if (H == 2 && (unsigned)(L0 + xipb) < (unsigned)NF) {
+            const T* src = Tg + (xabase + sf * L0);
+            xv = x_up ? ld_sc1(src) : *src;
+        }
+        // (3) static part (prefetched) into LDS: levels L0+H..L0+C+H-1 of own + downwind halo columns;
+        //     own column q < 2H comes from the previous chunk (H results, H old values)
 #pragma unroll
         for (int it = 0; it < NOWN + NHI; ++it)
             if (it < NOWN || rsub + RPI * (it - NOWN) < NDH) Tt[lrow[it]] = tv[it];
         if (!have_prev) {
-            // first chunk of the patch, or the previous chunk was skipped: levels L0-1 and L0 of the
+            // first chunk of the patch, or the previous chunk was skipped: levels L0-H..L0+H-1 of the
             // own column come from HBM (they are current: a skipped chunk changes nothing)
-            T v0 = INF, v1 = INF;
-            const int ip = L0 - jp - kp;
-            if (col_ok && (unsigned)ip < (unsigned)NF) v1 = Tg[colbase + (rf ? NF - 1 - ip : ip)];
-            if (col_ok && (unsigned)(ip - 1) < (unsigned)NF) v0 = Tg[colbase + (rf ? NF - ip : ip - 1)];
-            prev_last = v0;
-            carry = v1;
+#pragma unroll
+            for (int q = 0; q < 2 * H; ++q) {
+                const int ip = L0 - H + q - jp - kp;
+                T v = INF;
+                if (col_ok && (unsigned)ip < (unsigned)NF) v = Tg[colbase + (rf ? NF - 1 - ip : ip)];
+                carry[q] = v;
+            }
             have_prev = true;
         }
-        Tt[row * RS] = prev_last;
-        Tt[row * RS + 1] = carry;
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q) Tt[row * RS + q] = carry[q];
 #pragma unroll
         for (int it = 0; it < NUPI; ++it)
             if (ulrow[it] >= 0) Tt[ulrow[it]] = uv[it];
+        if (H == 2 && xlrow >= 0) Tt[xlrow] = xv;
         __syncthreads();
 
         bool near_src;
@@ -785,10 +947,10 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         }
 
         T own[NQ];
-        own[0] = prev_last;
-        own[1] = carry;
 #pragma unroll
-        for (int q = 2; q < NQ; ++q) own[q] = Tt[row * RS + q];
+        for (int q = 0; q < 2 * H; ++q) own[q] = carry[q];
+#pragma unroll
+        for (int q = 2 * H; q < NQ; ++q) own[q] = Tt[row * RS + q];
         T sc[C];
 #pragma unroll
         for (int q = 0; q < C; ++q) sc[q] = sv[q];
@@ -797,50 +959,79 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         // (4) prefetch the next chunk's static inputs; they land during the march
         if (Lc + C <= Le) { issue_static(Lc + C); pref_for = Lc + C; }
 
-        // brick (along F) of this thread's node at level q: it crosses at most one brick border
-        // inside the chunk, at q = q_split
-        int my_bf0, q_split;
+        // brick (along F) of this thread's node at level e: it crosses at most one brick border
+        // inside the chunk, at e = e_split
+        int my_bf0, e_split;
         {
-            const int ip1 = L0 - jp - kp;                 // i' at q = 1
-            const int i1 = rf ? NF - 1 - ip1 : ip1;       // natural i at q = 1; moves by sf per level
-            const int b0 = (i1 >= 0 ? i1 : 0) / FSM_BRICK;
+            const int ip0 = L0 - jp - kp;                 // i' at e = 0
+            const int i0n = rf ? NF - 1 - ip0 : ip0;      // natural i at e = 0; moves by sf per level
+            const int b0 = (i0n >= 0 ? i0n : 0) / FSM_BRICK;
             my_bf0 = b0 - rs_flo;
-            // first q at which the brick index changes
-            const int rem = rf ? (i1 - b0 * FSM_BRICK) + 1 : (b0 + 1) * FSM_BRICK - i1;
-            q_split = 1 + rem;
+            const int rem = rf ? (i0n - b0 * FSM_BRICK) + 1 : (b0 + 1) * FSM_BRICK - i0n;
+            e_split = rem;
         }
         bool chg_a = false, chg_b = false;
         bool changed = false;
 #pragma unroll
-        for (int q = 1; q <= C; ++q) {
-            bool active = (q >= qa) & (q <= qb);
+        for (int ee = 0; ee < C; ++ee) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int q = ee + H;
+            bool active = (ee >= ea) & (ee <= eb);
+            const int ip = L0 + ee - jp - kp;
             if (near_src && active) {
-                const int ip = L0 - 1 + q - jp - kp;
                 const uint32_t n = colbase + (rf ? NF - 1 - ip : ip);
                 active = !((Fz[n >> 5] >> (n & 31)) & 1u);
             }
             const T c = own[q];
-            const T af = vmin(own[q - 1], own[q + 1]);
-            const T aj = vmin(Tt[(row - 1) * RS + q - 1], Tt[(row + 1) * RS + q + 1]);
             T t;
-            if (IS3D) {
-                const T ak = vmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
-                t = update3(ak, aj, af, sc[q - 1], dx, active);
+            if (H == 1) {
+                const T af = vmin(own[q - 1], own[q + 1]);
+                const T aj = vmin(Tt[(row - 1) * RS + q - 1], Tt[(row + 1) * RS + q + 1]);
+                if (IS3D) {
+                    const T ak = vmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
+                    t = update3(ak, aj, af, sc[ee], dx, active);
+                } else {
+                    t = variant == 1 ? update2(aj, af, sc[ee], dx) : update2_xz(aj, af, sc[ee], dx, dz);
+                }
             } else {
-                t = variant == 1 ? update2(aj, af, sc[q - 1], dx) : update2_xz(aj, af, sc[q - 1], dx, dz);
+                // WENO3: five-point stencils in NATURAL index order along every axis.  Oriented
+                // offset -d is natural offset -d when the axis is swept upwards, +d otherwise.
+                constexpr int HH = H == 2 ? 2 : 1;  // (keeps the H == 1 instantiation in bounds)
+                const T fm1 = own[q - 1], fp1 = own[q + 1];
+                const T fm2 = own[q - HH], fp2 = own[q + HH];
+                const T jm1 = Tt[(row - 1) * RS + q - 1], jp1 = Tt[(row + 1) * RS + q + 1];
+                const T jm2 = Tt[(row - HH) * RS + q - HH], jp2 = Tt[(row + HH) * RS + q + HH];
+                const int in = rf ? NF - 1 - ip : ip;
+                const T hF = IS3D ? dx : (variant == 2 ? dz : dx);
+                const T aF = rf ? weno_axis(fp2, fp1, c, fm1, fm2, in, NF - 1, hF)
+                                : weno_axis(fm2, fm1, c, fp1, fp2, in, NF - 1, hF);
+                const T aJ = rj ? weno_axis(jp2, jp1, c, jm1, jm2, jn, NJ - 1, dx)
+                                : weno_axis(jm2, jm1, c, jp1, jp2, jn, NJ - 1, dx);
+                if (IS3D) {
+                    const T km1 = Tt[(row - RJ) * RS + q - 1], kp1 = Tt[(row + RJ) * RS + q + 1];
+                    const T km2 = Tt[(row - HH * RJ) * RS + q - HH], kp2 = Tt[(row + HH * RJ) * RS + q + HH];
+                    const T aK = rk ? weno_axis(kp2, kp1, c, km1, km2, kn, NK - 1, dx)
+                                    : weno_axis(km2, km1, c, kp1, kp2, kn, NK - 1, dx);
+                    // a1 <- K axis, a2 <- J axis, a3 <- F axis, as in the reference (k, j, i)
+                    t = solve3_literal(aK, aJ, aF, sc[ee] * dx);
+                } else {
+                    // 2-D: a = x axis (J here), b = z axis (F here)
+                    t = variant == 1 ? update2(aJ, aF, sc[ee], dx) : update2_xz(aJ, aF, sc[ee], dx, dz);
+                }
             }
             const bool acc = active & (t < c);
             const T nv = acc ? t : c;
             dec += acc ? c - t : (T)0;
             changed |= acc;
-            chg_a |= acc & (q < q_split);
-            chg_b |= acc & (q >= q_split);
+            chg_a |= acc & (ee < e_split);
+            chg_b |= acc & (ee >= e_split);
             own[q] = nv;
             Tt[row * RS + q] = nv;
             __syncthreads();
         }
-        prev_last = own[C];
-        carry = own[C + 1];
+#pragma unroll
+        for (int q = 0; q < 2 * H; ++q) carry[q] = own[C + q];
         if (SKIP) {
             // mark the bricks this thread changed (LDS flags, then one atomicMax per brick)
             const int base = (my_bk * rs_nj + my_bj) * rs_nf;
@@ -851,21 +1042,21 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         FSM_PROF_MARK(3)
         if (a.prof && tid == 0) atomicAdd(a.prof + 7, 1ull);
 
-        // (5) write back levels L0..L0+C-1 (tile q = 1..C); the columns a downstream patch reads
+        // (5) write back levels L0..L0+C-1 (tile q = H..H+C-1); the columns a downstream patch reads
         //     go out write-through (sc1)
         const bool any_changed = __syncthreads_or(changed);
         quiet = !any_changed;
         if (any_changed) {
 #pragma unroll
             for (int it = 0; it < NOWN; ++it) {
-                // same streaming map, one level earlier: level L0+e  <->  i' = L0 + ipb - 1
-                const int ipm = L0 + ipb[it] - 1;
+                // same streaming map, H levels earlier: level L0+e  <->  i' = L0 + ipb - H
+                const int ipm = L0 + ipb[it] - H;
                 if ((unsigned)ipm < (unsigned)NF) {
                     const int rid = rsub + RPI * it;
                     const int cj = rid % PJ, ck = rid / PJ;
-                    T* dst = Tg + (abase[it] + sf * (L0 - 1));
-                    const T v = Tt[lrow[it] - 1];
-                    if (cj == PJ - 1 || (IS3D && ck == PK - 1)) st_sc1(dst, v); else *dst = v;
+                    T* dst = Tg + (abase[it] + sf * (L0 - H));
+                    const T v = Tt[lrow[it] - H];
+                    if (cj >= PJ - H || (IS3D && ck >= PK - H)) st_sc1(dst, v); else *dst = v;
                 }
             }
         }

@@ -10,9 +10,10 @@ and error behaviour) for the fast-sweeping path:
   raytrace                rgrid.pyx:828-1199      (2-D) rgrid.pyx:3804-4143
   get_grid_traveltimes    rgrid.pyx:410-435       (2-D) rgrid.pyx:3102-3127
 
-What is not on the FSM hot path raises NotImplementedError (SPM/DSPM, compute_L/compute_M,
-return_rays) -- and so do weno=True and tt_from_rp=True until those rows of SURVEY.md
-section 8(f) are built.  There is no CPU fallback.
+weno=True (the reference's default: first-order sweeps, then third-order WENO sweeps) is
+supported.  What is not on the FSM hot path raises NotImplementedError (SPM/DSPM,
+compute_L/compute_M, return_rays) -- and so does tt_from_rp=True until that row of SURVEY.md
+section 8(f) is built.  There is no CPU fallback.
 """
 import ctypes as C
 
@@ -83,6 +84,12 @@ class _GridBase:
         a, b = C.c_int(), C.c_int()
         _lib.check(self._lib.ttcr_fsm_get_niter(self._h, int(thread_no), C.byref(a), C.byref(b)))
         return a.value
+
+    def get_niterw(self, thread_no=0):
+        """WENO sweep-iterations of the last solve in a slot (get_niterw, ttcr/Grid3Drnfs.h:57)."""
+        a, b = C.c_int(), C.c_int()
+        _lib.check(self._lib.ttcr_fsm_get_niter(self._h, int(thread_no), C.byref(a), C.byref(b)))
+        return b.value
 
     def timing(self):
         """HIP-event timing of the last raytrace call (dict)."""
@@ -212,7 +219,8 @@ class _Grid3d(_GridBase):
              eps=1.e-5, maxit=50, weno=1, nsnx=5, nsny=5, nsnz=5, n_secondary=2, n_tertiary=2,
              radius_factor_tertiary=3.0, translate_grid=False, fsm_gpu=False)
 
-    x, y, z are NODE coordinates (cells = size-1).  fsm_gpu is accepted and ignored: this
+    x, y, z are NODE coordinates (cells = size-1).  weno=1 (default) runs the two-stage solver
+    (first-order sweeps, then WENO3 sweeps).  fsm_gpu is accepted and ignored: this
     backend always runs on the GPU.  `device` (extra keyword) selects the HIP device.
     """
     _ndim = 3
