@@ -121,3 +121,59 @@ def test_hip_weno_matches_oracle_multi_patch(oracle, kind):
         o = oracle.solve2d(np.float32, nc, r["grid"].dx, r["grid"].dz, c["origin"], s, c["src"], rcv=c["rcv"], weno=True)
     assert (r["niter"], r["niterw"]) == (o["niter"], o["niterw"])
     np.testing.assert_array_equal(r["tt"], o["tt"])
+
+
+@pytest.mark.parametrize("weno", [0, 1], ids=["first-order", "weno3"])
+@pytest.mark.parametrize("n_threads", [2, 3])
+def test_hip_multi_source_batches(oracle, weno, n_threads):
+    """Several sources solved concurrently (slots = the reference's threads; two sources of a slot
+    group are marched together from an interleaved field): every slot's field, iteration counts and
+    receiver values must equal the single-source solves of the oracle."""
+    import ttcr_amd
+
+    rng = np.random.default_rng(17)
+    nn = (41, 37, 29)
+    dx = 0.5
+    x, y, z = (np.arange(n) * dx for n in nn)
+    s = rng.uniform(0.3, 1.0, nn)
+    srcs = np.array([[3.3, 4.1, 5.7], [10.0, 9.0, 2.0], [19.9, 0.1, 13.9], [0.0, 18.0, 14.0], [7.7, 7.7, 7.7]])
+    rcv1 = np.array([[1.0, 2.0, 3.0], [20.0, 18.0, 14.0], [5.5, 0.0, 7.25]])
+    g = ttcr_amd.Grid3d(x, y, z, n_threads=n_threads, cell_slowness=0, method="FSM", tt_from_rp=0, weno=weno,
+                        maxit=12, dtype=np.float32)
+    source = np.repeat(srcs, len(rcv1), axis=0)
+    rcv = np.tile(rcv1, (len(srcs), 1))
+    tt = g.raytrace(source, rcv, slowness=s)
+    want = []
+    outs = []
+    for p in srcs:
+        o = oracle.solve3d(np.float32, tuple(n - 1 for n in nn), g.dx, (0, 0, 0), s.flatten("F"), [p], rcv=rcv1,
+                           weno=bool(weno), maxit=12)
+        outs.append(o)
+        want.append(o["tt_rcv"])
+    np.testing.assert_array_equal(tt, np.concatenate(want))
+    # block distribution of the 5 sources over the slots (get_blk_size): slot b holds the LAST source of its block
+    from ttcr_amd.dist import blk_sizes
+    sizes = blk_sizes(len(srcs), n_threads)
+    last = np.cumsum(sizes) - 1
+    for slot, n in enumerate(last):
+        np.testing.assert_array_equal(g.get_grid_traveltimes(slot).flatten("F"), outs[n]["tt"])
+        assert g.get_niter(slot) == outs[n]["niter"] and g.get_niterw(slot) == outs[n]["niterw"]
+
+
+def test_hip_multi_source_2d(oracle):
+    import ttcr_amd
+
+    rng = np.random.default_rng(23)
+    nn = (150, 70)
+    x, z = np.arange(nn[0]) * 0.2, np.arange(nn[1]) * 0.2
+    s = rng.uniform(0.3, 1.0, nn)
+    srcs = np.array([[3.3, 4.1], [10.0, 9.0], [29.0, 0.1], [0.0, 13.0]])
+    rcv1 = np.array([[1.0, 2.0], [29.8, 13.8]])
+    g = ttcr_amd.Grid2d(x, z, n_threads=4, cell_slowness=0, method="FSM", weno=1, maxit=15, dtype=np.float64)
+    tt = g.raytrace(np.repeat(srcs, 2, axis=0), np.tile(rcv1, (4, 1)), slowness=s)
+    for n, p in enumerate(srcs):
+        o = oracle.solve2d(np.float64, (nn[0] - 1, nn[1] - 1), g.dx, g.dz, (0, 0), s.ravel(), [p], rcv=rcv1, weno=True,
+                           maxit=15)
+        np.testing.assert_array_equal(tt[2 * n:2 * n + 2], o["tt_rcv"])
+        np.testing.assert_array_equal(g.get_grid_traveltimes(n).ravel(), o["tt"])
+        assert (g.get_niter(n), g.get_niterw(n)) == (o["niter"], o["niterw"])

@@ -115,10 +115,12 @@ class GridT : public GridBase {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
+    DevBuf<T> d_gather;      // scratch for de-interleaving one field
     DevBuf<T> d_ssh;         // sheared copies of the node slowness, one per direction family
     size_t ssh_stride = 0;   // elements per copy: NK * M * NJ
     DevBuf<uint32_t> d_mask;
-    DevBuf<int> d_bbox, d_slots;
+    DevBuf<int> d_bbox, d_slots, d_lmask;
+    int* h_lmask = nullptr;  // pinned
     DevBuf<uint32_t> d_tiles;            // per launch w: the patches that have nodes in it
     std::vector<int> tile_off, tile_cnt;  // offsets / counts into d_tiles
     DevBuf<double> d_change;
@@ -185,11 +187,15 @@ class GridT : public GridBase {
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
         d_s.reserve(n_nodes);
-        d_tt.reserve(n_nodes * (size_t)n_slots);
+        NS = n_slots >= 2 ? 2 : 1;
+        if (const char* e = std::getenv("TTCR_FSM_PAIR")) if (std::atoi(e) == 0) NS = 1;
+        d_tt.reserve(n_nodes * (size_t)n_groups() * NS);
         mask_words = (n_nodes + 31) / 32;
         d_mask.reserve(mask_words * (size_t)n_slots);
         d_bbox.reserve(6 * (size_t)n_slots);
         d_slots.reserve(n_slots);
+        d_lmask.reserve(n_slots);
+        HIP_CHECK(hipHostMalloc((void**)&h_lmask, sizeof(int) * n_slots));
         d_change.reserve(n_slots);
         if (std::getenv("TTCR_FSM_PROF")) {
             d_prof.reserve(8);
@@ -201,7 +207,7 @@ class GridT : public GridBase {
         *h_abort = 0;
         HIP_CHECK(hipHostMalloc((void**)&h_iter, sizeof(int)));
         HIP_CHECK(hipHostMalloc((void**)&h_evals, sizeof(unsigned long long) * n_slots));
-        HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_slots * sizeof(T), stream));
+        HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_groups() * NS * sizeof(T), stream));
 
         if (dim == 3) {
             using C = TileCfg<T, 3>;
@@ -227,7 +233,7 @@ class GridT : public GridBase {
         nbj = (geom.NJ + FSM_BRICK - 1) / FSM_BRICK;
         nbk = (geom.NK + FSM_BRICK - 1) / FSM_BRICK;
         n_bricks = (size_t)nbf * nbj * nbk;
-        d_stamp.reserve(n_bricks * n_slots);
+        d_stamp.reserve(n_bricks * n_slots);  // one set per slot group is used
         d_iter.reserve(1);
         d_evals.reserve(n_slots);
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
@@ -249,11 +255,18 @@ class GridT : public GridBase {
 
     template <int DIM, int H>
     void launch_sweeps_persistent(int batch) {
+        if (NS == 2) launch_sweeps_persistent_ns<DIM, H, 2>(batch); else launch_sweeps_persistent_ns<DIM, H, 1>(batch);
+    }
+
+    template <int DIM, int H, int NSV>
+    void launch_sweeps_persistent_ns(int batch) {
         using C = TileCfg<T, DIM>;
         constexpr int CH = ChunkCfg<T, DIM>::C;
         PersistArgs<T> pa;
         SweepArgs<T>& a = pa.s;
         a.tt = d_tt.p;
+        a.ts = NS;
+        a.lmask = d_lmask.p;
         a.frozen = d_mask.p;
         a.bbox = d_bbox.p;
         a.change = d_change.p;
@@ -297,9 +310,9 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
             if (skip)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H><<<grid, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV><<<grid, block, 0, stream>>>(pa);
             else
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H><<<grid, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV><<<grid, block, 0, stream>>>(pa);
         }
         HIP_CHECK(hipGetLastError());
     }
@@ -337,6 +350,7 @@ class GridT : public GridBase {
         }
         if (h_change) (void)hipHostFree(h_change);
         if (h_slots) (void)hipHostFree(h_slots);
+        if (h_lmask) (void)hipHostFree(h_lmask);
         if (h_abort) (void)hipHostFree(h_abort);
         if (h_iter) (void)hipHostFree(h_iter);
         if (h_evals) (void)hipHostFree(h_evals);
@@ -393,13 +407,21 @@ class GridT : public GridBase {
         HIP_CHECK(hipSetDevice(device));
         check_slot(slot);
         if (n != n_nodes) throw ValueError("traveltime buffer has wrong size");
-        HIP_CHECK(hipMemcpyAsync(out, d_tt.p + (size_t)slot * n_nodes, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        if (NS == 1) {
+            HIP_CHECK(hipMemcpyAsync(out, tt_ptr(slot), n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        } else {
+            d_gather.reserve(n_nodes);
+            const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
+            fsm_gather_field<T><<<blocks, 256, 0, stream>>>(tt_ptr(slot), d_gather.p, n_nodes, NS);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(out, d_gather.p, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        }
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
     void* tt_device(int slot) override {
         check_slot(slot);
-        return d_tt.p + (size_t)slot * n_nodes;
+        return tt_ptr(slot);
     }
 
     void check_slot(int slot) const {
@@ -503,6 +525,8 @@ class GridT : public GridBase {
         using C = TileCfg<T, DIM>;
         SweepArgs<T> a;
         a.tt = d_tt.p;
+        a.ts = NS;
+        a.lmask = nullptr;
         a.frozen = d_mask.p;
         a.bbox = d_bbox.p;
         a.change = d_change.p;
@@ -540,6 +564,14 @@ class GridT : public GridBase {
         }
         HIP_CHECK(hipGetLastError());
     }
+
+    // Interleaved field layout: traveltime fields are stored in groups of NS sources,
+    // T[group][node][NS] (NS = 2 when the grid has at least two slots).  The persistent kernel then
+    // marches the NS sources of a group together: one address computation, one 8-byte load/store
+    // and one LDS access serve both, and the per-level bookkeeping is shared.
+    int NS = 1;
+    int n_groups() const { return (n_slots + NS - 1) / NS; }
+    T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
 
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
     bool persistent_now() const { return mode == 1 || stage == 1; }
@@ -601,14 +633,17 @@ class GridT : public GridBase {
         }
         d_pts.reserve(std::max<size_t>(tot_pts, 1));
         HIP_CHECK(hipMemcpyAsync(d_pts.p, pts.data(), pts.size() * sizeof(InitPoint<T>), hipMemcpyHostToDevice, stream));
+        for (int b = 0; b < nb; ++b)  // dirty-brick stamps: one set per slot group, "never changed"
+            HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)(slot_ids[b] / NS) * n_bricks, 0xFF, n_bricks * sizeof(int), stream));
         for (int b = 0; b < nb; ++b) {
             const int slot = slot_ids[b];
-            T* tt = d_tt.p + (size_t)slot * n_nodes;
+            T* tt = tt_ptr(slot);
             const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
-            fsm_fill<T><<<blocks, 256, 0, stream>>>(tt, n_nodes, real_traits<T>::max());
+            fsm_fill<T><<<blocks, 256, 0, stream>>>(tt, n_nodes, real_traits<T>::max(), NS);
             HIP_CHECK(hipMemsetAsync(d_mask.p + (size_t)slot * mask_words, 0, mask_words * sizeof(uint32_t), stream));
             InitArgs<T> ia;
             ia.tt = tt;
+            ia.ts = NS;
             ia.slowness = d_s.p;
             ia.frozen = d_mask.p + (size_t)slot * mask_words;
             ia.bbox = d_bbox.p + 6 * (size_t)slot;
@@ -620,8 +655,7 @@ class GridT : public GridBase {
             ia.nnz = ncz + 1;
             ia.dx = dx; ia.dz = dz; ia.xmin = xmin; ia.ymin = ymin; ia.zmin = zmin;
             ia.dim = dim;
-            HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)slot * n_bricks, 0xFF, n_bricks * sizeof(int), stream));
-            ia.stamp = d_stamp.p + (size_t)slot * n_bricks;
+            ia.stamp = d_stamp.p + (size_t)(slot / NS) * n_bricks;
             ia.nbf = nbf; ia.nbj = nbj; ia.nbk = nbk;
             fsm_init_source<T><<<1, 128, 0, stream>>>(ia);
             niter[slot] = 0;
@@ -642,13 +676,31 @@ class GridT : public GridBase {
         for (stage = 0; stage < (weno ? 2 : 1); ++stage) {
             std::vector<int> active(slot_ids);
             int it = 0;
+            // batch entries: slot groups for the persistent kernel (with a lane mask), slots otherwise
+            std::vector<int> groups;
+            for (int s2 : slot_ids)
+                if (groups.empty() || groups.back() != s2 / NS) groups.push_back(s2 / NS);
             while (!active.empty() && it < maxit) {
-                for (int b = 0; b < nb; ++b) h_slots[b] = b < (int)active.size() ? active[b] : -1;
-                HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * nb, hipMemcpyHostToDevice, stream));
+                int n_entries;
+                if (persistent_now()) {
+                    n_entries = (int)groups.size();
+                    for (int b = 0; b < n_entries; ++b) {
+                        int m2 = 0;
+                        for (int s2 : active)
+                            if (s2 / NS == groups[b]) m2 |= 1 << (s2 % NS);
+                        h_slots[b] = m2 ? groups[b] : -1;
+                        h_lmask[b] = m2;
+                    }
+                } else {
+                    n_entries = nb;
+                    for (int b = 0; b < nb; ++b) { h_slots[b] = b < (int)active.size() ? active[b] : -1; h_lmask[b] = 1; }
+                }
+                HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
+                HIP_CHECK(hipMemcpyAsync(d_lmask.p, h_lmask, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
                 *h_iter = it_total;
                 HIP_CHECK(hipMemcpyAsync(d_iter.p, h_iter, sizeof(int), hipMemcpyHostToDevice, stream));
-                run_iteration(nb);
+                run_iteration(n_entries);
                 HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
                 if (persistent_now()) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
@@ -672,7 +724,7 @@ class GridT : public GridBase {
             // the stamps of the first-order stage say nothing about the WENO stencil: start clean
             if (stage == 0 && weno && skip) {
                 for (int s2 : slot_ids)
-                    HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)s2 * n_bricks, 0x7f, n_bricks * sizeof(int), stream));
+                    HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)(s2 / NS) * n_bricks, 0x7f, n_bricks * sizeof(int), stream));
             }
         }
         const bool was_persistent = mode == 1 || weno;
@@ -722,12 +774,12 @@ class GridT : public GridBase {
         d_rx.reserve((size_t)nc * n);
         d_out.reserve(n);
         HIP_CHECK(hipMemcpyAsync(d_rx.p, p, sizeof(T) * nc * n, hipMemcpyHostToDevice, stream));
-        const T* tt = d_tt.p + (size_t)slot * n_nodes;
+        const T* tt = tt_ptr(slot);
         const int blocks = (n + 127) / 128;
         if (dim == 3)
-            fsm_interp3d<T><<<blocks, 128, 0, stream>>>(tt, d_rx.p, d_out.p, n, (int)ncx + 1, (int)ncy + 1, dx, xmin, ymin, zmin);
+            fsm_interp3d<T><<<blocks, 128, 0, stream>>>(tt, NS, d_rx.p, d_out.p, n, (int)ncx + 1, (int)ncy + 1, dx, xmin, ymin, zmin);
         else
-            fsm_interp2d<T><<<blocks, 128, 0, stream>>>(tt, d_rx.p, d_out.p, n, (int)ncz + 1, dx, dz, xmin, zmin);
+            fsm_interp2d<T><<<blocks, 128, 0, stream>>>(tt, NS, d_rx.p, d_out.p, n, (int)ncz + 1, dx, dz, xmin, zmin);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));

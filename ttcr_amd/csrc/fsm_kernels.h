@@ -227,7 +227,9 @@ struct SweepArgs {
     const uint32_t* frozen;   // [n_slots][mask_words] frozen bit per node
     const int* bbox;          // [n_slots][6] natural-index bounding box of frozen nodes (lo/hi per F,J,K)
     double* change;           // [n_slots] L1 decrease accumulated over the iteration
-    const int* slots;         // [batch] slot handled by blockIdx.z
+    const int* slots;         // [batch] slot (ts == 1) or slot group (ts == 2) handled by blockIdx.z / ticket
+    const int* lmask;         // [batch] ts == 2: bit l set = source l of the group is still being solved
+    int ts;                   // traveltime fields are interleaved in groups of ts sources: T[group][node][ts]
     const uint32_t* tiles;    // (TJ | TK<<16) of the patches that have nodes in launch w (blockIdx.x)
     SweepGeom g;
     uint32_t mask_words;
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
 
     const int slot = a.slots[blockIdx.z];
     if (slot < 0) return;  // source already converged: its blocks are masked out of the batch
-    T* __restrict__ Tg = a.tt + (size_t)slot * a.g.n_nodes;
+    // slot -> (group, lane) of the interleaved field layout
+    const int ts = a.ts;
+    T* __restrict__ Tg = a.tt + (size_t)(slot / ts) * a.g.n_nodes * ts + slot % ts;
     const T INF = real_traits<T>::inf();
     const int rf = a.rf, rj = a.rj, rk = a.rk;
 
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
                 const int i = rf ? NF - 1 - ip : ip;
                 const int j = rj ? NJ - 1 - jq : jq;
                 const int k = rk ? NK - 1 - kq : kq;
-                v = Tg[((uint32_t)k * NJ + j) * NF + i];
+                v = Tg[(size_t)(((uint32_t)k * NJ + j) * NF + i) * ts];
             }
             tv[it] = v;
         }
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
                 const int j = rj ? NJ - 1 - jq : jq;
                 const int k = rk ? NK - 1 - kq : kq;
                 const int r2 = IS3D ? (ck + 1) * RJ + cj + 1 : cj + 1;
-                Tg[((uint32_t)k * NJ + j) * NF + i] = Tt[r2 * RS + q + 1];
+                Tg[(size_t)(((uint32_t)k * NJ + j) * NF + i) * ts] = Tt[r2 * RS + q + 1];
             }
         }
         // wavefront (64-lane) reduction of the decrease, one atomic per wave
@@ -601,8 +605,50 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 }
 
 // ---- persistent sweep kernel, halo width H (1: first-order stage, 2: WENO3 stage) -----------
-template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H>
-__global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs<T> pa) {
+#ifndef FSM_MINW
+#define FSM_MINW 1
+#endif
+// NS sources of a slot group marched together (field layout T[group][node][NS]): one element type
+template <typename T, int NS> struct Pack;
+template <typename T> struct Pack<T, 1> { T v[1]; };
+template <typename T> struct alignas(2 * sizeof(T)) Pack<T, 2> { T v[2]; };
+
+template <typename T, int NS>
+__device__ __forceinline__ Pack<T, NS> pack_fill(T x) {
+    Pack<T, NS> p;
+#pragma unroll
+    for (int l = 0; l < NS; ++l) p.v[l] = x;
+    return p;
+}
+__device__ __forceinline__ Pack<float, 1> ld_sc1(const Pack<float, 1>* p) { Pack<float, 1> r; r.v[0] = ld_sc1(&p->v[0]); return r; }
+__device__ __forceinline__ Pack<double, 1> ld_sc1(const Pack<double, 1>* p) { Pack<double, 1> r; r.v[0] = ld_sc1(&p->v[0]); return r; }
+__device__ __forceinline__ Pack<float, 2> ld_sc1(const Pack<float, 2>* p) {
+    const unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Pack<float, 2> r;
+    r.v[0] = __uint_as_float((unsigned)u);
+    r.v[1] = __uint_as_float((unsigned)(u >> 32));
+    return r;
+}
+__device__ __forceinline__ Pack<double, 2> ld_sc1(const Pack<double, 2>* p) {
+    Pack<double, 2> r;
+    r.v[0] = ld_sc1(&p->v[0]);
+    r.v[1] = ld_sc1(&p->v[1]);
+    return r;
+}
+__device__ __forceinline__ void st_sc1(Pack<float, 1>* p, Pack<float, 1> x) { st_sc1(&p->v[0], x.v[0]); }
+__device__ __forceinline__ void st_sc1(Pack<double, 1>* p, Pack<double, 1> x) { st_sc1(&p->v[0], x.v[0]); }
+__device__ __forceinline__ void st_sc1(Pack<float, 2>* p, Pack<float, 2> x) {
+    const unsigned long long u = (unsigned long long)__float_as_uint(x.v[0]) | ((unsigned long long)__float_as_uint(x.v[1]) << 32);
+    __hip_atomic_store((unsigned long long*)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(Pack<double, 2>* p, Pack<double, 2> x) {
+    st_sc1(&p->v[0], x.v[0]);
+    st_sc1(&p->v[1], x.v[1]);
+}
+
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS>
+__global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
+    using P = Pack<T, NS>;
     constexpr int NT = PJ * PK;
     constexpr int RJ = PJ + 2 * H;
     constexpr int NROWS = IS3D ? RJ * (PK + 2 * H) : RJ;
@@ -618,7 +664,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     static_assert(NT % C == 0 && (IS3D || PK == 1) && C <= FSM_BRICK && (H == 1 || H == 2), "tile shape");
     const SweepArgs<T>& a = pa.s;
 
-    __shared__ T Tt[NROWS * RS];
+    __shared__ P Tt[NROWS * RS];
     __shared__ int s_ticket;
     __shared__ int s_skip;
     __shared__ int s_chg[64];  // bricks of the read set changed by this chunk
@@ -636,8 +682,8 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     const int npj = a.g.npj;
     int* prog = pa.sync + 2 + (size_t)z * pa.n_patches;
     int* my_prog = prog + (TK * npj + TJ);
-    const int slot = a.slots[z];
-    if (slot < 0) {  // converged source: nothing to do, but never leave a waiter hanging
+    const int grp = a.slots[z];   // slot (NS == 1) or slot group (NS == 2)
+    if (grp < 0) {  // converged source(s): nothing to do, but never leave a waiter hanging
         if (tid == 0) __hip_atomic_store(my_prog, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
@@ -648,8 +694,10 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     const int jmaxp = (j0 + PJ < NJ ? j0 + PJ : NJ) - 1;
     const int kmaxp = (k0 + PK < NK ? k0 + PK : NK) - 1;
     const int Ls = j0 + k0, Le = jmaxp + kmaxp + NF - 1;  // levels at which the patch has nodes
-    T* __restrict__ Tg = a.tt + (size_t)slot * a.g.n_nodes;
+    P* __restrict__ Tg = reinterpret_cast<P*>(a.tt) + (size_t)grp * a.g.n_nodes;
     const T INF = real_traits<T>::inf();
+    const P PINF = pack_fill<T, NS>(INF);
+    const int lm = NS == 1 ? 1 : a.lmask[z];   // sources of the group still being solved
     const int rf = a.rf, rj = a.rj, rk = a.rk;
     const int sf = rf ? -1 : 1;
 
@@ -663,8 +711,8 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     const uint32_t colbase = ((uint32_t)kn * NJ + jn) * NF;
     const T dx = a.dx, dz = a.dz;
     const int variant = a.variant;
-    const uint32_t* __restrict__ Fz = a.frozen + (size_t)slot * a.mask_words;
-    const int* bb = a.bbox + 6 * slot;
+    const uint32_t* __restrict__ Fz = a.frozen + (size_t)grp * NS * a.mask_words;   // + l * mask_words
+    const int* bb = a.bbox + 6 * grp * NS;                                           // + 6 * l
     const T* __restrict__ Sg = a.s_sheared;
     const int M = a.g.M;
     const size_t sbase = (size_t)(a.rev ? NK - 1 - kp : kp) * M * NJ + (a.rev ? NJ - 1 - jp : jp);
@@ -765,7 +813,8 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
 
     // static inputs of a chunk starting at level L: slowness of the own column (levels L..L+C-1)
     // and the not-yet-swept values at levels L+H..L+C+H-1 of the own and downwind-halo columns
-    T sv[C], tv[NOWN + NHI];
+    T sv[C];
+    P tv[NOWN + NHI];
     auto issue_static = [&](int L) {
         const int eoff = jp + kp - L;  // e at which i' == 0
         const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;
@@ -784,7 +833,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         const int sL = sf * L;
 #pragma unroll
         for (int it = 0; it < NOWN + NHI; ++it) {
-            T v = INF;
+            P v = PINF;
             if ((unsigned)(L + ipb[it]) < (unsigned)NF) v = Tg[abase[it] + sL];
             tv[it] = v;
         }
@@ -795,7 +844,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     // first iteration) the chunk would reproduce the values that are already there: skip it.
     const int sigma = SKIP ? pa.ndir * pa.iter_ptr[0] + pa.dir + 1 : 0;
     const int thr = sigma - pa.ndir > 0 ? sigma - pa.ndir : 0;
-    int* __restrict__ stamp = pa.stamp + (size_t)slot * pa.nbf * pa.nbj * pa.nbk;
+    int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;   // one stamp set per group
     // natural J / K extent of the read set (own + halo columns), fixed for the whole patch
     int rs_jlo, rs_jhi, rs_klo, rs_khi;
     {
@@ -811,12 +860,14 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
     const int my_bk = kn / FSM_BRICK - rs_klo;
     unsigned long long nevals = 0;
 
-    T dec = 0;
+    T dec[NS];
+#pragma unroll
+    for (int l = 0; l < NS; ++l) dec[l] = 0;
     // own column carried from the previous chunk: results at levels L0-H..L0-1, then the old values
     // at levels L0..L0+H-1
-    T carry[2 * H];
+    P carry[2 * H];
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) carry[q] = INF;
+    for (int q = 0; q < 2 * H; ++q) carry[q] = PINF;
     bool have_prev = false;   // carry[] is valid (the previous chunk was evaluated)
     bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
@@ -895,20 +946,20 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
             continue;
         }
         if (pref_for != L0) issue_static(L0);
-        nevals += (eb >= ea) ? (unsigned)(eb - ea + 1) : 0u;
+        nevals += (eb >= ea) ? (unsigned)(eb - ea + 1) : 0u;   // per active source, see the end
 
         // (2) upwind halo columns: fresh from HBM with sc1 loads (bypass L1)
-        T uv[NUPI];
+        P uv[NUPI];
 #pragma unroll
         for (int it = 0; it < NUPI; ++it) {
-            T v = INF;
+            P v = PINF;
             if ((unsigned)(L0 + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * L0));
             uv[it] = v;
         }
-        T xv = INF;
+        P xv = PINF;
         if (H == 2 && (unsigned)(L0 + xipb) < (unsigned)NF) {
-            const T* src = Tg + (xabase + sf * L0);
-            xv = x_up ? ld_sc1(src) : *src;
+            const P* src = Tg + (xabase + sf * L0);
+            if (x_up) xv = ld_sc1(src); else xv = *src;
         }
         // (3) static part (prefetched) into LDS: levels L0+H..L0+C+H-1 of own + downwind halo columns;
         //     own column q < 2H comes from the previous chunk (H results, H old values)
@@ -921,7 +972,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
 #pragma unroll
             for (int q = 0; q < 2 * H; ++q) {
                 const int ip = L0 - H + q - jp - kp;
-                T v = INF;
+                P v = PINF;
                 if (col_ok && (unsigned)ip < (unsigned)NF) v = Tg[colbase + (rf ? NF - 1 - ip : ip)];
                 carry[q] = v;
             }
@@ -935,7 +986,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         if (H == 2 && xlrow >= 0) Tt[xlrow] = xv;
         __syncthreads();
 
-        bool near_src;
+        bool near_src[NS];
         {
             int ilo = L0 - jmaxp - kmaxp, ihi = L0 + C - 1 - j0 - k0;
             ilo = ilo < 0 ? 0 : ilo;
@@ -943,10 +994,14 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
             const int flo = rf ? NF - 1 - ihi : ilo, fhi = rf ? NF - 1 - ilo : ihi;
             const int jlo = rj ? NJ - 1 - jmaxp : j0, jhi = rj ? NJ - 1 - j0 : jmaxp;
             const int klo = rk ? NK - 1 - kmaxp : k0, khi = rk ? NK - 1 - k0 : kmaxp;
-            near_src = !(fhi < bb[0] || flo > bb[1] || jhi < bb[2] || jlo > bb[3] || khi < bb[4] || klo > bb[5]);
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                const int* b6 = bb + 6 * l;
+                near_src[l] = !(fhi < b6[0] || flo > b6[1] || jhi < b6[2] || jlo > b6[3] || khi < b6[4] || klo > b6[5]);
+            }
         }
 
-        T own[NQ];
+        P own[NQ];
 #pragma unroll
         for (int q = 0; q < 2 * H; ++q) own[q] = carry[q];
 #pragma unroll
@@ -974,58 +1029,67 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         bool changed = false;
 #pragma unroll
         for (int ee = 0; ee < C; ++ee) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int q = ee + H;
-            bool active = (ee >= ea) & (ee <= eb);
+            const bool in_grid = (ee >= ea) & (ee <= eb);
             const int ip = L0 + ee - jp - kp;
-            if (near_src && active) {
-                const uint32_t n = colbase + (rf ? NF - 1 - ip : ip);
-                active = !((Fz[n >> 5] >> (n & 31)) & 1u);
+            const P c = own[q];
+            // neighbour values of both sources arrive with one LDS access each
+            const P fm1 = own[q - 1], fp1 = own[q + 1];
+            const P jm1 = Tt[(row - 1) * RS + q - 1], jp1 = Tt[(row + 1) * RS + q + 1];
+            P km1 = PINF, kp1 = PINF;
+            if (IS3D) { km1 = Tt[(row - RJ) * RS + q - 1]; kp1 = Tt[(row + RJ) * RS + q + 1]; }
+            constexpr int HH = H == 2 ? 2 : 1;  // (keeps the H == 1 instantiation in bounds)
+            P fm2 = PINF, fp2 = PINF, jm2 = PINF, jp2 = PINF, km2 = PINF, kp2 = PINF;
+            if (H == 2) {
+                fm2 = own[q - HH]; fp2 = own[q + HH];
+                jm2 = Tt[(row - HH) * RS + q - HH]; jp2 = Tt[(row + HH) * RS + q + HH];
+                if (IS3D) { km2 = Tt[(row - HH * RJ) * RS + q - HH]; kp2 = Tt[(row + HH * RJ) * RS + q + HH]; }
             }
-            const T c = own[q];
-            T t;
-            if (H == 1) {
-                const T af = vmin(own[q - 1], own[q + 1]);
-                const T aj = vmin(Tt[(row - 1) * RS + q - 1], Tt[(row + 1) * RS + q + 1]);
-                if (IS3D) {
-                    const T ak = vmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
-                    t = update3(ak, aj, af, sc[ee], dx, active);
-                } else {
-                    t = variant == 1 ? update2(aj, af, sc[ee], dx) : update2_xz(aj, af, sc[ee], dx, dz);
+            P nv;
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                bool active = in_grid & ((lm >> l) & 1);
+                if (near_src[l] && active) {
+                    const uint32_t n = colbase + (rf ? NF - 1 - ip : ip);
+                    active = !((Fz[(size_t)l * a.mask_words + (n >> 5)] >> (n & 31)) & 1u);
                 }
-            } else {
-                // WENO3: five-point stencils in NATURAL index order along every axis.  Oriented
-                // offset -d is natural offset -d when the axis is swept upwards, +d otherwise.
-                constexpr int HH = H == 2 ? 2 : 1;  // (keeps the H == 1 instantiation in bounds)
-                const T fm1 = own[q - 1], fp1 = own[q + 1];
-                const T fm2 = own[q - HH], fp2 = own[q + HH];
-                const T jm1 = Tt[(row - 1) * RS + q - 1], jp1 = Tt[(row + 1) * RS + q + 1];
-                const T jm2 = Tt[(row - HH) * RS + q - HH], jp2 = Tt[(row + HH) * RS + q + HH];
-                const int in = rf ? NF - 1 - ip : ip;
-                const T hF = IS3D ? dx : (variant == 2 ? dz : dx);
-                const T aF = rf ? weno_axis(fp2, fp1, c, fm1, fm2, in, NF - 1, hF)
-                                : weno_axis(fm2, fm1, c, fp1, fp2, in, NF - 1, hF);
-                const T aJ = rj ? weno_axis(jp2, jp1, c, jm1, jm2, jn, NJ - 1, dx)
-                                : weno_axis(jm2, jm1, c, jp1, jp2, jn, NJ - 1, dx);
-                if (IS3D) {
-                    const T km1 = Tt[(row - RJ) * RS + q - 1], kp1 = Tt[(row + RJ) * RS + q + 1];
-                    const T km2 = Tt[(row - HH * RJ) * RS + q - HH], kp2 = Tt[(row + HH * RJ) * RS + q + HH];
-                    const T aK = rk ? weno_axis(kp2, kp1, c, km1, km2, kn, NK - 1, dx)
-                                    : weno_axis(km2, km1, c, kp1, kp2, kn, NK - 1, dx);
-                    // a1 <- K axis, a2 <- J axis, a3 <- F axis, as in the reference (k, j, i)
-                    t = solve3_literal(aK, aJ, aF, sc[ee] * dx);
+                T t;
+                if (H == 1) {
+                    const T af = vmin(fm1.v[l], fp1.v[l]);
+                    const T aj = vmin(jm1.v[l], jp1.v[l]);
+                    if (IS3D) {
+                        const T ak = vmin(km1.v[l], kp1.v[l]);
+                        t = update3(ak, aj, af, sc[ee], dx, active);
+                    } else {
+                        t = variant == 1 ? update2(aj, af, sc[ee], dx) : update2_xz(aj, af, sc[ee], dx, dz);
+                    }
                 } else {
-                    // 2-D: a = x axis (J here), b = z axis (F here)
-                    t = variant == 1 ? update2(aJ, aF, sc[ee], dx) : update2_xz(aJ, aF, sc[ee], dx, dz);
+                    // WENO3: five-point stencils in NATURAL index order along every axis.  Oriented
+                    // offset -d is natural offset -d when the axis is swept upwards, +d otherwise.
+                    const int in = rf ? NF - 1 - ip : ip;
+                    const T hF = IS3D ? dx : (variant == 2 ? dz : dx);
+                    const T cc = c.v[l];
+                    const T aF = rf ? weno_axis(fp2.v[l], fp1.v[l], cc, fm1.v[l], fm2.v[l], in, NF - 1, hF)
+                                    : weno_axis(fm2.v[l], fm1.v[l], cc, fp1.v[l], fp2.v[l], in, NF - 1, hF);
+                    const T aJ = rj ? weno_axis(jp2.v[l], jp1.v[l], cc, jm1.v[l], jm2.v[l], jn, NJ - 1, dx)
+                                    : weno_axis(jm2.v[l], jm1.v[l], cc, jp1.v[l], jp2.v[l], jn, NJ - 1, dx);
+                    if (IS3D) {
+                        const T aK = rk ? weno_axis(kp2.v[l], kp1.v[l], cc, km1.v[l], km2.v[l], kn, NK - 1, dx)
+                                        : weno_axis(km2.v[l], km1.v[l], cc, kp1.v[l], kp2.v[l], kn, NK - 1, dx);
+                        // a1 <- K axis, a2 <- J axis, a3 <- F axis, as in the reference (k, j, i)
+                        t = solve3_literal(aK, aJ, aF, sc[ee] * dx);
+                    } else {
+                        // 2-D: a = x axis (J here), b = z axis (F here)
+                        t = variant == 1 ? update2(aJ, aF, sc[ee], dx) : update2_xz(aJ, aF, sc[ee], dx, dz);
+                    }
                 }
+                const bool acc = active & (t < c.v[l]);
+                nv.v[l] = acc ? t : c.v[l];
+                dec[l] += acc ? c.v[l] - t : (T)0;
+                changed |= acc;
+                chg_a |= acc & (ee < e_split);
+                chg_b |= acc & (ee >= e_split);
             }
-            const bool acc = active & (t < c);
-            const T nv = acc ? t : c;
-            dec += acc ? c - t : (T)0;
-            changed |= acc;
-            chg_a |= acc & (ee < e_split);
-            chg_b |= acc & (ee >= e_split);
             own[q] = nv;
             Tt[row * RS + q] = nv;
             __syncthreads();
@@ -1054,8 +1118,8 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
                 if ((unsigned)ipm < (unsigned)NF) {
                     const int rid = rsub + RPI * it;
                     const int cj = rid % PJ, ck = rid / PJ;
-                    T* dst = Tg + (abase[it] + sf * (L0 - H));
-                    const T v = Tt[lrow[it] - H];
+                    P* dst = Tg + (abase[it] + sf * (L0 - H));
+                    const P v = Tt[lrow[it] - H];
                     if (cj >= PJ - H || (IS3D && ck >= PK - H)) st_sc1(dst, v); else *dst = v;
                 }
             }
@@ -1079,21 +1143,30 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_persistent(const PersistArgs
         FSM_PROF_MARK(4)
     }
 
-    // L1 decrease of this unit: wavefront reduction, one atomic per wave
-    double accd = (double)dec;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
-    if ((tid & 63) == 0 && accd != 0.0) atomicAdd(a.change + slot, accd);
+    // L1 decrease of every source of the unit: wavefront reduction, one atomic per wave and source
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nevals += __shfl_down(nevals, off, 64);
-    if ((tid & 63) == 0 && nevals) atomicAdd(pa.evals + slot, nevals);
+#pragma unroll
+    for (int l = 0; l < NS; ++l) {
+        double accd = (double)dec[l];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
+        if ((tid & 63) == 0 && accd != 0.0) atomicAdd(a.change + grp * NS + l, accd);
+        if ((tid & 63) == 0 && nevals && ((lm >> l) & 1)) atomicAdd(pa.evals + grp * NS + l, nevals);
+    }
 }
 
 // ---- small kernels -------------------------------------------------------------------------
 
 template <typename T>
-__global__ void fsm_fill(T* p, size_t n, T v) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+__global__ void fsm_fill(T* p, size_t n, T v, int stride) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i * stride] = v;
+}
+
+// de-interleave one source's field for the host (getTT)
+template <typename T>
+__global__ void fsm_gather_field(const T* __restrict__ p, T* __restrict__ out, size_t n, int stride) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = p[i * stride];
 }
 
 // Grid3Drcfs::setSlowness (ttcr/Grid3Drcfs.h:88-171) / Grid2Drcfs::setSlowness
@@ -1172,7 +1245,8 @@ struct InitPoint {
 
 template <typename T>
 struct InitArgs {
-    T* tt;                 // slot field
+    T* tt;                 // slot field (element n at tt[n*ts])
+    int ts;
     const T* slowness;
     uint32_t* frozen;      // slot mask
     int* bbox;             // slot bbox (F,J,K lo/hi) -- written by thread 0
@@ -1201,7 +1275,7 @@ __global__ void fsm_init_source(const InitArgs<T> a) {
         const int nbox = a.dim == 3 ? w * w * w : w * w;
         if (p.on_node && tid == 0) {
             const size_t nn = a.dim == 3 ? ((size_t)p.k * a.nny + p.j) * a.nnx + p.i : (size_t)p.i * a.nnz + p.k;
-            a.tt[nn] = p.t0;
+            a.tt[nn * a.ts] = p.t0;
             atomicOr(&a.frozen[nn >> 5], 1u << (nn & 31));
         }
         __syncthreads();
@@ -1214,7 +1288,7 @@ __global__ void fsm_init_source(const InitArgs<T> a) {
                 const T x = node_coord(a.xmin, ii, a.dx), y = node_coord(a.ymin, jj, a.dx), z = node_coord(a.zmin, kk, a.dx);
                 const T d2 = (x - p.x) * (x - p.x) + (y - p.y) * (y - p.y) + (z - p.z) * (z - p.z);
                 const T d = (T)__builtin_sqrt((double)d2);  // == correctly rounded sqrt in T
-                a.tt[m] = p.t0 + d * a.slowness[m];
+                a.tt[m * a.ts] = p.t0 + d * a.slowness[m];
                 atomicOr(&a.frozen[m >> 5], 1u << (m & 31));
             } else {
                 const int ii = p.i + b0 + b / w, kk = p.k + b0 + b % w;  // kk: z index
@@ -1233,7 +1307,7 @@ __global__ void fsm_init_source(const InitArgs<T> a) {
                 } else {
                     tt = p.t0 + d * a.slowness[m];
                 }
-                a.tt[m] = tt;
+                a.tt[m * a.ts] = tt;
                 atomicOr(&a.frozen[m >> 5], 1u << (m & 31));
             }
         }
@@ -1268,7 +1342,7 @@ __global__ void fsm_init_source(const InitArgs<T> a) {
 
 // Receiver traveltimes: Grid3Drn::getTraveltime (ttcr/Grid3Drn.h:794-930)
 template <typename T>
-__global__ void fsm_interp3d(const T* __restrict__ Tn, const T* __restrict__ pts, T* __restrict__ out, int n,
+__global__ void fsm_interp3d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
                              int nnx, int nny, T dx, T xmin, T ymin, T zmin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -1282,7 +1356,7 @@ __global__ void fsm_interp3d(const T* __restrict__ Tn, const T* __restrict__ pts
     const bool onx = (double)ab(px - (xmin + (T)i * dx)) < small2;
     const bool ony = (double)ab(py - (ymin + (T)j * dy)) < small2;
     const bool onz = (double)ab(pz - (zmin + (T)k * dz)) < small2;
-#define TT(ii, jj, kk) Tn[((size_t)(kk) * nny + (jj)) * nnx + (ii)]
+#define TT(ii, jj, kk) Tn[(((size_t)(kk) * nny + (jj)) * nnx + (ii)) * ts]
     T tt;
     if (onx && ony && onz) {
         tt = TT(i, j, k);
@@ -1344,7 +1418,7 @@ __global__ void fsm_interp3d(const T* __restrict__ Tn, const T* __restrict__ pts
 
 // Grid2Drn::getTraveltime (ttcr/Grid2Drn.h:359-414)
 template <typename T>
-__global__ void fsm_interp2d(const T* __restrict__ Tn, const T* __restrict__ pts, T* __restrict__ out, int n,
+__global__ void fsm_interp2d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
                              int nnz, T dx, T dz, T xmin, T zmin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -1357,18 +1431,18 @@ __global__ void fsm_interp2d(const T* __restrict__ Tn, const T* __restrict__ pts
     const bool onz = (double)ab(pz - (zmin + (T)j * dz)) < small;
     T tt;
     if (onx && onz) {
-        tt = Tn[(size_t)i * nnz + j];
+        tt = Tn[((size_t)i * nnz + j) * ts];
     } else if (onx) {
-        T t1 = Tn[(size_t)i * nnz + j], t2 = Tn[(size_t)i * nnz + j + 1];
+        T t1 = Tn[((size_t)i * nnz + j) * ts], t2 = Tn[((size_t)i * nnz + j + 1) * ts];
         T w1 = (zmin + (T)(j + 1) * dz - pz) / dz, w2 = (pz - (zmin + (T)j * dz)) / dz;
         tt = t1 * w1 + t2 * w2;
     } else if (onz) {
-        T t1 = Tn[(size_t)i * nnz + j], t2 = Tn[(size_t)(i + 1) * nnz + j];
+        T t1 = Tn[((size_t)i * nnz + j) * ts], t2 = Tn[((size_t)(i + 1) * nnz + j) * ts];
         T w1 = (xmin + (T)(i + 1) * dx - px) / dx, w2 = (px - (xmin + (T)i * dx)) / dx;
         tt = t1 * w1 + t2 * w2;
     } else {
-        T t1 = Tn[(size_t)i * nnz + j], t2 = Tn[(size_t)(i + 1) * nnz + j];
-        T t3 = Tn[(size_t)i * nnz + j + 1], t4 = Tn[(size_t)(i + 1) * nnz + j + 1];
+        T t1 = Tn[((size_t)i * nnz + j) * ts], t2 = Tn[((size_t)(i + 1) * nnz + j) * ts];
+        T t3 = Tn[((size_t)i * nnz + j + 1) * ts], t4 = Tn[((size_t)(i + 1) * nnz + j + 1) * ts];
         T w1 = (xmin + (T)(i + 1) * dx - px) / dx, w2 = (px - (xmin + (T)i * dx)) / dx;
         t1 = t1 * w1 + t2 * w2;
         t2 = t3 * w1 + t4 * w2;
