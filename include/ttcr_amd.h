@@ -118,6 +118,12 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "mode"         1: persistent sweep kernel, one launch per directional sweep, patches ordered by
  *                     progress counters in HBM (default); 0: one launch per tile wavefront
  *                  (env TTCR_FSM_MODE overrides the default at grid creation)
+ *   "tt_from_rp"   1: receiver traveltimes are integrated along the ray traced back through the
+ *                     traveltime field (replaces setTraveltimeFromRaypath(bool), ttcr/Grid3D.h, and the
+ *                     `ttrp` constructor argument; Grid3Drn::getTraveltimeFromRaypath, ttcr/Grid3Drn.h:
+ *                     1103-1243; 3-D only); 0: trilinear interpolation (getTraveltime).  Default 0.
+ *   "interp_vel"   1: the ray integration interpolates velocity instead of slowness (`intVel`
+ *                     constructor argument / processVel, ttcr/Grid3Drn.h:2451-2676).  Default 0.
  *   "skip"         1: persistent kernel skips chunks whose read set (bricks of 16^3 nodes, tracked
  *                     by last-change sweep number) did not change since their last evaluation --
  *                     exact, results and iteration counts are unchanged; 0: evaluate every chunk (default) */

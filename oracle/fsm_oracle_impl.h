@@ -492,6 +492,208 @@ REAL SFX(fsm_interp3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL px, REAL p
     return tt;
 }
 
+/* --------------------------------------------- traveltime from raypath (3-D) -- */
+/* Interpolator<T>::linear / bilinear / trilinear, ttcr/Interpolator.h:37-85 */
+static REAL SFX(lin1)(const REAL x[3], const REAL s[2]) {
+    return (s[0] * (x[2] - x[0]) + s[1] * (x[0] - x[1])) / (x[2] - x[1]);
+}
+static REAL SFX(lin2)(const REAL x[3], const REAL y[3], const REAL s[4]) {
+    return (s[0] * (x[2] - x[0]) * (y[2] - y[0]) + s[1] * (x[2] - x[0]) * (y[0] - y[1]) +
+            s[2] * (x[0] - x[1]) * (y[2] - y[0]) + s[3] * (x[0] - x[1]) * (y[0] - y[1])) /
+           ((x[2] - x[1]) * (y[2] - y[1]));
+}
+static REAL SFX(lin3)(const REAL x[3], const REAL y[3], const REAL z[3], const REAL s[8]) {
+    return (s[0] * (x[2] - x[0]) * (y[2] - y[0]) * (z[2] - z[0]) + s[1] * (x[2] - x[0]) * (y[2] - y[0]) * (z[0] - z[1]) +
+            s[2] * (x[2] - x[0]) * (y[0] - y[1]) * (z[2] - z[0]) + s[3] * (x[2] - x[0]) * (y[0] - y[1]) * (z[0] - z[1]) +
+            s[4] * (x[0] - x[1]) * (y[2] - y[0]) * (z[2] - z[0]) + s[5] * (x[0] - x[1]) * (y[2] - y[0]) * (z[0] - z[1]) +
+            s[6] * (x[0] - x[1]) * (y[0] - y[1]) * (z[2] - z[0]) + s[7] * (x[0] - x[1]) * (y[0] - y[1]) * (z[0] - z[1])) /
+           ((x[2] - x[1]) * (y[2] - y[1]) * (z[2] - z[1]));
+}
+
+/* Grid3Drn::computeSlowness(pt, isTranslated = true), ttcr/Grid3Drn.h:2451-2676.
+ * iv = processVel (interpolate velocity instead of slowness). */
+static REAL SFX(slowness_at3d)(const SFX(fsm_grid3d) * g, const REAL* sn, REAL px, REAL py, REAL pz, int iv) {
+    const size_t nnx = g->nnx, nny = g->nny, nnz = g->nnz;
+    const REAL xmin = g->xmin, ymin = g->ymin, zmin = g->zmin, dx = g->dx, dy = g->dx, dz = g->dx;
+    ptrdiff_t onX = -1, onY = -1, onZ = -1;
+    for (size_t n = 0; n < nnx; ++n)
+        if (FABS(px - (xmin + n * dx)) < FSM_SMALL2) { onX = (ptrdiff_t)n; break; }
+    for (size_t n = 0; n < nny; ++n)
+        if (FABS(py - (ymin + n * dy)) < FSM_SMALL2) { onY = (ptrdiff_t)n; break; }
+    for (size_t n = 0; n < nnz; ++n)
+        if (FABS(pz - (zmin + n * dz)) < FSM_SMALL2) { onZ = (ptrdiff_t)n; break; }
+#define SN(ii, jj, kk) (iv ? (REAL)(1.0 / sn[((size_t)(kk) * nny + (jj)) * nnx + (ii)]) : sn[((size_t)(kk) * nny + (jj)) * nnx + (ii)])
+#define RET(v) return iv ? (REAL)(1.0 / (v)) : (v)
+    REAL s[8], x[3], y[3], z[3];
+    if (onX != -1 && onY != -1 && onZ != -1) {
+        return sn[((size_t)onZ * nny + onY) * nnx + onX];
+    } else if (onX != -1 && onY != -1) {
+        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        s[0] = SN(onX, onY, k); s[1] = SN(onX, onY, k + 1);
+        x[0] = pz; x[1] = zmin + k * dz; x[2] = zmin + (k + 1) * dz;
+        RET(SFX(lin1)(x, s));
+    } else if (onX != -1 && onZ != -1) {
+        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
+        s[0] = SN(onX, j, onZ); s[1] = SN(onX, j + 1, onZ);
+        x[0] = py; x[1] = ymin + j * dy; x[2] = ymin + (j + 1) * dy;
+        RET(SFX(lin1)(x, s));
+    } else if (onY != -1 && onZ != -1) {
+        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+        s[0] = SN(i, onY, onZ); s[1] = SN(i + 1, onY, onZ);
+        x[0] = px; x[1] = xmin + i * dx; x[2] = xmin + (i + 1) * dx;
+        RET(SFX(lin1)(x, s));
+    } else if (onX != -1) {
+        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
+        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        s[0] = SN(onX, j, k); s[1] = SN(onX, j, k + 1); s[2] = SN(onX, j + 1, k); s[3] = SN(onX, j + 1, k + 1);
+        x[0] = py; y[0] = pz; x[1] = ymin + j * dy; y[1] = zmin + k * dz; x[2] = ymin + (j + 1) * dy; y[2] = zmin + (k + 1) * dz;
+        RET(SFX(lin2)(x, y, s));
+    } else if (onY != -1) {
+        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        s[0] = SN(i, onY, k); s[1] = SN(i, onY, k + 1); s[2] = SN(i + 1, onY, k); s[3] = SN(i + 1, onY, k + 1);
+        x[0] = px; y[0] = pz; x[1] = xmin + i * dx; y[1] = zmin + k * dz; x[2] = xmin + (i + 1) * dx; y[2] = zmin + (k + 1) * dz;
+        RET(SFX(lin2)(x, y, s));
+    } else if (onZ != -1) {
+        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
+        s[0] = SN(i, j, onZ); s[1] = SN(i, j + 1, onZ); s[2] = SN(i + 1, j, onZ); s[3] = SN(i + 1, j + 1, onZ);
+        x[0] = px; y[0] = py; x[1] = xmin + i * dx; y[1] = ymin + j * dy; x[2] = xmin + (i + 1) * dx; y[2] = ymin + (j + 1) * dy;
+        RET(SFX(lin2)(x, y, s));
+    } else {
+        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
+        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        s[0] = SN(i, j, k); s[1] = SN(i, j, k + 1); s[2] = SN(i, j + 1, k); s[3] = SN(i, j + 1, k + 1);
+        s[4] = SN(i + 1, j, k); s[5] = SN(i + 1, j, k + 1); s[6] = SN(i + 1, j + 1, k); s[7] = SN(i + 1, j + 1, k + 1);
+        x[0] = px; y[0] = py; z[0] = pz;
+        x[1] = xmin + i * dx; y[1] = ymin + j * dy; z[1] = zmin + k * dz;
+        x[2] = xmin + (i + 1) * dx; y[2] = ymin + (j + 1) * dy; z[2] = zmin + (k + 1) * dz;
+        RET(SFX(lin3)(x, y, z, s));
+    }
+#undef SN
+#undef RET
+}
+
+/* Grid3Drn::grad(g, pt, nt), ttcr/Grid3Drn.h:1033-1100: 4th-order centred operator on the
+ * interpolated field.  (x uses pt.x - dx, y and z use pt - d/2.0 -- as in the reference.) */
+static void SFX(grad3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL ptx, REAL pty, REAL ptz, REAL* gx, REAL* gy, REAL* gz) {
+    static const REAL k1 = 1. / 24.;
+    static const REAL k2 = 9. / 8.;
+    const REAL dx = g->dx, dy = g->dx, dz = g->dx;
+    REAL p1 = ptx - dx;
+    REAL p2 = p1 + 0.5 * dx, p3 = p1 + 1.5 * dx, p4 = p1 + 2.0 * dx;
+    if (p1 <= g->xmin) {
+        p1 = g->xmin; p2 = p1 + 0.5 * dx; p3 = p1 + 1.5 * dx; p4 = p1 + 2.0 * dx;
+    } else if (p4 >= g->xmax) {
+        p4 = g->xmax; p3 = p4 - 0.5 * dx; p2 = p4 - 1.5 * dx; p1 = p4 - 2.0 * dx;
+    }
+    *gx = (k1 * SFX(fsm_interp3d)(g, T, p1, pty, ptz) - k2 * SFX(fsm_interp3d)(g, T, p2, pty, ptz) +
+           k2 * SFX(fsm_interp3d)(g, T, p3, pty, ptz) - k1 * SFX(fsm_interp3d)(g, T, p4, pty, ptz)) / dx;
+    p1 = pty - dy / 2.0;
+    p2 = p1 + 0.5 * dy; p3 = p1 + 1.5 * dy; p4 = p1 + 2.0 * dy;
+    if (p1 <= g->ymin) {
+        p1 = g->ymin; p2 = p1 + 0.5 * dy; p3 = p1 + 1.5 * dy; p4 = p1 + 2.0 * dy;
+    } else if (p4 >= g->ymax) {
+        p4 = g->ymax; p3 = p4 - 0.5 * dy; p2 = p4 - 1.5 * dy; p1 = p4 - 2.0 * dy;
+    }
+    *gy = (k1 * SFX(fsm_interp3d)(g, T, ptx, p1, ptz) - k2 * SFX(fsm_interp3d)(g, T, ptx, p2, ptz) +
+           k2 * SFX(fsm_interp3d)(g, T, ptx, p3, ptz) - k1 * SFX(fsm_interp3d)(g, T, ptx, p4, ptz)) / dy;
+    p1 = ptz - dz / 2.0;
+    p2 = p1 + 0.5 * dz; p3 = p1 + 1.5 * dz; p4 = p1 + 2.0 * dz;
+    if (p1 <= g->zmin) {
+        p1 = g->zmin; p2 = p1 + 0.5 * dz; p3 = p1 + 1.5 * dz; p4 = p1 + 2.0 * dz;
+    } else if (p4 >= g->zmax) {
+        p4 = g->zmax; p3 = p4 - 0.5 * dz; p2 = p4 - 1.5 * dz; p1 = p4 - 2.0 * dz;
+    }
+    *gz = (k1 * SFX(fsm_interp3d)(g, T, ptx, pty, p1) - k2 * SFX(fsm_interp3d)(g, T, ptx, pty, p2) +
+           k2 * SFX(fsm_interp3d)(g, T, ptx, pty, p3) - k1 * SFX(fsm_interp3d)(g, T, ptx, pty, p4)) / dz;
+}
+
+static int SFX(sgn)(REAL v) { return v == 0 ? 0 : (signbit(v) ? -1 : 1); } /* boost::math::sign */
+static REAL SFX(dist3)(const REAL a[3], const REAL b[3]) { /* sxyz::getDistance, ttcr/ttcr_t.h:289-291 */
+    return (REAL)sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+}
+
+/* one "advance curr along g to the next grid plane" block of getTraveltimeFromRaypath
+ * (ttcr/Grid3Drn.h:1131-1165 and :1193-1223) */
+static void SFX(step_to_plane)(const SFX(fsm_grid3d) * g, REAL cur[3], const REAL gv[3]) {
+    const REAL dx = g->dx, dy = g->dx, dz = g->dx;
+    const ptrdiff_t i = (ptrdiff_t)(FSM_SMALL2 + (cur[0] - g->xmin) / dx);
+    const ptrdiff_t j = (ptrdiff_t)(FSM_SMALL2 + (cur[1] - g->ymin) / dy);
+    const ptrdiff_t k = (ptrdiff_t)(FSM_SMALL2 + (cur[2] - g->zmin) / dz);
+    REAL xp = g->xmin + dx * (i + (SFX(sgn)(gv[0]) > 0.0 ? 1.0 : 0.0));
+    REAL yp = g->ymin + dy * (j + (SFX(sgn)(gv[1]) > 0.0 ? 1.0 : 0.0));
+    REAL zp = g->zmin + dz * (k + (SFX(sgn)(gv[2]) > 0.0 ? 1.0 : 0.0));
+    if (FABS(xp - cur[0]) < FSM_SMALL2) xp += dx * SFX(sgn)(gv[0]);
+    if (FABS(yp - cur[1]) < FSM_SMALL2) yp += dy * SFX(sgn)(gv[1]);
+    if (FABS(zp - cur[2]) < FSM_SMALL2) zp += dz * SFX(sgn)(gv[2]);
+    REAL tx = gv[0] != 0.0 ? (xp - cur[0]) / gv[0] : REAL_MAX;
+    REAL ty = gv[1] != 0.0 ? (yp - cur[1]) / gv[1] : REAL_MAX;
+    REAL tz = gv[2] != 0.0 ? (zp - cur[2]) / gv[2] : REAL_MAX;
+    if (tx < ty && tx < tz) {
+        cur[0] += tx * gv[0]; cur[1] += tx * gv[1]; cur[2] += tx * gv[2];
+        cur[0] = xp;
+    } else if (ty < tz) {
+        cur[0] += ty * gv[0]; cur[1] += ty * gv[1]; cur[2] += ty * gv[2];
+        cur[1] = yp;
+    } else {
+        cur[0] += tz * gv[0]; cur[1] += tz * gv[1]; cur[2] += tz * gv[2];
+        cur[2] = zp;
+    }
+}
+
+/* Grid3Drn::getTraveltimeFromRaypath, ttcr/Grid3Drn.h:1103-1243: steepest-descent walk from the
+ * receiver to the source through the traveltime field, trapezoidal slowness integration.
+ * Points are in grid coordinates.  Returns 0, or 1 when the ray leaves the grid (the reference
+ * throws std::runtime_error), or 2 when max_steps is exhausted (the reference would loop). */
+int SFX(fsm_tt_from_raypath3d)(const SFX(fsm_grid3d) * g, const REAL* sn, const REAL* T, int n_src, const REAL* src,
+                               const REAL* t0, const REAL rx[3], int iv, long max_steps, REAL* tt_out) {
+    REAL tt = 0.0, s1, s2;
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) { *tt_out = t0[ns]; return 0; }
+    REAL prev[3] = {rx[0], rx[1], rx[2]}, cur[3] = {rx[0], rx[1], rx[2]}, gv[3];
+    s1 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+    const REAL dx = g->dx;
+    const REAL maxDist = (REAL)sqrt(dx * dx + dx * dx + dx * dx);
+    int reached = 0;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) return 2;
+        SFX(grad3d)(g, T, cur[0], cur[1], cur[2], &gv[0], &gv[1], &gv[2]);
+        gv[0] *= (REAL)-1.0; gv[1] *= (REAL)-1.0; gv[2] *= (REAL)-1.0;
+        SFX(step_to_plane)(g, cur, gv);
+        if (cur[0] < g->xmin || cur[0] > g->xmax || cur[1] < g->ymin || cur[1] > g->ymax || cur[2] < g->zmin ||
+            cur[2] > g->zmax)
+            return 1;
+        s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+        tt += 0.5 * (s1 + s2) * SFX(dist3)(prev, cur);
+        s1 = s2;
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        for (int ns = 0; ns < n_src; ++ns) {
+            const REAL* tx = src + 3 * ns;
+            REAL dist = SFX(dist3)(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1]; gv[2] = tx[2] - cur[2];
+                SFX(step_to_plane)(g, cur, gv);
+                if (SFX(dist3)(cur, prev) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(prev, tx);
+                } else {
+                    s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+                    tt += 0.5 * (s1 + s2) * SFX(dist3)(prev, cur);
+                    s1 = s2;
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(cur, tx);
+                }
+                reached = 1;
+            }
+        }
+    }
+    *tt_out = tt;
+    return 0;
+}
+
 /* ------------------------------------------------------------------ 2D -- */
 /* 2D node index is z-fastest: n = i*(ncz+1)+j (ttcr/Grid2Drn.h:720). */
 

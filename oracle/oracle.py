@@ -101,7 +101,7 @@ def _prep_pts(dt, pts, ncol):
 
 
 def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-            cell_slowness=False, translate=False, rcv=None, weno=False):
+            cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False):
     """Restatement of Grid3Drnfs / Grid3Drcfs ::raytrace (tt_from_rp=False; weno selects the
     two-stage first-order + WENO3 driver).
 
@@ -144,8 +144,24 @@ def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=5
         r = _prep_pts(dt, rcv, 3).copy()
         if translate:
             r -= np.array([g.ox, g.oy, g.oz], dtype=dt)
-        f = getattr(L, "fsm_interp3d_" + sfx)
-        out["tt_rcv"] = np.array([f(C.byref(g), _p(T), ct(p[0]), ct(p[1]), ct(p[2])) for p in r], dtype=dt)
+        if tt_from_rp:
+            # Grid3D::raytrace with tt_from_rp (ttcr/Grid3D.h:493-496): traveltime integrated along the ray
+            frp = getattr(L, "fsm_tt_from_raypath3d_" + sfx)
+            vals = np.empty(r.shape[0], dtype=dt)
+            for n, pnt in enumerate(r):
+                pp = np.ascontiguousarray(pnt, dtype=dt)
+                v = ct(0)
+                rc = frp(C.byref(g), _p(sn), _p(T), C.c_int(nsrc), _p(src), _p(t0), _p(pp), C.c_int(int(interp_vel)),
+                         C.c_long(1000000), C.byref(v))
+                if rc == 1:
+                    raise RuntimeError("Error while computing raypaths: going outside grid")
+                if rc == 2:
+                    raise RuntimeError("raypath did not reach the source")
+                vals[n] = v.value
+            out["tt_rcv"] = vals
+        else:
+            f = getattr(L, "fsm_interp3d_" + sfx)
+            out["tt_rcv"] = np.array([f(C.byref(g), _p(T), ct(p[0]), ct(p[1]), ct(p[2])) for p in r], dtype=dt)
     return out
 
 
@@ -160,7 +176,7 @@ def cells_to_nodes3d(dtype, ncells, sc):
 
 
 def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-                cell_slowness=False, translate=False, rcv=None, weno=False):
+                cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False):
     """The compiled, unmodified reference (build container only)."""
     dt = np.dtype(dtype)
     sfx, ct = _TYPES[dt][:2]
@@ -178,6 +194,7 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
     rc = getattr(R, "ref_fsm3d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncy),
                                         C.c_uint32(ncz), ct(dx), ct(origin[0]), ct(origin[1]), ct(origin[2]),
                                         ct(eps), C.c_int(maxit), C.c_int(int(weno)), C.c_int(int(translate)),
+                                        C.c_int(int(tt_from_rp)), C.c_int(int(interp_vel)),
                                         _p(s), C.c_int(nsrc), _p(src), _p(t0), C.c_int(r.shape[0]), _p(r),
                                         _p(tt_rcv), _p(T), niter)
     if rc != 0:

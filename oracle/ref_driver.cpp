@@ -85,18 +85,19 @@ static int run2d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
 // ncx/ncy/ncz are CELL counts, as in the reference constructors.
 #define REF3D(NAME, T)                                                                              \
     extern "C" int NAME(int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz, T dx, T xmin,  \
-                        T ymin, T zmin, T eps, int maxit, int weno, int translate,                  \
-                        const T* slowness, int n_src, const T* src_xyz, const T* t0, int n_rcv,     \
-                        const T* rcv_xyz, T* tt_rcv, T* tt_grid, int* niter) {                      \
+                        T ymin, T zmin, T eps, int maxit, int weno, int translate, int ttrp,        \
+                        int intvel, const T* slowness, int n_src, const T* src_xyz, const T* t0,    \
+                        int n_rcv, const T* rcv_xyz, T* tt_rcv, T* tt_grid, int* niter) {           \
         try {                                                                                       \
             if (cell_slowness) {                                                                    \
                 ttcr::Grid3Drcfs<T, uint32_t> g(ncx, ncy, ncz, dx, xmin, ymin, zmin, eps, maxit,    \
-                                                weno != 0, false, false, 1, translate != 0);        \
+                                                weno != 0, ttrp != 0, intvel != 0, 1,               \
+                                                translate != 0);                                    \
                 return run3d<T>(g, slowness, (size_t)ncx * ncy * ncz, n_src, src_xyz, t0, n_rcv,    \
                                 rcv_xyz, tt_rcv, tt_grid, niter);                                   \
             }                                                                                       \
             ttcr::Grid3Drnfs<T, uint32_t> g(ncx, ncy, ncz, dx, xmin, ymin, zmin, eps, maxit,        \
-                                            weno != 0, false, false, 1, translate != 0);            \
+                                            weno != 0, ttrp != 0, intvel != 0, 1, translate != 0);  \
             return run3d<T>(g, slowness, (size_t)(ncx + 1) * (ncy + 1) * (ncz + 1), n_src, src_xyz, \
                             t0, n_rcv, rcv_xyz, tt_rcv, tt_grid, niter);                            \
         } catch (std::exception & e) {                                                              \

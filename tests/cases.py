@@ -129,6 +129,12 @@ def weno_ok(c):
     return min(c["ncells"]) >= 3 and int(np.prod(np.array(c["ncells"]) + 1)) <= 20000
 
 
+def rp_ok(c):
+    """Cases used for traveltime-from-raypath: smooth models only (on rough random media the
+    reference's steepest-descent walk does not terminate)."""
+    return c["dim"] == 3 and weno_ok(c) and "random" not in c["name"]
+
+
 # ------------------------------------------------------------------ case matrix
 # Every case: dict(name, dim, ncells, dx[,dz], origin, slowness (float64), cell_slowness,
 #                  src (n,dim), t0 (n,), rcv (m,dim), translate)

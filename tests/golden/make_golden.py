@@ -7,6 +7,9 @@ For every case of tests/cases.py and both dtypes the file holds the reference's 
   <case>/<dtype>/tt       full node traveltime field (Grid3Drn::getTT, flat, x-fastest / z-fastest)
   <case>/<dtype>/niter    get_niter()
   <case>/<dtype>/tt_rcv   Grid3Drn::getTraveltime at the case's receivers (tt_from_rp = false)
+  <case>/<dtype>/rp_tt_rcv, rpv_tt_rcv   receiver traveltimes of the weno + tt_from_rp solve
+                          (Grid3Drn::getTraveltimeFromRaypath), without / with interp_vel; *_error = 1 when
+                          the reference throws "going outside grid" for the case
   <case>/<dtype>/weno_*   the same four outputs (+ niterw) of the two-stage weno=True solve, for the
                           cases of cases.weno_ok()
 and the inputs  <case>/slowness (float64; cast to the dtype under test), so that the
@@ -58,6 +61,19 @@ def main():
                 out[key + "/weno_niterw"] = np.int32(r["niterw"])
                 out[key + "/weno_tt_rcv"] = r["tt_rcv"]
                 print(key, "weno niter", r["niter"], r["niterw"])
+            if cases.rp_ok(c):
+                # default ttcrpy 3-D configuration: weno + traveltime integrated along the raypath
+                for tag, iv in (("rp", False), ("rpv", True)):
+                    try:
+                        r = O.ref_solve3d(dt, c["ncells"], c["dx"], c["origin"], c["slowness"], c["src"], c["t0"],
+                                          cell_slowness=c["cell_slowness"], translate=c["translate"], rcv=c["rcv"],
+                                          weno=True, tt_from_rp=True, interp_vel=iv)
+                        out[key + f"/{tag}_tt_rcv"] = r["tt_rcv"]
+                        out[key + f"/{tag}_error"] = np.int32(0)
+                    except RuntimeError as e:
+                        assert "going outside grid" in str(e)
+                        out[key + f"/{tag}_error"] = np.int32(1)
+                    print(key, tag, "error" if int(out[key + f"/{tag}_error"]) else "ok")
     path = os.path.join(HERE, "fsm_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -38,7 +38,7 @@ def test_constructor_checks():
     with pytest.raises(NotImplementedError):
         ttcr_amd.Grid3d(x, x, x, method="SPM")
     with pytest.raises(NotImplementedError, match="tt_from_rp"):
-        ttcr_amd.Grid3d(x, x, x, method="FSM")  # reference default tt_from_rp=1
+        ttcr_amd.Grid2d(x, x, method="FSM", tt_from_rp=1)  # 2-D raypath traveltimes are not built
     with pytest.raises(ValueError, match="dtype"):
         ttcr_amd.Grid3d(x, x, x, method="FSM", dtype=np.int32)
     with pytest.raises(NotImplementedError):

@@ -42,6 +42,24 @@ def test_oracle_weno_matches_golden(oracle, golden, c, dt):
     np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/weno_tt_rcv"])
 
 
+RP = [(c, dt) for c, dt in ALL if cases.rp_ok(c)]
+
+
+@pytest.mark.parametrize("c,dt", RP, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in RP])
+@pytest.mark.parametrize("tag,iv", [("rp", False), ("rpv", True)])
+def test_oracle_tt_from_raypath_matches_golden(oracle, golden, c, dt, tag, iv):
+    """weno=True + tt_from_rp=True (ttcrpy's 3-D defaults): traveltimes integrated along the ray"""
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    kw = dict(cell_slowness=c["cell_slowness"], translate=c["translate"], rcv=c["rcv"], weno=True, tt_from_rp=True,
+              interp_vel=iv)
+    if int(golden[key + f"/{tag}_error"]):
+        with pytest.raises(RuntimeError, match="going outside grid"):
+            oracle.solve3d(dt, c["ncells"], c["dx"], c["origin"], golden[f"{c['name']}/slowness"], c["src"], c["t0"], **kw)
+        return
+    r = oracle.solve3d(dt, c["ncells"], c["dx"], c["origin"], golden[f"{c['name']}/slowness"], c["src"], c["t0"], **kw)
+    np.testing.assert_array_equal(r["tt_rcv"], golden[key + f"/{tag}_tt_rcv"])
+
+
 def test_golden_covers_multi_iteration_cases(golden):
     # the stopping rule / sweep order is only exercised when iterations >= 2 do real work
     assert int(golden["random_24x20x28_node/float32/niter"]) >= 4

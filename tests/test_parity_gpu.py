@@ -54,6 +54,31 @@ def test_hip_weno_matches_golden_bit_exact(golden, c, dt):
     np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/weno_tt_rcv"])
 
 
+RP = [(c, dt) for c, dt in ALL if cases.rp_ok(c)]
+
+
+@pytest.mark.parametrize("c,dt", RP, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in RP])
+@pytest.mark.parametrize("tag,iv", [("rp", 0), ("rpv", 1)])
+def test_hip_tt_from_raypath_matches_golden(golden, c, dt, tag, iv):
+    """ttcrpy's 3-D defaults (weno=1, tt_from_rp=1): receiver traveltimes integrated along the ray
+    traced back through the field, bit-exact; same error when the reference's ray leaves the grid"""
+    import ttcr_amd
+    from gpu_util import source_array
+
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    nc, o = c["ncells"], c["origin"]
+    x, y, z = (o[a] + np.arange(nc[a] + 1) * c["dx"] for a in range(3))
+    g = ttcr_amd.Grid3d(x, y, z, cell_slowness=c["cell_slowness"], method="FSM", tt_from_rp=1, weno=1, interp_vel=iv,
+                        translate_grid=c["translate"], dtype=dt)
+    s = np.asarray(golden[f"{c['name']}/slowness"]).reshape(g.shape, order="F")
+    if int(golden[key + f"/{tag}_error"]):
+        with pytest.raises(RuntimeError, match="going outside grid"):
+            g.raytrace(source_array(c), c["rcv"], slowness=s, aggregate_src=True)
+        return
+    tt = g.raytrace(source_array(c), c["rcv"], slowness=s, aggregate_src=True)
+    np.testing.assert_array_equal(tt, golden[key + f"/{tag}_tt_rcv"])
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_hip_matches_oracle_on_fresh_inputs(oracle, dt):
     """inputs that are NOT in the golden file: random slowness, random off-node source"""

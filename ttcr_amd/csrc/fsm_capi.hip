@@ -86,6 +86,7 @@ class GridBase {
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter, niterw;
     bool weno = false;
+    int ttrp = 0, interp_vel = 0;  // traveltime from raypath (ttcr/Grid3D.h:493-496), processVel
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
     int skip = 0;  // persistent kernel: 1 = skip chunks whose read set did not change (exact); see DESIGN.md
     int mode = 1;  // 1: persistent kernel, one launch per sweep (default); 0: one launch per tile wavefront
@@ -116,6 +117,8 @@ class GridT : public GridBase {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
+    DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
+    DevBuf<int> d_rstat;
     DevBuf<T> d_ssh;         // sheared copies of the node slowness, one per direction family
     size_t ssh_stride = 0;   // elements per copy: NK * M * NJ
     DevBuf<uint32_t> d_mask;
@@ -785,6 +788,45 @@ class GridT : public GridBase {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
+    // Grid3Drn::getTraveltimeFromRaypath for every receiver of one source (ttcr/Grid3D.h:493-496)
+    void raypath_grid_coords(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out) {
+        if (n <= 0) return;
+        if (dim != 3) throw Unsupported("tt_from_rp=True is only built for 3-D grids");
+        d_rx.reserve((size_t)3 * n);
+        d_out.reserve(n);
+        d_rstat.reserve(n);
+        d_rsrc.reserve((size_t)3 * n_tx);
+        d_rt0.reserve(n_tx);
+        HIP_CHECK(hipMemcpyAsync(d_rx.p, p, sizeof(T) * 3 * n, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txp, sizeof(T) * 3 * n_tx, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0p, sizeof(T) * n_tx, hipMemcpyHostToDevice, stream));
+        RayGeom<T> rg;
+        rg.nnx = ncx + 1; rg.nny = ncy + 1; rg.nnz = ncz + 1;
+        rg.dx = dx; rg.xmin = xmin; rg.ymin = ymin; rg.zmin = zmin; rg.xmax = xmax; rg.ymax = ymax; rg.zmax = zmax;
+        rg.interp_vel = interp_vel;
+        const long max_steps = 8L * ((long)ncx + ncy + ncz + 3);  // a ray crosses at most one plane per step
+        fsm_raypath3d<T><<<(n + 63) / 64, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, n,
+                                                            d_out.p, d_rstat.p, max_steps);
+        HIP_CHECK(hipGetLastError());
+        std::vector<int> st(n);
+        HIP_CHECK(hipMemcpyAsync(out, d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (int m = 0; m < n; ++m) {
+            if (st[m] == 0) continue;
+            std::ostringstream msg;
+            if (st[m] == 1) {
+                msg << "Error while computing raypaths: going outside grid \n                Rx: " << p[3 * m] << ' '
+                    << p[3 * m + 1] << ' ' << p[3 * m + 2] << "\n                Tx: " << txp[0] << ' ' << txp[1] << ' '
+                    << txp[2] << "\n";
+            } else {
+                msg << "Error while computing raypaths: ray from Rx " << p[3 * m] << ' ' << p[3 * m + 1] << ' ' << p[3 * m + 2]
+                    << " did not reach the source within " << max_steps << " steps";
+            }
+            throw std::runtime_error(msg.str());
+        }
+    }
+
     // Grid3D::raytrace multi-source overload (ttcr/Grid3D.h:810-853)
     void raytrace_multi(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off,
                         const void* rx_v, void* tt_out_v, int forced_slot) override {
@@ -831,7 +873,11 @@ class GridT : public GridBase {
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
                 for (size_t b = 0; b < sl.size(); ++b) {
                     const int n = sr[b];
-                    interp_grid_coords(sl[b], rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n]);
+                    if (ttrp)
+                        raypath_grid_coords(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)nc * tx_off[n], t0 + tx_off[n],
+                                            rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n]);
+                    else
+                        interp_grid_coords(sl[b], rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n]);
                 }
             }
         }
@@ -990,6 +1036,10 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
         else if (k == "use_graph") g->impl->use_graph = value != 0;
         else if (k == "mode") g->impl->mode = (int)value;
         else if (k == "skip") g->impl->skip = (int)value;
+        else if (k == "tt_from_rp") {
+            if (value != 0 && g->impl->dim != 3) throw Unsupported("tt_from_rp=True is only built for 3-D grids");
+            g->impl->ttrp = value != 0;
+        } else if (k == "interp_vel") g->impl->interp_vel = value != 0;
         else throw ValueError("unknown option '" + k + "'");
     });
 }

@@ -1342,12 +1342,9 @@ __global__ void fsm_init_source(const InitArgs<T> a) {
 
 // Receiver traveltimes: Grid3Drn::getTraveltime (ttcr/Grid3Drn.h:794-930)
 template <typename T>
-__global__ void fsm_interp3d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
-                             int nnx, int nny, T dx, T xmin, T ymin, T zmin) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+__device__ __forceinline__ T interp3d_pt(const T* __restrict__ Tn, int ts, T px, T py, T pz, int nnx, int nny, T dx,
+                                         T xmin, T ymin, T zmin) {
     const double small2 = 1.e-4 * 1.e-4;
-    const T px = pts[3 * r], py = pts[3 * r + 1], pz = pts[3 * r + 2];
     const T dy = dx, dz = dx;
     const uint32_t i = (uint32_t)(small2 + (double)((px - xmin) / dx));
     const uint32_t j = (uint32_t)(small2 + (double)((py - ymin) / dy));
@@ -1413,8 +1410,231 @@ __global__ void fsm_interp3d(const T* __restrict__ Tn, int ts, const T* __restri
         tt = t1 * w1 + t2 * w2;
     }
 #undef TT
+    return tt;
+}
+
+template <typename T>
+__global__ void fsm_interp3d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
+                             int nnx, int nny, T dx, T xmin, T ymin, T zmin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, dx, xmin, ymin, zmin);
+}
+
+// ---- traveltime from raypath (tt_from_rp, the 3-D default of ttcrpy) --------------------------
+// Grid3Drn::getTraveltimeFromRaypath (ttcr/Grid3Drn.h:1103-1243): steepest-descent walk from the
+// receiver to the source through the traveltime field -- gradient by the 4th-order centred
+// operator grad (:1033-1100) on the trilinearly interpolated field, one grid plane per step,
+// trapezoidal integration of the interpolated slowness computeSlowness (:2451-2676).  One thread
+// per receiver; every expression keeps the reference's T1/double mix.
+template <typename T>
+struct RayGeom {
+    int nnx, nny, nnz;
+    T dx, xmin, ymin, zmin, xmax, ymax, zmax;
+    int interp_vel;
+};
+
+__device__ __forceinline__ float rabs(float v) { return __builtin_fabsf(v); }
+__device__ __forceinline__ double rabs(double v) { return __builtin_fabs(v); }
+
+// first node index n with |p - (cmin + n*d)| < small2, or -1 (the reference scans all nodes)
+template <typename T>
+__device__ __forceinline__ int on_node(T p, T cmin, T d, int nn) {
+    const double small2 = 1.e-4 * 1.e-4;
+    long c = (long)__builtin_floor(((double)p - (double)cmin) / (double)d);
+    long lo = c - 2 < 0 ? 0 : c - 2, hi = c + 3 > nn - 1 ? nn - 1 : c + 3;
+    for (long n = lo; n <= hi; ++n)
+        if ((double)rabs(p - (cmin + (T)(unsigned long)n * d)) < small2) return (int)n;
+    return -1;
+}
+
+template <typename T>
+__device__ T slowness_at3d(const RayGeom<T>& g, const T* __restrict__ sn, T px, T py, T pz) {
+    const int nnx = g.nnx, nny = g.nny;
+    const T xmin = g.xmin, ymin = g.ymin, zmin = g.zmin, dx = g.dx, dy = g.dx, dz = g.dx;
+    const double small = 1.e-4;
+    const int iv = g.interp_vel;
+    const int onX = on_node(px, xmin, dx, g.nnx), onY = on_node(py, ymin, dy, g.nny), onZ = on_node(pz, zmin, dz, g.nnz);
+    auto SN = [&](unsigned i, unsigned j, unsigned k) {
+        const T v = sn[((size_t)k * nny + j) * nnx + i];
+        return iv ? (T)(1.0 / (double)v) : v;
+    };
+    auto RET = [&](T v) { return iv ? (T)(1.0 / (double)v) : v; };
+    auto lin1 = [](const T x[3], const T s[2]) { return (s[0] * (x[2] - x[0]) + s[1] * (x[0] - x[1])) / (x[2] - x[1]); };
+    auto lin2 = [](const T x[3], const T y[3], const T s[4]) {
+        return (s[0] * (x[2] - x[0]) * (y[2] - y[0]) + s[1] * (x[2] - x[0]) * (y[0] - y[1]) +
+                s[2] * (x[0] - x[1]) * (y[2] - y[0]) + s[3] * (x[0] - x[1]) * (y[0] - y[1])) /
+               ((x[2] - x[1]) * (y[2] - y[1]));
+    };
+    T s[8], x[3], y[3], z[3];
+    if (onX != -1 && onY != -1 && onZ != -1) {
+        return sn[((size_t)onZ * nny + onY) * nnx + onX];
+    } else if (onX != -1 && onY != -1) {
+        const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+        s[0] = SN(onX, onY, k); s[1] = SN(onX, onY, k + 1);
+        x[0] = pz; x[1] = zmin + (T)k * dz; x[2] = zmin + (T)(k + 1) * dz;
+        return RET(lin1(x, s));
+    } else if (onX != -1 && onZ != -1) {
+        const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
+        s[0] = SN(onX, j, onZ); s[1] = SN(onX, j + 1, onZ);
+        x[0] = py; x[1] = ymin + (T)j * dy; x[2] = ymin + (T)(j + 1) * dy;
+        return RET(lin1(x, s));
+    } else if (onY != -1 && onZ != -1) {
+        const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
+        s[0] = SN(i, onY, onZ); s[1] = SN(i + 1, onY, onZ);
+        x[0] = px; x[1] = xmin + (T)i * dx; x[2] = xmin + (T)(i + 1) * dx;
+        return RET(lin1(x, s));
+    } else if (onX != -1) {
+        const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
+        const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+        s[0] = SN(onX, j, k); s[1] = SN(onX, j, k + 1); s[2] = SN(onX, j + 1, k); s[3] = SN(onX, j + 1, k + 1);
+        x[0] = py; y[0] = pz; x[1] = ymin + (T)j * dy; y[1] = zmin + (T)k * dz; x[2] = ymin + (T)(j + 1) * dy; y[2] = zmin + (T)(k + 1) * dz;
+        return RET(lin2(x, y, s));
+    } else if (onY != -1) {
+        const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
+        const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+        s[0] = SN(i, onY, k); s[1] = SN(i, onY, k + 1); s[2] = SN(i + 1, onY, k); s[3] = SN(i + 1, onY, k + 1);
+        x[0] = px; y[0] = pz; x[1] = xmin + (T)i * dx; y[1] = zmin + (T)k * dz; x[2] = xmin + (T)(i + 1) * dx; y[2] = zmin + (T)(k + 1) * dz;
+        return RET(lin2(x, y, s));
+    } else if (onZ != -1) {
+        const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
+        const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
+        s[0] = SN(i, j, onZ); s[1] = SN(i, j + 1, onZ); s[2] = SN(i + 1, j, onZ); s[3] = SN(i + 1, j + 1, onZ);
+        x[0] = px; y[0] = py; x[1] = xmin + (T)i * dx; y[1] = ymin + (T)j * dy; x[2] = xmin + (T)(i + 1) * dx; y[2] = ymin + (T)(j + 1) * dy;
+        return RET(lin2(x, y, s));
+    }
+    const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
+    const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
+    const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+    s[0] = SN(i, j, k); s[1] = SN(i, j, k + 1); s[2] = SN(i, j + 1, k); s[3] = SN(i, j + 1, k + 1);
+    s[4] = SN(i + 1, j, k); s[5] = SN(i + 1, j, k + 1); s[6] = SN(i + 1, j + 1, k); s[7] = SN(i + 1, j + 1, k + 1);
+    x[0] = px; y[0] = py; z[0] = pz;
+    x[1] = xmin + (T)i * dx; y[1] = ymin + (T)j * dy; z[1] = zmin + (T)k * dz;
+    x[2] = xmin + (T)(i + 1) * dx; y[2] = ymin + (T)(j + 1) * dy; z[2] = zmin + (T)(k + 1) * dz;
+    const T v = (s[0] * (x[2] - x[0]) * (y[2] - y[0]) * (z[2] - z[0]) + s[1] * (x[2] - x[0]) * (y[2] - y[0]) * (z[0] - z[1]) +
+                 s[2] * (x[2] - x[0]) * (y[0] - y[1]) * (z[2] - z[0]) + s[3] * (x[2] - x[0]) * (y[0] - y[1]) * (z[0] - z[1]) +
+                 s[4] * (x[0] - x[1]) * (y[2] - y[0]) * (z[2] - z[0]) + s[5] * (x[0] - x[1]) * (y[2] - y[0]) * (z[0] - z[1]) +
+                 s[6] * (x[0] - x[1]) * (y[0] - y[1]) * (z[2] - z[0]) + s[7] * (x[0] - x[1]) * (y[0] - y[1]) * (z[0] - z[1])) /
+                ((x[2] - x[1]) * (y[2] - y[1]) * (z[2] - z[1]));
+    return RET(v);
+}
+
+template <typename T>
+__device__ void grad3d(const RayGeom<T>& g, const T* __restrict__ Tn, int ts, T ptx, T pty, T ptz, T* gv) {
+    const T k1 = (T)(1. / 24.), k2 = (T)(9. / 8.);
+    const T dx = g.dx;
+    auto TT = [&](T a, T b, T c) { return interp3d_pt(Tn, ts, a, b, c, g.nnx, g.nny, dx, g.xmin, g.ymin, g.zmin); };
+    auto pts4 = [&](T p1, T cmin, T cmax, T& o1, T& o2, T& o3, T& o4) {
+        T p2 = (T)((double)p1 + 0.5 * (double)dx), p3 = (T)((double)p1 + 1.5 * (double)dx), p4 = (T)((double)p1 + 2.0 * (double)dx);
+        if (p1 <= cmin) {
+            p1 = cmin;
+            p2 = (T)((double)p1 + 0.5 * (double)dx); p3 = (T)((double)p1 + 1.5 * (double)dx); p4 = (T)((double)p1 + 2.0 * (double)dx);
+        } else if (p4 >= cmax) {
+            p4 = cmax;
+            p3 = (T)((double)p4 - 0.5 * (double)dx); p2 = (T)((double)p4 - 1.5 * (double)dx); p1 = (T)((double)p4 - 2.0 * (double)dx);
+        }
+        o1 = p1; o2 = p2; o3 = p3; o4 = p4;
+    };
+    T p1, p2, p3, p4;
+    pts4(ptx - dx, g.xmin, g.xmax, p1, p2, p3, p4);
+    gv[0] = (k1 * TT(p1, pty, ptz) - k2 * TT(p2, pty, ptz) + k2 * TT(p3, pty, ptz) - k1 * TT(p4, pty, ptz)) / dx;
+    pts4((T)((double)pty - (double)dx / 2.0), g.ymin, g.ymax, p1, p2, p3, p4);
+    gv[1] = (k1 * TT(ptx, p1, ptz) - k2 * TT(ptx, p2, ptz) + k2 * TT(ptx, p3, ptz) - k1 * TT(ptx, p4, ptz)) / dx;
+    pts4((T)((double)ptz - (double)dx / 2.0), g.zmin, g.zmax, p1, p2, p3, p4);
+    gv[2] = (k1 * TT(ptx, pty, p1) - k2 * TT(ptx, pty, p2) + k2 * TT(ptx, pty, p3) - k1 * TT(ptx, pty, p4)) / dx;
+}
+
+template <typename T>
+__device__ __forceinline__ int sgn_boost(T v) { return v == 0 ? 0 : (__builtin_signbit(v) ? -1 : 1); }
+
+template <typename T>
+__device__ __forceinline__ T dist3(const T* a, const T* b) {
+    const T d2 = (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+    return (T)__builtin_sqrt((double)d2);
+}
+
+template <typename T>
+__device__ void step_to_plane(const RayGeom<T>& g, T* cur, const T* gv) {
+    const double small2 = 1.e-4 * 1.e-4;
+    const T dx = g.dx;
+    const long i = (long)(small2 + (double)((cur[0] - g.xmin) / dx));
+    const long j = (long)(small2 + (double)((cur[1] - g.ymin) / dx));
+    const long k = (long)(small2 + (double)((cur[2] - g.zmin) / dx));
+    T xp = (T)((double)g.xmin + (double)dx * ((double)i + (sgn_boost(gv[0]) > 0 ? 1.0 : 0.0)));
+    T yp = (T)((double)g.ymin + (double)dx * ((double)j + (sgn_boost(gv[1]) > 0 ? 1.0 : 0.0)));
+    T zp = (T)((double)g.zmin + (double)dx * ((double)k + (sgn_boost(gv[2]) > 0 ? 1.0 : 0.0)));
+    if ((double)rabs(xp - cur[0]) < small2) xp += dx * (T)sgn_boost(gv[0]);
+    if ((double)rabs(yp - cur[1]) < small2) yp += dx * (T)sgn_boost(gv[1]);
+    if ((double)rabs(zp - cur[2]) < small2) zp += dx * (T)sgn_boost(gv[2]);
+    const T big = real_traits<T>::max();
+    const T tx = gv[0] != 0 ? (xp - cur[0]) / gv[0] : big;
+    const T ty = gv[1] != 0 ? (yp - cur[1]) / gv[1] : big;
+    const T tz = gv[2] != 0 ? (zp - cur[2]) / gv[2] : big;
+    if (tx < ty && tx < tz) {
+        cur[0] += tx * gv[0]; cur[1] += tx * gv[1]; cur[2] += tx * gv[2];
+        cur[0] = xp;
+    } else if (ty < tz) {
+        cur[0] += ty * gv[0]; cur[1] += ty * gv[1]; cur[2] += ty * gv[2];
+        cur[1] = yp;
+    } else {
+        cur[0] += tz * gv[0]; cur[1] += tz * gv[1]; cur[2] += tz * gv[2];
+        cur[2] = zp;
+    }
+}
+
+// status: 0 ok, 1 the ray left the grid (the reference throws), 2 step limit (the reference would not return)
+template <typename T>
+__global__ void fsm_raypath3d(const T* __restrict__ Tn, int ts, const T* __restrict__ sn, RayGeom<T> g, int n_src,
+                              const T* __restrict__ src, const T* __restrict__ t0, const T* __restrict__ rcv, int n_rcv,
+                              T* __restrict__ out, int* __restrict__ status, long max_steps) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rcv) return;
+    const T rx[3] = {rcv[3 * r], rcv[3 * r + 1], rcv[3 * r + 2]};
+    status[r] = 0;
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) { out[r] = t0[ns]; return; }
+    T tt = 0, s1, s2;
+    T prev[3] = {rx[0], rx[1], rx[2]}, cur[3] = {rx[0], rx[1], rx[2]}, gv[3];
+    s1 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
+    const T dx = g.dx;
+    const T maxDist = (T)__builtin_sqrt((double)(dx * dx + dx * dx + dx * dx));
+    bool reached = false;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) { status[r] = 2; out[r] = tt; return; }
+        grad3d(g, Tn, ts, cur[0], cur[1], cur[2], gv);
+        gv[0] *= (T)-1.0; gv[1] *= (T)-1.0; gv[2] *= (T)-1.0;
+        step_to_plane(g, cur, gv);
+        if (cur[0] < g.xmin || cur[0] > g.xmax || cur[1] < g.ymin || cur[1] > g.ymax || cur[2] < g.zmin || cur[2] > g.zmax) {
+            status[r] = 1; out[r] = tt; return;
+        }
+        s2 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
+        tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(prev, cur));
+        s1 = s2;
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        for (int ns = 0; ns < n_src; ++ns) {
+            const T tx[3] = {src[3 * ns], src[3 * ns + 1], src[3 * ns + 2]};
+            const T dist = dist3(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1]; gv[2] = tx[2] - cur[2];
+                step_to_plane(g, cur, gv);
+                if (dist3(cur, prev) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
+                    s2 = slowness_at3d(g, sn, tx[0], tx[1], tx[2]);
+                    tt = (T)((double)tt + ((double)t0[ns] + (0.5 * (double)(s1 + s2)) * (double)dist3(prev, tx)));
+                } else {
+                    s2 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
+                    tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(prev, cur));
+                    s1 = s2;
+                    s2 = slowness_at3d(g, sn, tx[0], tx[1], tx[2]);
+                    tt = (T)((double)tt + ((double)t0[ns] + (0.5 * (double)(s1 + s2)) * (double)dist3(cur, tx)));
+                }
+                reached = true;
+            }
+        }
+    }
     out[r] = tt;
 }
+
 
 // Grid2Drn::getTraveltime (ttcr/Grid2Drn.h:359-414)
 template <typename T>

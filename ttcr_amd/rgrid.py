@@ -11,9 +11,9 @@ and error behaviour) for the fast-sweeping path:
   get_grid_traveltimes    rgrid.pyx:410-435       (2-D) rgrid.pyx:3102-3127
 
 weno=True (the reference's default: first-order sweeps, then third-order WENO sweeps) is
-supported.  What is not on the FSM hot path raises NotImplementedError (SPM/DSPM,
-compute_L/compute_M, return_rays) -- and so does tt_from_rp=True until that row of SURVEY.md
-section 8(f) is built.  There is no CPU fallback.
+supported, and so is tt_from_rp=True in 3-D (the 3-D default: traveltimes integrated along the
+ray traced back through the field).  What is not on the FSM hot path raises NotImplementedError
+(SPM/DSPM, compute_L/compute_M, return_rays, 2-D tt_from_rp).  There is no CPU fallback.
 """
 import ctypes as C
 
@@ -64,10 +64,9 @@ class _GridBase:
         self._use_pool = bool(use_thread_pool)
 
     def set_traveltime_from_raypath(self, traveltime_from_raypath):
-        if traveltime_from_raypath:
-            raise NotImplementedError("tt_from_rp=True (traveltime from raypath, ttcr/Grid3Drn.h:1103-1243) "
-                                      "is not built yet; use tt_from_rp=False")
-        self.tt_from_rp = False
+        """Set option to compute traveltime using raypath (rgrid.pyx:373-384)"""
+        self.set_option("tt_from_rp", 1 if traveltime_from_raypath else 0)
+        self.tt_from_rp = bool(traveltime_from_raypath)
 
     def set_option(self, key, value):
         """Backend knob (fixed_iters, max_batch, use_graph); no reference equivalent."""
@@ -262,15 +261,16 @@ class _Grid3d(_GridBase):
             raise NotImplementedError("method '%s' is outside the MI355X FSM path (SURVEY.md section 8)" % method)
         else:
             raise ValueError('Method {0:s} undefined'.format(method))
-        if self.tt_from_rp:
-            raise NotImplementedError("tt_from_rp=True (traveltime from raypath, ttcr/Grid3Drn.h:1103-1243) "
-                                      "is not built yet; pass tt_from_rp=False")
         self._lib = _lib.load()
         st = self._lib.ttcr_fsm3d_create(C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
                                          int(self.cell_slowness), x.size - 1, y.size - 1, z.size - 1, self._dx,
                                          float(x[0]), float(y[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
                                          self._n_threads, int(self.translate_grid), self._device)
         _lib.check(st)
+        if self.tt_from_rp:
+            self.set_option("tt_from_rp", 1)
+        if self.interp_vel:
+            self.set_option("interp_vel", 1)
 
     def __reduce__(self):
         params = (self.n_threads, self.cell_slowness, self.method, self.tt_from_rp, self.interp_vel, self.eps,
