@@ -2,12 +2,12 @@
 """bench.py -- headline benchmark of the MI355X FSM eikonal solver.
 
 Metric (BASELINE.json): Mnodes/s per sweep-iteration on a 512^3 fp32 grid, plus sources/s.
-Workload at every N (weak scaling): each GPU solves `--sources-per-gpu` (8) sources of the
-64 drawn by the reference's generator (mt19937_64(12345), tests/accuracy_grid3d.cpp:352-360)
-on the 512^3-node gradient model s = 1/(1 + 0.1 z) over [0,20]^3 km, fp32, first-order FSM
-(weno=False, tt_from_rp=False, eps=1e-5, maxit=50), 441 receivers (rcv.dat lattice): config[2]
-of BASELINE.json, i.e. 64 sources over 8 GPUs.  One "step" = one full solve (init + sweep
-iterations to convergence + receiver interpolation) of the rank's sources.  Inputs are
+Workload = config[2] of BASELINE.json at every N (strong scaling): the 64 sources drawn by the
+reference's generator (mt19937_64(12345), tests/accuracy_grid3d.cpp:352-360) on the 512^3-node
+gradient model s = 1/(1 + 0.1 z) over [0,20]^3 km, fp32, first-order FSM (weno=False,
+tt_from_rp=False, eps=1e-5, maxit=50), 441 receivers (rcv.dat lattice), block-distributed over
+the N GPUs like get_blk_size (64 on one GPU, 8 per GPU on eight).  One "step" = one full solve
+(init + sweep iterations to convergence + receiver interpolation) of the rank's sources.  Inputs are
 resident in HBM before the timed region (slowness is broadcast over RCCL and handed to the
 solver as a device pointer); the receiver traveltimes are gathered to rank 0 over RCCL inside
 every step (a few KB).
@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="nodes per axis")
-    ap.add_argument("--sources-per-gpu", type=int, default=8)
+    ap.add_argument("--sources", type=int, default=64, help="total sources of the job (sharded over the GPUs)")
+    ap.add_argument("--sources-per-gpu", type=int, default=0, help="override: fixed sources per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to "
@@ -112,7 +113,13 @@ def main():
             dist.init_process_group(args.backend)
 
     n = args.size
-    S = args.sources_per_gpu
+    from ttcr_amd.dist import shard_bounds
+    if args.sources_per_gpu > 0:
+        n_total, weak = args.sources_per_gpu * world, True
+    else:
+        n_total, weak = args.sources, False
+    src_lo, src_hi = shard_bounds(n_total, world, rank)
+    S = src_hi - src_lo
     dx = 20.0 / (n - 1)
     x = np.arange(n, dtype=np.float64) * dx
     grid = ttcr_amd.Grid3d(x, x, x, n_threads=S, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0,
@@ -137,21 +144,24 @@ def main():
     torch.cuda.synchronize()
     grid.set_slowness_device(s_dev.data_ptr(), s_dev.numel())
 
-    all_src = cases.mt_sources(max(64, world * S))
-    my_src = all_src[rank * S:(rank + 1) * S]
+    all_src = cases.mt_sources(max(64, n_total))
+    my_src = all_src[src_lo:src_hi]
     rcv1 = cases.rcv_lattice3d()
     # ttcrpy convention: one (source, receiver) row pair per datum
     src_rows = np.repeat(my_src, rcv1.shape[0], axis=0)
     rcv_rows = np.tile(rcv1, (S, 1))
     n_nodes = n ** 3
 
-    gathered = [torch.empty(src_rows.shape[0], dtype=torch.float32, device=cdev) for _ in range(world)] if rank == 0 else None
+    # equal-sized gather buffers (ranks own at most ceil(n_total/world) sources)
+    max_rows = -(-n_total // world) * rcv1.shape[0]
+    gathered = [torch.empty(max_rows, dtype=torch.float32, device=cdev) for _ in range(world)] if rank == 0 else None
 
     def step():
         tt = grid.raytrace(src_rows, rcv_rows)
         tm = grid.timing()
         if world > 1:
-            t_dev = torch.from_numpy(tt).to(cdev)
+            t_dev = torch.zeros(max_rows, dtype=torch.float32, device=cdev)
+            t_dev[:tt.shape[0]] = torch.from_numpy(tt).to(cdev)
             dist.gather(t_dev, gathered, dst=0)
         return tt, tm
 
@@ -209,14 +219,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(el_max / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "sources_per_s": round(world * S * args.steps / el_max, 3),
-            "config": {"workload": f"Grid3d {n}^3 nodes gradient velocity, {S} sources per GPU ({world * S} total) "
-                                   f"of the mt19937_64(12345) set, 441 receivers, fp32, weno=False, tt_from_rp=False",
-                       "grid_nodes": n_nodes, "sources_per_gpu": S, "sweep_iterations_per_source": iters_per_src,
+            "sources_per_s": round(n_total * args.steps / el_max, 3),
+            "config": {"workload": f"Grid3d {n}^3 nodes gradient velocity, {n_total} sources of the mt19937_64(12345) "
+                                   f"set block-distributed over {world} GPU(s) ({S} on rank 0), 441 receivers, fp32, "
+                                   f"weno=False, tt_from_rp=False",
+                       "grid_nodes": n_nodes, "sources_total": n_total, "sources_rank0": S,
+                       "sweep_iterations_per_source": sorted(set(iters_per_src)),
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, gather of traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
