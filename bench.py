@@ -74,6 +74,26 @@ def cpu_baseline(n=256, n_src=3):
     return out
 
 
+def profiled_traffic(n, n_src_rank0, world):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes of this very command
+    (profiles/r01/final_512x64_{FETCH,WRITE}_SIZE_summary.csv, made by scripts/pmc_run.sh: separate
+    --pmc passes, KB units, gfx950 x2 correction of the read counter calibrated in the same run).
+    bench.py cannot profile itself, so the number is only reported for the profiled configuration."""
+    if not (n == 512 and n_src_rank0 == 64 and world == 1):
+        return None, None
+    try:
+        vals = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            path = os.path.join(ROOT, "profiles", "r01", f"final_512x64_{c}_summary.csv")
+            with open(path) as f:
+                for line in f:
+                    if "fsm_sweep_persistent" in line:
+                        vals[c] = float(line.rsplit(",", 1)[1])  # KB per dispatch
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01/final_512x64_*_SIZE_summary.csv"
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +230,7 @@ def main():
         bytes_total = BYTES_PER_NODE_ITER / 8.0 * evaluated
         achieved = bytes_total / (sweep_ms * 1e-3) / 1e9
         nominal = BYTES_PER_NODE_ITER * node_iters / (sweep_ms * 1e-3) / 1e9
+        traffic, traffic_src = profiled_traffic(n, S, world)
         out = {
             "metric": "Mnodes/s per sweep-iteration (512^3 fp32 grid, first-order FSM)",
             "value": round(value, 1),
@@ -231,7 +252,8 @@ def main():
                        "sweep_iterations_per_source": sorted(set(iters_per_src)),
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, gather of traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "fsm_sweep_persistent<float,16,16,8,true,%s>" % ("true" if os.environ.get("TTCR_FSM_SKIP", "0") == "1" else "false") if os.environ.get("TTCR_FSM_MODE", "1") != "0" else "fsm_sweep_tile<float,16,16,16,true>",
                          "algorithmic_bytes_per_node_per_sweep_iteration": BYTES_PER_NODE_ITER,
                          "evaluated_fraction": round(evaluated / max(node_iters * 8, 1), 4),
