@@ -74,22 +74,27 @@ def cpu_baseline(n=256, n_src=3):
     return out
 
 
+KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,true> (one launch per sweep-iteration)",
+           "1": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,false> (one launch per directional sweep)",
+           "0": "fsm_sweep_tile<float,16,16,16,true> (one launch per tile wavefront)"}
+
+
 def profiled_traffic(n, n_src_rank0, world):
-    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes of this very command
-    (profiles/r01/final_512x64_{FETCH,WRITE}_SIZE_summary.csv, made by scripts/pmc_run.sh: separate
+    """HBM bytes per launch (one sweep-iteration of the batch) from the committed rocprofv3 PMC passes of this very command
+    (profiles/r01/xs_512x64_{FETCH,WRITE}_SIZE_summary.csv, made by scripts/pmc_run.sh: separate
     --pmc passes, KB units, gfx950 x2 correction of the read counter calibrated in the same run).
     bench.py cannot profile itself, so the number is only reported for the profiled configuration."""
-    if not (n == 512 and n_src_rank0 == 64 and world == 1):
+    if not (n == 512 and n_src_rank0 == 64 and world == 1 and os.environ.get("TTCR_FSM_MODE", "2") == "2"):
         return None, None
     try:
         vals = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            path = os.path.join(ROOT, "profiles", "r01", f"final_512x64_{c}_summary.csv")
+            path = os.path.join(ROOT, "profiles", "r01", f"xs_512x64_{c}_summary.csv")
             with open(path) as f:
                 for line in f:
                     if "fsm_sweep_persistent" in line:
                         vals[c] = float(line.rsplit(",", 1)[1])  # KB per dispatch
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01/final_512x64_*_SIZE_summary.csv"
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01/xs_512x64_*_SIZE_summary.csv"
     except Exception:
         return None, None
 
@@ -254,7 +259,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "fsm_sweep_persistent<float,16,16,8,true,%s>" % ("true" if os.environ.get("TTCR_FSM_SKIP", "0") == "1" else "false") if os.environ.get("TTCR_FSM_MODE", "1") != "0" else "fsm_sweep_tile<float,16,16,16,true>",
+                         "kernel": KERNELS.get(os.environ.get("TTCR_FSM_MODE", "2"), "?"),
                          "algorithmic_bytes_per_node_per_sweep_iteration": BYTES_PER_NODE_ITER,
                          "evaluated_fraction": round(evaluated / max(node_iters * 8, 1), 4),
                          "nominal_GBs_all_updates": round(nominal, 1),

@@ -115,8 +115,10 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "fixed_iters"  > 0: run exactly that many sweep-iterations, ignore eps
  *   "max_batch"    sources swept concurrently by one launch sequence (default: n_slots)
  *   "use_graph"    1: replay the per-iteration launch sequence from a hipGraph (default 1)
- *   "mode"         1: persistent sweep kernel, one launch per directional sweep, patches ordered by
- *                     progress counters in HBM (default); 0: one launch per tile wavefront
+ *   "mode"         2: persistent sweep kernel, ONE launch per sweep-iteration: patches ordered by
+ *                     progress counters in HBM, the next directional sweep starts on the patches the
+ *                     previous one has finished (default); 1: same kernel, one launch per directional
+ *                     sweep; 0: one launch per tile wavefront.  All three give bit-identical fields.
  *                  (env TTCR_FSM_MODE overrides the default at grid creation)
  *   "tt_from_rp"   1: receiver traveltimes are integrated along the ray traced back through the
  *                     traveltime field (replaces setTraveltimeFromRaypath(bool), ttcr/Grid3D.h, and the

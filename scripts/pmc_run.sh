@@ -17,10 +17,14 @@ for C in ("FETCH_SIZE","WRITE_SIZE"):
     tot=collections.Counter(); cnt=collections.Counter()
     for f in glob.glob("$OUT/**/*${TAG}_%s*counter_collection.csv"%C, recursive=True):
         for r in csv.DictReader(open(f)):
-            k=r.get("Kernel_Name","?")[:60]
+            k=r.get("Kernel_Name","?")
             tot[k]+=float(r["Counter_Value"]); cnt[k]+=1
+    with open("$OUT/${TAG}_%s_summary.csv"%C, "w") as o:
+        o.write("Kernel_Name,Dispatches,Counter,Sum_KB,PerDispatch_KB\n")
+        for k,v in tot.most_common(8):
+            o.write('"%s",%d,%s,%.1f,%.1f\n'%(k,cnt[k],C,v,v/cnt[k]))
     for k,v in tot.most_common(3):
-        print(C, k, "dispatches", cnt[k], "sum", v, "per-dispatch", v/cnt[k])
+        print(C, k[:60], "dispatches", cnt[k], "sum", v, "per-dispatch", v/cnt[k])
 PY
 find $OUT -name "*counter_collection.csv" -size +3M -delete
 find $OUT -name "*.db" -delete

@@ -40,15 +40,17 @@ def test_fullsize_properties(n):
     niter = g.get_niter()
     assert niter == 2
     assert np.all(np.isfinite(T)) and T.min() >= 0.0
-    # (a) the two sweep drivers (persistent kernel / one launch per tile wavefront) are two different
-    #     linear extensions of the same Gauss-Seidel order: bit-identical fields
-    g0, _, _ = gradient_grid(n)
-    g0.set_option("mode", 0)
-    tt0 = g0.raytrace(src, rcv, slowness=s)
-    assert g0.get_niter() == niter
-    np.testing.assert_array_equal(tt0, tt)
-    np.testing.assert_array_equal(g0.get_grid_traveltimes(), T)
-    del g0
+    # (a) the three sweep drivers (one launch per iteration with overlapping sweeps [default] / one
+    #     launch per sweep / one launch per tile wavefront) are different linear extensions of the
+    #     same Gauss-Seidel order: bit-identical fields
+    for mode in (0, 1):
+        g0, _, _ = gradient_grid(n)
+        g0.set_option("mode", mode)
+        tt0 = g0.raytrace(src, rcv, slowness=s)
+        assert g0.get_niter() == niter
+        np.testing.assert_array_equal(tt0, tt)
+        np.testing.assert_array_equal(g0.get_grid_traveltimes(), T)
+        del g0
     # (b) linearity: scaling the slowness by a power of two scales every traveltime exactly
     g.raytrace(src, rcv, slowness=4.0 * s)
     np.testing.assert_array_equal(g.get_grid_traveltimes(), 4.0 * T)

@@ -13,7 +13,8 @@ from gpu_util import run_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[(1, 0), (1, 1), (0, 0)], ids=["persistent", "persistent+skip", "wavefront-launches"],
+@pytest.fixture(params=[(1, 0), (1, 1), (0, 0), (2, 0), (2, 1)],
+                ids=["persistent", "persistent+skip", "wavefront-launches", "overlapped-sweeps", "overlapped-sweeps+skip"],
                 autouse=True)
 def sweep_mode(request, monkeypatch):
     """every parity test runs with each sweep driver (ttcr_fsm_set_option "mode" / "skip")"""

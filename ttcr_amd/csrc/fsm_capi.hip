@@ -89,7 +89,8 @@ class GridBase {
     int ttrp = 0, interp_vel = 0;  // traveltime from raypath (ttcr/Grid3D.h:493-496), processVel
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
     int skip = 0;  // persistent kernel: 1 = skip chunks whose read set did not change (exact); see DESIGN.md
-    int mode = 1;  // 1: persistent kernel, one launch per sweep (default); 0: one launch per tile wavefront
+    int mode = 2;  // 2: persistent kernel, one launch per sweep-iteration, sweeps overlap (default);
+                   // 1: persistent kernel, one launch per sweep; 0: one launch per tile wavefront
     Timing timing;
 };
 
@@ -253,7 +254,7 @@ class GridT : public GridBase {
         n_patches = (int)order.size();
         d_order.reserve(order.size());
         HIP_CHECK(hipMemcpy(d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        d_sync.reserve(2 + (size_t)n_patches * n_slots);
+        d_sync.reserve(2 + (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4));
     }
 
     template <int DIM, int H>
@@ -295,6 +296,26 @@ class GridT : public GridBase {
         pa.skip = skip;
         const dim3 block(C::PJ * C::PK), grid((unsigned)n_patches * batch);
         const int ndir = DIM == 3 ? 8 : 4;
+        if (mode == 2) {
+            // whole iteration in one launch: tickets direction-major, sweeps overlap at their ends
+            pa.ssh = d_ssh.p;
+            pa.ssh_stride = ssh_stride;
+            pa.dir = 0;
+            a.rf = a.rj = a.rk = a.rev = 0;
+            a.s_sheared = nullptr;
+            pa.timeout_ticks = 1000000000ull;  // 10 s: a unit may wait for most of the previous sweep
+            const dim3 gridx((unsigned)n_patches * batch * ndir);
+            HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
+            HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
+            if (skip)
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
+            else
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+        pa.ssh = nullptr;
+        pa.ssh_stride = 0;
         static const int RX2[4] = {0, 1, 1, 0}, RZ2[4] = {0, 0, 1, 1};
         for (int d = 0; d < ndir; ++d) {
             int fam;
@@ -313,9 +334,9 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
             if (skip)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV><<<grid, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, false><<<grid, block, 0, stream>>>(pa);
             else
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV><<<grid, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, false><<<grid, block, 0, stream>>>(pa);
         }
         HIP_CHECK(hipGetLastError());
     }
@@ -577,12 +598,12 @@ class GridT : public GridBase {
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
 
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
-    bool persistent_now() const { return mode == 1 || stage == 1; }
+    bool persistent_now() const { return mode >= 1 || stage == 1; }
 
     void issue_sweeps(int batch) {
         if (stage == 1) {
             if (dim == 3) launch_sweeps_persistent<3, 2>(batch); else launch_sweeps_persistent<2, 2>(batch);
-        } else if (mode == 1) {
+        } else if (mode >= 1) {
             if (dim == 3) launch_sweeps_persistent<3, 1>(batch); else launch_sweeps_persistent<2, 1>(batch);
         } else {
             if (dim == 3) launch_sweeps<3>(batch); else launch_sweeps<2>(batch);
@@ -616,7 +637,7 @@ class GridT : public GridBase {
         } else {
             issue_sweeps(batch);
         }
-        timing.launches += persistent_now() ? (long long)ndir : (long long)ndir * n_launch;
+        timing.launches += mode == 2 ? 1 : persistent_now() ? (long long)ndir : (long long)ndir * n_launch;
     }
 
     // One batch: sources src_ids[b] solved concurrently, source b in slot slot_ids[b].
@@ -730,7 +751,7 @@ class GridT : public GridBase {
                     HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)(s2 / NS) * n_bricks, 0x7f, n_bricks * sizeof(int), stream));
             }
         }
-        const bool was_persistent = mode == 1 || weno;
+        const bool was_persistent = mode >= 1 || weno;
         stage = 0;
         HIP_CHECK(hipEventRecord(ev1, stream));
         HIP_CHECK(hipEventSynchronize(ev1));
@@ -738,7 +759,7 @@ class GridT : public GridBase {
             unsigned long long h[8];
             HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
             HIP_CHECK(hipMemset(d_prof.p, 0, sizeof(h)));
-            if (mode == 1) {
+            if (mode >= 1) {
                 const double nb_ = (double)std::max<unsigned long long>(h[7], 1);
                 std::fprintf(stderr, "[ttcr_amd prof] chunks %llu  per chunk (us): issue %.2f  wait %.2f  stage %.2f  march %.2f  publish %.2f\n",
                              h[7], h[0] * 0.01 / nb_, h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_, h[4] * 0.01 / nb_);

@@ -472,6 +472,9 @@ struct PersistArgs {
     int nbf, nbj, nbk;        // bricks of FSM_BRICK^3 nodes (natural coordinates)
     int dir, ndir;            // direction index within the iteration, directions per iteration
     int skip;                 // 0: evaluate every chunk
+    // whole-iteration launch (XS): all directions in one grid, sheared copies by family
+    const T* ssh;             // [families][ssh_stride]
+    size_t ssh_stride;
 };
 
 
@@ -646,7 +649,13 @@ __device__ __forceinline__ void st_sc1(Pack<double, 2>* p, Pack<double, 2> x) {
     st_sc1(&p->v[1], x.v[1]);
 }
 
-template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS>
+// XS = true: ONE launch per sweep-iteration.  Tickets run direction-major, so the patches of sweep
+// d+1 start while sweep d is still draining its last anti-diagonals: a unit (d, patch) begins as
+// soon as sweep d-1 has finished every patch that owns a column within 2H of its own columns
+// (those are all the writers of what it reads and all the readers of what it writes).  Every
+// traveltime access is then an agent-scope (sc1) access: values written by another XCD within
+// the same launch must come from memory, not from a stale L1 line or a dirty remote L2.
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS>
 __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
     using P = Pack<T, NS>;
     constexpr int NT = PJ * PK;
@@ -674,14 +683,36 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
     __syncthreads();
     const int ticket = s_ticket;
-    const int pidx = ticket / pa.batch, z = ticket - pidx * pa.batch;
-    if (pidx >= pa.n_patches) return;
+    const int per_dir = pa.n_patches * pa.batch;
+    const int dir = XS ? ticket / per_dir : pa.dir;
+    const int trem = XS ? ticket - dir * per_dir : ticket;
+    const int pidx = trem / pa.batch, z = trem - pidx * pa.batch;
+    if (XS ? dir >= pa.ndir : pidx >= pa.n_patches) return;
     const uint32_t tile = pa.order[pidx];
     const int TJ = tile & 0xffffu, TK = tile >> 16;
     const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
     const int npj = a.g.npj;
-    int* prog = pa.sync + 2 + (size_t)z * pa.n_patches;
+    int* prog = pa.sync + 2 + ((size_t)(XS ? dir : 0) * pa.batch + z) * pa.n_patches;
     int* my_prog = prog + (TK * npj + TJ);
+    // sweep direction: 3-D bits (F, J, K); 2-D order (+x+z, -x+z, -x-z, +x-z) with J = x, F = z
+    int rf, rj, rk, rev;
+    const T* __restrict__ Sg;
+    if (XS) {
+        int fam;
+        if (IS3D) {
+            rf = dir & 1; rj = (dir >> 1) & 1; rk = (dir >> 2) & 1;
+            rev = rk;
+            fam = (rf ^ rk) | ((rj ^ rk) << 1);
+        } else {
+            rj = (dir == 1) | (dir == 2); rf = dir >> 1; rk = 0;
+            rev = rj;
+            fam = rf ^ rj;
+        }
+        Sg = pa.ssh + (size_t)fam * pa.ssh_stride;
+    } else {
+        rf = a.rf; rj = a.rj; rk = a.rk; rev = a.rev;
+        Sg = a.s_sheared;
+    }
     const int grp = a.slots[z];   // slot (NS == 1) or slot group (NS == 2)
     if (grp < 0) {  // converged source(s): nothing to do, but never leave a waiter hanging
         if (tid == 0) __hip_atomic_store(my_prog, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -698,7 +729,6 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     const T INF = real_traits<T>::inf();
     const P PINF = pack_fill<T, NS>(INF);
     const int lm = NS == 1 ? 1 : a.lmask[z];   // sources of the group still being solved
-    const int rf = a.rf, rj = a.rj, rk = a.rk;
     const int sf = rf ? -1 : 1;
 
     // march identity of this thread: one column
@@ -713,9 +743,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     const int variant = a.variant;
     const uint32_t* __restrict__ Fz = a.frozen + (size_t)grp * NS * a.mask_words;   // + l * mask_words
     const int* bb = a.bbox + 6 * grp * NS;                                           // + 6 * l
-    const T* __restrict__ Sg = a.s_sheared;
     const int M = a.g.M;
-    const size_t sbase = (size_t)(a.rev ? NK - 1 - kp : kp) * M * NJ + (a.rev ? NJ - 1 - jp : jp);
+    const size_t sbase = (size_t)(rev ? NK - 1 - kp : kp) * M * NJ + (rev ? NJ - 1 - jp : jp);
 
     // LDS row (without the level) of the column at patch-relative (cj, ck), halo included
     auto lds_row = [&](int cj, int ck) { return (IS3D ? (ck + H) * RJ + cj + H : cj + H) * RS; };
@@ -820,7 +849,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;
         const int eb = eoff + NF - 1 < C - 1 ? eoff + NF - 1 : C - 1;
         int x = L - kp;  // i' + j' at level L
-        x = a.rev ? NF + NJ - 2 - x : x;
+        x = rev ? NF + NJ - 2 - x : x;
         x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
         x = x < 0 ? x + M : x;
 #pragma unroll
@@ -828,13 +857,13 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             T v = 0;
             if (q >= ea && q <= eb) v = Sg[sbase + (size_t)x * NJ];
             sv[q] = v;
-            if (a.rev) { x = x == 0 ? M - 1 : x - 1; } else { x = x + 1 == M ? 0 : x + 1; }
+            if (rev) { x = x == 0 ? M - 1 : x - 1; } else { x = x + 1 == M ? 0 : x + 1; }
         }
         const int sL = sf * L;
 #pragma unroll
         for (int it = 0; it < NOWN + NHI; ++it) {
             P v = PINF;
-            if ((unsigned)(L + ipb[it]) < (unsigned)NF) v = Tg[abase[it] + sL];
+            if ((unsigned)(L + ipb[it]) < (unsigned)NF) v = XS ? ld_sc1(Tg + (abase[it] + sL)) : Tg[abase[it] + sL];
             tv[it] = v;
         }
     };
@@ -842,7 +871,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     // dirty-brick tracking: sigma = global sweep number (1-based); the same chunk was last evaluated
     // at sigma - ndir.  If no brick of its read set changed at or after that sweep (or ever, in the
     // first iteration) the chunk would reproduce the values that are already there: skip it.
-    const int sigma = SKIP ? pa.ndir * pa.iter_ptr[0] + pa.dir + 1 : 0;
+    const int sigma = SKIP ? pa.ndir * pa.iter_ptr[0] + dir + 1 : 0;
     const int thr = sigma - pa.ndir > 0 ? sigma - pa.ndir : 0;
     int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;   // one stamp set per group
     // natural J / K extent of the read set (own + halo columns), fixed for the whole patch
@@ -871,6 +900,40 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     bool have_prev = false;   // carry[] is valid (the previous chunk was evaluated)
     bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
+    if (XS && dir > 0) {
+        // previous sweep of this iteration: wait for the patches (of ITS oriented partition) that own
+        // a column within 2H of ours -- at most 3 x 3 of them, one lane each
+        const int pd = dir - 1;
+        int prj, prk;
+        if (IS3D) { prj = (pd >> 1) & 1; prk = (pd >> 2) & 1; } else { prj = (pd == 1) | (pd == 2); prk = 0; }
+        int ja = j0 - 2 * H, jb = jmaxp + 2 * H, ka = k0 - 2 * H, kb = kmaxp + 2 * H;
+        ja = ja < 0 ? 0 : ja; jb = jb > NJ - 1 ? NJ - 1 : jb;
+        ka = ka < 0 ? 0 : ka; kb = kb > NK - 1 ? NK - 1 : kb;
+        // oriented (this sweep) -> natural -> oriented (previous sweep)
+        int ja2 = (rj != prj) ? NJ - 1 - jb : ja, jb2 = (rj != prj) ? NJ - 1 - ja : jb;
+        int ka2 = (rk != prk) ? NK - 1 - kb : ka, kb2 = (rk != prk) ? NK - 1 - ka : kb;
+        const int tja = ja2 / PJ, ntj = jb2 / PJ - tja + 1;
+        const int tka = IS3D ? ka2 / PK : 0, ntk = IS3D ? kb2 / PK - tka + 1 : 1;
+        if (tid < 16) {
+            const int ia = tid & 3, ib = tid >> 2;
+            if (ia < ntj && ib < ntk) {
+                const int* pp = pa.sync + 2 + ((size_t)pd * pa.batch + z) * pa.n_patches + ((tka + ib) * npj + tja + ia);
+                const unsigned long long t0 = wall_clock64();
+                int spins = 0;
+                while (__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0x3fffffff) {
+                    if ((++spins & 63) == 0) {
+                        if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        if (wall_clock64() - t0 > pa.timeout_ticks) {
+                            __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (!SKIP) { issue_static(Lc); pref_for = Lc; }
     for (; Lc <= Le; Lc += C) {
         const int L0 = Lc;
@@ -959,7 +1022,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         P xv = PINF;
         if (H == 2 && (unsigned)(L0 + xipb) < (unsigned)NF) {
             const P* src = Tg + (xabase + sf * L0);
-            if (x_up) xv = ld_sc1(src); else xv = *src;
+            if (x_up || XS) xv = ld_sc1(src); else xv = *src;
         }
         // (3) static part (prefetched) into LDS: levels L0+H..L0+C+H-1 of own + downwind halo columns;
         //     own column q < 2H comes from the previous chunk (H results, H old values)
@@ -973,7 +1036,10 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             for (int q = 0; q < 2 * H; ++q) {
                 const int ip = L0 - H + q - jp - kp;
                 P v = PINF;
-                if (col_ok && (unsigned)ip < (unsigned)NF) v = Tg[colbase + (rf ? NF - 1 - ip : ip)];
+                if (col_ok && (unsigned)ip < (unsigned)NF) {
+                    const P* src = Tg + (colbase + (rf ? NF - 1 - ip : ip));
+                    v = XS ? ld_sc1(src) : *src;
+                }
                 carry[q] = v;
             }
             have_prev = true;
@@ -1120,7 +1186,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                     const int cj = rid % PJ, ck = rid / PJ;
                     P* dst = Tg + (abase[it] + sf * (L0 - H));
                     const P v = Tt[lrow[it] - H];
-                    if (cj >= PJ - H || (IS3D && ck >= PK - H)) st_sc1(dst, v); else *dst = v;
+                    if (XS || cj >= PJ - H || (IS3D && ck >= PK - H)) st_sc1(dst, v); else *dst = v;
                 }
             }
         }
