@@ -58,6 +58,21 @@ def cpu_baseline(n=256, n_src=3):
            "kind": "port",
            "sample": f"{n_src} sources (first of the mt19937_64(12345) set) on the {n}^3-node gradient model, fp32, "
                      f"{iters} sweep-iterations, {el:.1f} s on 1 of {os.cpu_count()} host cores"}
+    # (ii) source-parallel on the host cores, one source per thread like the reference's n_threads
+    #      pool (ttcr/Grid3D.h:821-832); ctypes releases the GIL for the duration of a solve
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        nthr = max(1, min(os.cpu_count() or 1, 64))
+        many = cases.mt_sources(64)[:nthr]
+        t = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nthr) as ex:
+            its = list(ex.map(lambda p: O.solve3d(np.float32, (n - 1,) * 3, dx, (0, 0, 0), s, [p])["niter"], many))
+        el = time.perf_counter() - t
+        out["all_cores_value"] = round(n ** 3 * sum(its) / el / 1e6, 3)
+        out["all_cores"] = nthr
+        out["all_cores_sample"] = f"{nthr} sources, one per thread, {n}^3 nodes, {sum(its)} sweep-iterations in {el:.1f} s"
+    except Exception as e:
+        out["all_cores_error"] = str(e)[:200]
     # the unmodified compiled reference, when its build travelled with the tree (kind would be "reference")
     try:
         if O.have_ref():

@@ -58,7 +58,9 @@ int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
 
 /* Replaces: Grid2Drnfs<T,uint32_t,sxz<T>>::Grid2Drnfs (ttcr/Grid2Drnfs.h:84-95)
  *           Grid2Drcfs<...>::Grid2Drcfs               (ttcr/Grid2Drcfs.h:45-58)
- * as constructed in src/ttcrpy/rgrid.pyx:2962-2966. */
+ * as constructed in src/ttcrpy/rgrid.pyx:2962-2966.  rotated_template: Grid2Drn::sweep45
+ * (ttcr/Grid2Drn.h:756-794) after every sweep of the first-order solver when dx == dz and weno is
+ * off (ttcr/Grid2Drnfs.h:277-286); ignored otherwise, like the reference does. */
 int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncz,
                       double dx, double dz, double xmin, double zmin, double eps, int maxit, int weno,
                       int rotated_template, int n_slots, int device);

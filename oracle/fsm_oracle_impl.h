@@ -909,6 +909,53 @@ static void SFX(init2d)(const SFX(fsm_grid2d) * g, const REAL* s, REAL* T, unsig
     }
 }
 
+/* Stencil rotated by pi/4: Grid2Drn::update_node45 (ttcr/Grid2Drn.h:957-1015).  a = min over the
+ * (+1,+1)/(-1,-1) diagonal, b = min over the (+1,-1)/(-1,+1) diagonal, neighbours outside the
+ * grid count as max(); fh = sqrt(2) s dx (double literal: product formed in double, rounded once). */
+static void SFX(update_node45)(REAL* T, const REAL* s, REAL dx, size_t nnx, size_t nnz, size_t i, size_t j) {
+    const size_t ncx = nnx - 1, ncz = nnz - 1;
+    REAL a, b, t;
+    if (i == 0) {
+        a = j != ncz ? T[(i + 1) * nnz + j + 1] : REAL_MAX;
+    } else if (i == ncx) {
+        a = j != 0 ? T[(i - 1) * nnz + j - 1] : REAL_MAX;
+    } else {
+        a = j != ncz ? T[(i + 1) * nnz + j + 1] : REAL_MAX;
+        t = j != 0 ? T[(i - 1) * nnz + j - 1] : REAL_MAX;
+        a = a < t ? a : t;
+    }
+    if (i == 0) {
+        b = j != 0 ? T[(i + 1) * nnz + j - 1] : REAL_MAX;
+    } else if (i == ncx) {
+        b = j != ncz ? T[(i - 1) * nnz + j + 1] : REAL_MAX;
+    } else {
+        b = j != 0 ? T[(i + 1) * nnz + j - 1] : REAL_MAX;
+        t = j != ncz ? T[(i - 1) * nnz + j + 1] : REAL_MAX;
+        b = b < t ? b : t;
+    }
+    REAL fh = 1.414213562373095 * s[i * nnz + j] * dx;
+    if (FABS(a - b) >= fh)
+        t = (a < b ? a : b) + fh;
+    else
+        t = 0.5 * (a + b + sqrt(2. * fh * fh - (a - b) * (a - b)));
+    if (t < T[i * nnz + j]) T[i * nnz + j] = t;
+}
+
+/* Grid2Drn::sweep45 (ttcr/Grid2Drn.h:756-794): the four orderings of sweep2d, rotated stencil */
+static void SFX(sweep2d_45)(REAL* T, const REAL* s, const unsigned char* frozen, REAL dx, size_t nnx, size_t nnz) {
+    static const int RI[4] = {0, 1, 1, 0};
+    static const int RJ[4] = {0, 0, 1, 1};
+    for (int dir = 0; dir < 4; ++dir) {
+        for (size_t ii = 0; ii < nnx; ++ii) {
+            const size_t i = RI[dir] ? nnx - 1 - ii : ii;
+            for (size_t jj = 0; jj < nnz; ++jj) {
+                const size_t j = RJ[dir] ? nnz - 1 - jj : jj;
+                if (!frozen[i * nnz + j]) SFX(update_node45)(T, s, dx, nnx, nnz, i, j);
+            }
+        }
+    }
+}
+
 /* Grid2Drcfs::setSlowness, ttcr/Grid2Drcfs.h:98-138 (cells z-fastest: c = i*ncz + j).
  * Summation order of the reference: (i,j) (i,j-1) (i-1,j) (i-1,j-1). */
 void SFX(fsm_cells_to_nodes2d)(size_t ncx, size_t ncz, const REAL* sc, REAL* sn) {
@@ -933,10 +980,12 @@ void SFX(fsm_cells_to_nodes2d)(size_t ncx, size_t ncz, const REAL* sc, REAL* sn)
         }
 }
 
-/* Grid2Drnfs::raytrace driver, ttcr/Grid2Drnfs.h:198-299, weno3 == false,
- * rotated_template == false branch (:277-297). */
+/* Grid2Drnfs::raytrace driver, ttcr/Grid2Drnfs.h:198-299.  `weno` carries two flags: bit 0 = weno3,
+ * bit 1 = rotated_template (sweep45 after every sweep of the first-order solver when dx == dz and
+ * weno3 is off, :277-286; ignored otherwise, like the reference does). */
 int SFX(fsm_solve2d)(const SFX(fsm_grid2d) * g, const REAL* s, int n_src, const REAL* src,
-                     const REAL* t0, REAL eps, int maxit, int weno, REAL* T, REAL* change_hist, int* niterw_out) {
+                     const REAL* t0, REAL eps, int maxit, int weno_flags, REAL* T, REAL* change_hist, int* niterw_out) {
+    const int weno = weno_flags & 1, rotated = (weno_flags >> 1) & 1;
     const size_t N = g->nnx * g->nnz;
     REAL epsilon = eps;
     epsilon *= (REAL)N;
@@ -950,6 +999,7 @@ int SFX(fsm_solve2d)(const SFX(fsm_grid2d) * g, const REAL* s, int n_src, const 
     const int xz = !(g->dx == g->dz);
     while (change >= epsilon && niter < maxit) {
         SFX(sweep2d)(T, s, frozen, g->dx, g->dz, xz, g->nnx, g->nnz);
+        if (rotated && !weno && !xz) SFX(sweep2d_45)(T, s, frozen, g->dx, g->nnx, g->nnz);
         change = 0.0;
         for (size_t n = 0; n < N; ++n) {
             REAL dt = FABS(times[n] - T[n]);

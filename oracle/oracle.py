@@ -206,8 +206,8 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
 
 
 def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-            cell_slowness=False, rcv=None, weno=False):
-    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (rotated_template=False)."""
+            cell_slowness=False, rcv=None, weno=False, rotated=False):
+    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (rotated: sweep45 after every sweep, ttcr/Grid2Drnfs.h:277-286)."""
     dt = np.dtype(dtype)
     sfx, ct, _, G2 = _TYPES[dt]
     L = lib()
@@ -233,7 +233,8 @@ def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, max
     hist = np.zeros(2 * maxit, dtype=dt)
     nw = C.c_int(0)
     niter = getattr(L, "fsm_solve2d_" + sfx)(C.byref(g), _p(sn), C.c_int(nsrc), _p(src), _p(t0), ct(eps),
-                                             C.c_int(maxit), C.c_int(int(weno)), _p(T), _p(hist), C.byref(nw))
+                                             C.c_int(maxit), C.c_int(int(bool(weno)) | (2 if rotated else 0)), _p(T), _p(hist),
+                                             C.byref(nw))
     out = dict(tt=T, niter=int(niter), niterw=int(nw.value), change=hist[:niter].copy(),
                changew=hist[maxit:maxit + nw.value].copy(), node_slowness=sn)
     if rcv is not None:

@@ -211,6 +211,11 @@ def _rcv2(nc, dx, dz, origin, rng):
     return np.vstack([on, off, mixed, hi[None, :], lo[None, :]])
 
 
+def rot_ok(c):
+    """Cases run with rotated_template=True as well (sweep45 only exists for 2-D square cells)"""
+    return c["dim"] == 2 and c["dx"] == c["dz"]
+
+
 def cases2d():
     rng = np.random.default_rng(4048)
     out = []

@@ -10,6 +10,8 @@ For every case of tests/cases.py and both dtypes the file holds the reference's 
   <case>/<dtype>/rp_tt_rcv, rpv_tt_rcv   receiver traveltimes of the weno + tt_from_rp solve
                           (Grid3Drn::getTraveltimeFromRaypath), without / with interp_vel; *_error = 1 when
                           the reference throws "going outside grid" for the case
+  <case>/<dtype>/rot_tt, rot_niter, rot_tt_rcv   first-order solve with rotated_template=True (sweep45 after
+                          every sweep, ttcr/Grid2Drnfs.h:277-286), for the cases of cases.rot_ok()
   <case>/<dtype>/weno_*   the same four outputs (+ niterw) of the two-stage weno=True solve, for the
                           cases of cases.weno_ok()
 and the inputs  <case>/slowness (float64; cast to the dtype under test), so that the
@@ -48,6 +50,13 @@ def main():
             out[key + "/niter"] = np.int32(r["niter"])
             out[key + "/tt_rcv"] = r["tt_rcv"]
             print(key, "niter", r["niter"])
+            if cases.rot_ok(c):
+                r = O.ref_solve2d(dt, c["ncells"], c["dx"], c["dz"], c["origin"], c["slowness"], c["src"],
+                                  c["t0"], cell_slowness=c["cell_slowness"], rcv=c["rcv"], rotated=True)
+                out[key + "/rot_tt"] = r["tt"]
+                out[key + "/rot_niter"] = np.int32(r["niter"])
+                out[key + "/rot_tt_rcv"] = r["tt_rcv"]
+                print(key, "rotated niter", r["niter"])
             if cases.weno_ok(c):
                 # two-stage solve with the third-order WENO stage (weno=True, the ttcrpy default)
                 if c["dim"] == 3:

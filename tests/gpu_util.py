@@ -4,7 +4,7 @@ import numpy as np
 import ttcr_amd
 
 
-def grid_from_case(c, dt, n_threads=1, weno=0):
+def grid_from_case(c, dt, n_threads=1, weno=0, rotated=0):
     nc = c["ncells"]
     o = c["origin"]
     if c["dim"] == 3:
@@ -20,7 +20,7 @@ def grid_from_case(c, dt, n_threads=1, weno=0):
         x = o[0] + np.arange(nc[0] + 1) * c["dx"]
         z = o[1] + np.arange(nc[1] + 1) * c["dz"]
         g = ttcr_amd.Grid2d(x, z, n_threads=n_threads, cell_slowness=c["cell_slowness"], method="FSM",
-                            tt_from_rp=0, weno=weno, dtype=dt)
+                            tt_from_rp=0, weno=weno, rotated_template=rotated, dtype=dt)
         s = np.asarray(c["slowness"], dtype=np.float64).reshape(g.shape)
     return g, s
 
@@ -30,8 +30,8 @@ def source_array(c):
     return np.hstack([np.asarray(c["t0"], dtype=np.float64)[:, None], c["src"]])
 
 
-def run_case(c, dt, weno=0):
-    g, s = grid_from_case(c, dt, weno=weno)
+def run_case(c, dt, weno=0, rotated=0):
+    g, s = grid_from_case(c, dt, weno=weno, rotated=rotated)
     tt_rcv = g.raytrace(source_array(c), c["rcv"], slowness=s, aggregate_src=True)
     if c["dim"] == 3:
         field = g.get_grid_traveltimes().flatten("F")

@@ -61,7 +61,8 @@ def test_argument_validation_happens_before_the_device(lib):
     # the WENO stencil needs >= 3 cells per axis
     assert lib.ttcr_fsm3d_create(C.byref(h), 0, 0, 4, 2, 4, 1.0, 0., 0., 0., 1e-5, 50, 1, 1, 0, -1) == _lib.ERR_VALUE
     assert "weno" in _lib.last_error()
-    assert lib.ttcr_fsm2d_create(C.byref(h), 0, 0, 4, 4, 1.0, 1.0, 0., 0., 1e-5, 50, 0, 1, 1, -1) == _lib.ERR_UNSUPPORTED
+    assert lib.ttcr_fsm2d_create(C.byref(h), 0, 0, 4, 2, 1.0, 1.0, 0., 0., 1e-5, 50, 1, 0, 1, -1) == _lib.ERR_VALUE
+    assert lib.ttcr_fsm2d_create(C.byref(h), 0, 0, 4, 4, 1.0, -1.0, 0., 0., 1e-5, 50, 0, 1, 1, -1) == _lib.ERR_VALUE
 
 
 def test_product_does_not_import_the_oracle():

@@ -42,6 +42,21 @@ def test_oracle_weno_matches_golden(oracle, golden, c, dt):
     np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/weno_tt_rcv"])
 
 
+ROT = [(c, dt) for c, dt in ALL if cases.rot_ok(c)]
+
+
+@pytest.mark.parametrize("c,dt", ROT, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in ROT])
+def test_oracle_rotated_template_matches_golden(oracle, golden, c, dt):
+    """rotated_template=True: sweep45 (stencil rotated by pi/4) after every first-order sweep"""
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    r = oracle.solve2d(dt, c["ncells"], c["dx"], c["dz"], c["origin"], golden[f"{c['name']}/slowness"], c["src"],
+                       c["t0"], cell_slowness=c["cell_slowness"], rcv=c["rcv"], rotated=True)
+    assert r["niter"] == int(golden[key + "/rot_niter"])
+    np.testing.assert_array_equal(r["tt"], golden[key + "/rot_tt"])
+    np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/rot_tt_rcv"])
+    assert not np.array_equal(r["tt"], golden[key + "/tt"])  # the stage really changes the field
+
+
 RP = [(c, dt) for c, dt in ALL if cases.rp_ok(c)]
 
 

@@ -41,6 +41,20 @@ def test_restatement_bit_exact_vs_reference(O, c, dt, weno):
     np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_rotated_template_bit_exact_vs_reference(O, dt):
+    """sweep45 on fresh random media, several sizes and source positions (on-node, off-node, corner, multi-point)"""
+    rng = np.random.default_rng(3)
+    for ncx, ncz in ((20, 30), (33, 17), (1, 9)):
+        nn = (ncx + 1) * (ncz + 1)
+        s = rng.uniform(0.25, 1.0, nn)
+        for src in ([[0.15, 2.05]], [[0.5, 3.0]], [[0.0, 0.0]], [[0.2, 0.7], [0.4, 3.0]]):
+            kw = dict(dtype=dt, ncells=(ncx, ncz), dx=0.5, dz=0.5, origin=(0, 0), slowness=s, src=src, rotated=True)
+            a, b = O.solve2d(**kw), O.ref_solve2d(**kw)
+            assert a["niter"] == b["niter"]
+            np.testing.assert_array_equal(a["tt"], b["tt"])
+
+
 def test_reference_rejects_outside_point(O):
     with pytest.raises(RuntimeError, match="outside grid"):
         O.ref_solve3d(np.float64, (4, 4, 4), 1.0, (0, 0, 0), np.ones(125), [[5.0, 1.0, 1.0]])

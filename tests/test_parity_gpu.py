@@ -55,6 +55,52 @@ def test_hip_weno_matches_golden_bit_exact(golden, c, dt):
     np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/weno_tt_rcv"])
 
 
+ROT = [(c, dt) for c, dt in ALL if cases.rot_ok(c)]
+
+
+@pytest.mark.parametrize("c,dt", ROT, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in ROT])
+def test_hip_rotated_template_matches_golden_bit_exact(golden, c, dt):
+    """rotated_template=True: Grid2Drn::sweep45 after every first-order sweep (ttcr/Grid2Drnfs.h:277-286)"""
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    c = dict(c, slowness=golden[f"{c['name']}/slowness"])
+    r = run_case(c, dt, rotated=1)
+    assert r["niter"] == int(golden[key + "/rot_niter"])
+    np.testing.assert_array_equal(r["tt"], golden[key + "/rot_tt"])
+    np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/rot_tt_rcv"])
+
+
+@pytest.mark.parametrize("dt,shape", [(np.float32, (1201, 150)), (np.float64, (600, 210)), (np.float32, (254, 700)),
+                                      (np.float64, (511, 300))],
+                         ids=["f32-2strips", "f64-2strips", "f32-1strip-256", "f64-2strips-edge"])
+def test_hip_rotated_template_strips_vs_oracle(oracle, dt, shape):
+    """grids wider than one column strip of the sweep45 kernel (1022 / 510 columns), random medium,
+    off-node source, two slots solved concurrently: bit-exact vs the CPU oracle"""
+    import ttcr_amd
+
+    nx, nz = shape
+    rng = np.random.default_rng(77)
+    s = rng.uniform(0.25, 1.0, shape)
+    x, z = np.arange(nx) * 0.25, 1.0 + np.arange(nz) * 0.25
+    g = ttcr_amd.Grid2d(x, z, n_threads=2, cell_slowness=0, method="FSM", weno=0, rotated_template=1, dtype=dt)
+    srcs = np.array([[x[-1] * 0.71, 1.0 + 3.3], [x[3], z[5]]])
+    rcv = np.array([[0.0, 1.0], [x[-1], z[-1]], [x[7] + 0.1, z[9] + 0.05]])
+    g.raytrace(np.repeat(srcs, 3, axis=0), np.tile(rcv, (2, 1)), slowness=s)
+    for k in range(2):
+        r = oracle.solve2d(dt, (nx - 1, nz - 1), g.dx, g.dz, (x[0], z[0]), s.astype(dt).ravel(), [srcs[k]], rotated=True)
+        assert g.get_niter(k) == r["niter"]
+        np.testing.assert_array_equal(g.get_grid_traveltimes(k).ravel(), r["tt"])
+
+
+def test_hip_rotated_template_ignored_like_the_reference(golden):
+    """with weno=True or dx != dz the reference never calls sweep45: the flag changes nothing"""
+    for name, weno in (("random2d_xz", 0), ("grad2d_65_off", 1)):
+        c = next(c for c in cases.cases2d() if c["name"] == name)
+        c = dict(c, slowness=golden[f"{name}/slowness"])
+        a, b = run_case(c, np.float32, weno=weno, rotated=1), run_case(c, np.float32, weno=weno, rotated=0)
+        np.testing.assert_array_equal(a["tt"], b["tt"])
+        assert (a["niter"], a["niterw"]) == (b["niter"], b["niterw"])
+
+
 RP = [(c, dt) for c, dt in ALL if cases.rp_ok(c)]
 
 

@@ -149,8 +149,7 @@ __device__ __forceinline__ double update3(double ax, double ay, double az, doubl
 
 // ---- 2-D local solvers ---------------------------------------------------------------------
 // Grid2Drn::update_node, ttcr/Grid2Drn.h:945-950 (square cells). a: x-axis minimum, b: z-axis.
-__device__ __forceinline__ float update2(float a, float b, float s, float dx) {
-    const float fh = s * dx;
+__device__ __forceinline__ float update2_fh(float a, float b, float fh) {
     const float d = a - b;
     if (__builtin_fabsf(d) >= fh) return (a < b ? a : b) + fh;
     const float d2 = d * d;
@@ -159,11 +158,16 @@ __device__ __forceinline__ float update2(float a, float b, float s, float dx) {
     const float sab = a + b;
     return (float)(0.5 * ((double)sab + __builtin_sqrt(disc)));
 }
-__device__ __forceinline__ double update2(double a, double b, double s, double dx) {
-    const double fh = s * dx;
+__device__ __forceinline__ double update2_fh(double a, double b, double fh) {
     if (__builtin_fabs(a - b) >= fh) return (a < b ? a : b) + fh;
     return 0.5 * (a + b + __builtin_sqrt(2. * fh * fh - (a - b) * (a - b)));
 }
+__device__ __forceinline__ float update2(float a, float b, float s, float dx) { return update2_fh(a, b, s * dx); }
+__device__ __forceinline__ double update2(double a, double b, double s, double dx) { return update2_fh(a, b, s * dx); }
+// Grid2Drn::update_node45, ttcr/Grid2Drn.h:1005-1007: fh = sqrt(2) s dx with a double literal, so the
+// float instantiation forms both products in double and rounds once
+__device__ __forceinline__ float fh45(float s, float dx) { return (float)((1.414213562373095 * (double)s) * (double)dx); }
+__device__ __forceinline__ double fh45(double s, double dx) { return (1.414213562373095 * s) * dx; }
 
 // Grid2Drn::update_node_xz, ttcr/Grid2Drn.h:1041-1054 (dx != dz)
 __device__ __forceinline__ float update2_xz(float a, float b, float sn, float dx, float dz) {
@@ -1220,6 +1224,155 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         if ((tid & 63) == 0 && accd != 0.0) atomicAdd(a.change + grp * NS + l, accd);
         if ((tid & 63) == 0 && nevals && ((lm >> l) & 1)) atomicAdd(pa.evals + grp * NS + l, nevals);
     }
+}
+
+// ---- rotated template (2-D, rotated_template=true): Grid2Drn::sweep45, ttcr/Grid2Drn.h:756-794 ----
+// The stencil uses the four diagonal neighbours, so a node depends on the WHOLE previous row of the
+// outer loop (x'-1, z'-1 and z'+1): the level function of this ordering is L = 2 x' + z' (the two
+// upwind neighbours sit at L-3 and L-1, the two downwind ones at L+1 and L+3).  An optional stage of
+// the reference (off by default): one workgroup per source (sources run concurrently on different
+// CUs; a single source is latency bound).
+template <typename T>
+struct Sweep45Args {
+    T* tt;                    // [group][node][ts]
+    const T* s;               // node slowness, natural layout (z fastest)
+    const uint32_t* frozen;   // [n_slots][mask_words]
+    double* change;           // [n_slots]
+    const int* slots;         // [batch] slot, or slot group when by_group
+    const int* lmask;         // [batch] by_group: sources of the group still being solved
+    int ts, by_group;
+    int nnx, nnz;
+    size_t n_nodes;
+    uint32_t mask_words;
+    T dx;
+};
+
+// One workgroup per source; ring row r <-> thread r.  The columns x' (outer loop index of the
+// reference) are taken in strips of NT-2: a row only depends on the row before it, so a strip can
+// run through all its levels once the strip before it is complete.  Rows 0 and NT-1 of the ring are
+// the halo columns (finished values of the previous strip / untouched values of the next one).
+// Per column the ring holds 16 consecutive levels; chunks of 8 levels: load levels L0+4..L0+11 of
+// every row (the node of row r at level L is z' = L - 2(r-1)), then 8 LDS-only levels.
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void fsm_sweep45(const Sweep45Args<T> a) {
+    constexpr int W = 16, C = 8;
+    __shared__ T ring[NT * W];
+    int slot;
+    if (a.by_group) {
+        const int z = blockIdx.x / a.ts, l = blockIdx.x % a.ts;
+        const int grp = a.slots[z];
+        if (grp < 0 || !((a.lmask[z] >> l) & 1)) return;
+        slot = grp * a.ts + l;
+    } else {
+        slot = a.slots[blockIdx.x];
+        if (slot < 0) return;
+    }
+    T* __restrict__ Tg = a.tt + ((size_t)(slot / a.ts) * a.n_nodes * a.ts + slot % a.ts);
+    const uint32_t* __restrict__ Fz = a.frozen + (size_t)slot * a.mask_words;
+    const int nnx = a.nnx, nnz = a.nnz, ts = a.ts;
+    const T TMAX = real_traits<T>::max();
+    const int r = threadIdx.x;
+    constexpr int S = NT - 2;
+    T dec = 0;
+    for (int dir = 0; dir < 4; ++dir) {
+        const int ri = (dir == 1) | (dir == 2), rj = dir >> 1;
+        for (int x0 = 0; x0 < nnx; x0 += S) {
+            const int ncol = nnx - x0 < S ? nnx - x0 : S;
+            const int nlev = 2 * (ncol - 1) + nnz;     // local levels L = 2 (r-1) + z'
+            const int xp = x0 + r - 1;                 // oriented column of this ring row
+            const bool col_in = xp >= 0 && xp < nnx && r <= ncol + 1;
+            const bool own = r >= 1 && r <= ncol;
+            const int i = ri ? nnx - 1 - xp : xp;
+            const uint32_t rowbase = (uint32_t)(col_in ? i : 0) * nnz;
+            // levels [lo, lo+C) of this row, old values (+ slowness / frozen bits when they are own nodes)
+            auto load_levels = [&](int lo, T* v) {
+#pragma unroll
+                for (int e = 0; e < C; ++e) {
+                    const int zp = lo + e - 2 * (r - 1);
+                    const bool ok = col_in && zp >= 0 && zp < nnz;
+                    const uint32_t n = rowbase + (rj ? nnz - 1 - zp : zp);
+                    v[e] = ok ? ld_sc1(Tg + (size_t)n * ts) : TMAX;
+                }
+            };
+            auto load_static = [&](int lo, T* sv, unsigned& fz) {
+                fz = 0;
+#pragma unroll
+                for (int e = 0; e < C; ++e) {
+                    const int zp = lo + e - 2 * (r - 1);
+                    const bool ok = own && zp >= 0 && zp < nnz;
+                    const uint32_t n = rowbase + (rj ? nnz - 1 - zp : zp);
+                    sv[e] = ok ? a.s[n] : (T)0;
+                    const bool frozen = ok ? ((Fz[n >> 5] >> (n & 31)) & 1u) : true;
+                    fz |= (frozen ? 1u : 0u) << e;
+                }
+            };
+            auto to_ring = [&](int lo, const T* v) {
+#pragma unroll
+                for (int e = 0; e < C; ++e) ring[r * W + ((lo + e) & (W - 1))] = v[e];
+            };
+            T vn[C], svn[C];
+            unsigned fzn;
+            load_levels(-4, vn);
+            to_ring(-4, vn);
+            load_levels(4, vn);
+            load_static(0, svn, fzn);
+            for (int L0 = 0; L0 < nlev; L0 += C) {
+                T sv[C];
+#pragma unroll
+                for (int e = 0; e < C; ++e) sv[e] = svn[e];
+                const unsigned fz = fzn;
+                to_ring(L0 + 4, vn);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // next chunk's inputs: issued now, they land during the LDS-only level march
+                if (L0 + C < nlev) {
+                    load_levels(L0 + C + 4, vn);
+                    load_static(L0 + C, svn, fzn);
+                }
+                T res[C];
+                unsigned chg = 0;
+#pragma unroll
+                for (int e = 0; e < C; ++e) {
+                    const int L = L0 + e;
+                    if (!((fz >> e) & 1u)) {
+                        const T tmm = ring[(r - 1) * W + ((L - 3) & (W - 1))];   // (x'-1, z'-1)
+                        const T tmp = ring[(r - 1) * W + ((L - 1) & (W - 1))];   // (x'-1, z'+1)
+                        const T tpm = ring[(r + 1) * W + ((L + 1) & (W - 1))];   // (x'+1, z'-1)
+                        const T tpp = ring[(r + 1) * W + ((L + 3) & (W - 1))];   // (x'+1, z'+1)
+                        const T c = ring[r * W + (L & (W - 1))];
+                        // natural diagonals: a = min over (+1,+1)/(-1,-1), b = min over (+1,-1)/(-1,+1);
+                        // flipping exactly one axis swaps the two diagonals
+                        const bool sw = ri != rj;
+                        const T a1 = sw ? tpm : tpp, a2 = sw ? tmp : tmm;
+                        const T b1 = sw ? tpp : tpm, b2 = sw ? tmm : tmp;
+                        const T av = a1 < a2 ? a1 : a2, bv = b1 < b2 ? b1 : b2;
+                        const T t = update2_fh(av, bv, fh45(sv[e], a.dx));
+                        if (t < c) {
+                            ring[r * W + (L & (W - 1))] = t;
+                            res[e] = t;
+                            chg |= 1u << e;
+                            dec += c - t;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                // write back what changed; nobody reads these nodes from memory before the strip ends
+#pragma unroll
+                for (int e = 0; e < C; ++e) {
+                    if ((chg >> e) & 1u) {
+                        const int zp = L0 + e - 2 * (r - 1);
+                        st_sc1(Tg + (size_t)(rowbase + (rj ? nnz - 1 - zp : zp)) * ts, res[e]);
+                    }
+                }
+            }
+            // the next strip (and the next direction) reads what this one stored
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    double accd = (double)dec;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
+    if ((threadIdx.x & 63) == 0 && accd != 0.0) atomicAdd(a.change + slot, accd);
 }
 
 // ---- small kernels -------------------------------------------------------------------------
