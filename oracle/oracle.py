@@ -266,3 +266,34 @@ def ref_solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5,
     if rc != 0:
         raise RuntimeError(R.ref_last_error().decode())
     return dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
+
+
+# --------------------------------------------------------------------------- file formats (reference side)
+
+
+def ref_set_save(base, all=0, format=1):
+    """make the next ref_solve* also call saveTT(base, all, 0, format) on the reference grid ('' = off)"""
+    ref().ref_set_save(C.c_char_p((base or "").encode()), C.c_int(int(all)), C.c_int(int(format)))
+
+
+def ref_read_src(fname, max_n=100000):
+    xyz = np.zeros((max_n, 3))
+    t0 = np.zeros(max_n)
+    R = ref()
+    R.ref_read_src.restype = C.c_int
+    n = R.ref_read_src(C.c_char_p(fname.encode()), _p(xyz), _p(t0), C.c_int(max_n))
+    return xyz[:n].copy(), t0[:n].copy()
+
+
+def ref_read_rcv(fname, max_n=100000):
+    xyz = np.zeros((max_n, 3))
+    R = ref()
+    R.ref_read_rcv.restype = C.c_int
+    n = R.ref_read_rcv(C.c_char_p(fname.encode()), _p(xyz), C.c_int(max_n))
+    return xyz[:n].copy()
+
+
+def ref_write_rcv(rcvfile, ttfile, xyz, tt):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    tt = np.ascontiguousarray(tt, dtype=np.float64)
+    ref().ref_write_rcv(C.c_char_p(rcvfile.encode()), C.c_char_p(ttfile.encode()), C.c_int(xyz.shape[0]), _p(xyz), _p(tt))

@@ -13,7 +13,9 @@
 //   Grid2Drnfs<T,uint32_t,sxz<T>>  ttcr/Grid2Drnfs.h:84-95, :198-299
 //   Grid2Drcfs<T,uint32_t,sxz<T>>  ttcr/Grid2Drcfs.h:98-138
 // called through the public base-class overloads Grid3D::raytrace
-// (ttcr/Grid3D.h:470-502) / Grid2D::raytrace.
+// (ttcr/Grid3D.h:470-502) / Grid2D::raytrace; plus the file formats either side of the path:
+//   Grid3Drn::saveTT (ttcr/Grid3Drn.h:2679-2762), Grid2Drn::saveTT (ttcr/Grid2Drn.h:419-500),
+//   Src<T>::init (ttcr/Src.h:62-131), Rcv<T>::init / save_tt / save_rcvfile (ttcr/Rcv.h:78-216).
 #include <cstdint>
 #include <cstring>
 #include <exception>
@@ -24,6 +26,8 @@
 #include "Grid2Drnfs.h"
 #include "Grid3Drcfs.h"
 #include "Grid3Drnfs.h"
+#include "Rcv.h"
+#include "Src.h"
 
 namespace ttcr {
 int verbose = 0;
@@ -31,6 +35,14 @@ int gpu_profile = 0;
 }  // namespace ttcr
 
 static thread_local std::string g_err;
+// when set, the next solve also calls saveTT(base, all, 0, format) on the reference grid
+static thread_local std::string g_save_base;
+static thread_local int g_save_all = 0, g_save_format = 1;
+extern "C" void ref_set_save(const char* base, int all, int format) {
+    g_save_base = base ? base : "";
+    g_save_all = all;
+    g_save_format = format;
+}
 
 template <typename T, typename GRID>
 static int run3d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const T* src_xyz,
@@ -50,6 +62,7 @@ static int run3d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
         std::memcpy(tt_grid, grid_tt.data(), grid_tt.size() * sizeof(T));
         niter[0] = g.get_niter();
         niter[1] = g.get_niterw();
+        if (!g_save_base.empty()) g.saveTT(g_save_base, g_save_all, 0, g_save_format);
         return 0;
     } catch (std::exception& e) {
         g_err = e.what();
@@ -75,6 +88,7 @@ static int run2d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
         std::memcpy(tt_grid, grid_tt.data(), grid_tt.size() * sizeof(T));
         niter[0] = g.get_niter();
         niter[1] = g.get_niterw();
+        if (!g_save_base.empty()) g.saveTT(g_save_base, g_save_all, 0, g_save_format);
         return 0;
     } catch (std::exception& e) {
         g_err = e.what();
@@ -135,5 +149,35 @@ REF3D(ref_fsm3d_f64, double)
 
 REF2D(ref_fsm2d_f32, float)
 REF2D(ref_fsm2d_f64, double)
+
+// Src / Rcv text files (double instantiation): coordinates (+ t0) into caller buffers, count returned
+extern "C" int ref_read_src(const char* fname, double* xyz, double* t0, int max_n) {
+    ttcr::Src<double> s(fname);
+    s.init();
+    const int n = (int)s.get_coord().size();
+    for (int i = 0; i < n && i < max_n; ++i) {
+        xyz[3 * i] = s.get_coord()[i].x; xyz[3 * i + 1] = s.get_coord()[i].y; xyz[3 * i + 2] = s.get_coord()[i].z;
+        t0[i] = s.get_t0()[i];
+    }
+    return n;
+}
+extern "C" int ref_read_rcv(const char* fname, double* xyz, int max_n) {
+    ttcr::Rcv<double> r(fname);
+    r.init(1);
+    const int n = (int)r.get_coord().size();
+    for (int i = 0; i < n && i < max_n; ++i) {
+        xyz[3 * i] = r.get_coord()[i].x; xyz[3 * i + 1] = r.get_coord()[i].y; xyz[3 * i + 2] = r.get_coord()[i].z;
+    }
+    return n;
+}
+// Rcv::save_rcvfile to `rcvfile` and Rcv::save_tt (one arrival per receiver) to `ttfile`
+extern "C" void ref_write_rcv(const char* rcvfile, const char* ttfile, int n, const double* xyz, const double* tt) {
+    ttcr::Rcv<double> r(rcvfile);
+    for (int i = 0; i < n; ++i) r.add_coord({xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+    r.init_tt(1);
+    r.get_tt(0).assign(tt, tt + n);
+    r.save_rcvfile();
+    r.save_tt(ttfile, 0);
+}
 
 extern "C" const char* ref_last_error() { return g_err.c_str(); }

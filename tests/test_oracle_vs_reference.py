@@ -60,3 +60,93 @@ def test_reference_rejects_outside_point(O):
         O.ref_solve3d(np.float64, (4, 4, 4), 1.0, (0, 0, 0), np.ones(125), [[5.0, 1.0, 1.0]])
     with pytest.raises(RuntimeError, match="outside grid"):
         O.solve3d(np.float64, (4, 4, 4), 1.0, (0, 0, 0), np.ones(125), [[5.0, 1.0, 1.0]])
+
+
+# ---------------------------------------------------------------- file formats
+
+class _Field:
+    """a solved field dressed as the grid object ttcr_amd.io.save_tt takes"""
+
+    def __init__(self, dt, coords, steps, tt, translate=False):
+        self._dtype, self._ndim = dt, len(coords)
+        if self._ndim == 3:
+            self._x, self._y, self._z = (np.asarray(c, dtype=dt) for c in coords)
+        else:
+            self._x, self._z = (np.asarray(c, dtype=dt) for c in coords)
+            self._dz = steps[1]
+        self._dx = steps[0]   # the step the reference grid was constructed with
+        self.translate_grid = translate
+        self._tt = tt
+
+    def _flat_tt(self, thread_no):
+        return self._tt
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("fmt,ext", [(1, ".dat"), (3, ".bin")])
+def test_save_tt_byte_identical_to_reference(O, tmp_path, dt, fmt, ext):
+    """Grid3Drn::saveTT / Grid2Drn::saveTT text and binary files, byte for byte (node order, coordinate
+    arithmetic in the grid's precision, 12 significant digits); incl. a translated grid"""
+    from ttcr_amd import io
+
+    rng = np.random.default_rng(11)
+    for translate in (False, True):
+        nc, dx, org = (6, 4, 5), 0.3, (1.7, -2.2, 0.1)
+        s = rng.uniform(0.3, 1.0, 7 * 5 * 6)
+        O.ref_set_save(str(tmp_path / "ref3"), 0, fmt)
+        try:
+            r = O.ref_solve3d(dt, nc, dx, org, s, [[2.0, -1.5, 0.9]], translate=translate)
+        finally:
+            O.ref_set_save("")
+        x, y, z = (dt(org[a]) + np.arange(nc[a] + 1).astype(dt) * dt(dx) for a in range(3))
+        io.save_tt(_Field(dt, (x, y, z), (dx,), r["tt"], translate), str(tmp_path / "ours3"), 0, 0, fmt)
+        assert (tmp_path / ("ours3" + ext)).read_bytes() == (tmp_path / ("ref3" + ext)).read_bytes()
+    nc, dx, dz, org = (7, 5), 0.25, 0.4, (3.1, -0.7)
+    s = rng.uniform(0.3, 1.0, 8 * 6)
+    O.ref_set_save(str(tmp_path / "ref2"), 0, fmt)
+    try:
+        r = O.ref_solve2d(dt, nc, dx, dz, org, s, [[3.9, 0.2]])
+    finally:
+        O.ref_set_save("")
+    x = dt(org[0]) + np.arange(nc[0] + 1).astype(dt) * dt(dx)
+    z = dt(org[1]) + np.arange(nc[1] + 1).astype(dt) * dt(dz)
+    io.save_tt(_Field(dt, (x, z), (dx, dz), r["tt"]), str(tmp_path / "ours2"), 0, 0, fmt)
+    assert (tmp_path / ("ours2" + ext)).read_bytes() == (tmp_path / ("ref2" + ext)).read_bytes()
+
+
+def test_src_rcv_files_like_the_reference_classes(O, tmp_path):
+    """read_src / read_rcv == Src<double>::init / Rcv<double>::init on the reference's own files and on the
+    VTK / CRT layouts; save_rcvfile / save_rcv_tt write what Rcv::save_rcvfile / save_tt write"""
+    from ttcr_amd import io
+
+    ref_files = "/root/reference/tests/files/"
+    for f in ("src.dat", "src3d_in.dat", "src3d_in2.dat"):
+        a, b = io.read_src(ref_files + f), O.ref_read_src(ref_files + f)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    for f in ("rcv.dat", "rcv3d_in.dat", "rcv3d_in2.dat"):
+        np.testing.assert_array_equal(io.read_rcv(ref_files + f), O.ref_read_rcv(ref_files + f))
+    p = tmp_path / "pts.vtk"
+    p.write_text("# vtk DataFile Version 3.0\npoints\nASCII\nDATASET POLYDATA\nPOINTS 3 float\n1 2 3\n4.5 5.5 6.5 7 8\n9\n")
+    q = tmp_path / "pts.crt"
+    q.write_text("S1 1.0 2.0 3.0 /\nS2 4.0 5.0 6.0 /\n")
+    for f in (p, q):
+        np.testing.assert_array_equal(io.read_rcv(str(f)), O.ref_read_rcv(str(f)))
+        a, b = io.read_src(str(f)), O.ref_read_src(str(f))
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    rng = np.random.default_rng(2)
+    xyz = rng.normal(0, 1e3, (17, 3)) * 10.0 ** rng.integers(-9, 9, (17, 1))
+    tt = np.abs(rng.normal(0, 1, 17)) * 10.0 ** rng.integers(-12, 6, 17)
+    O.ref_write_rcv(str(tmp_path / "ref_rcv.dat"), str(tmp_path / "ref_tt.dat"), xyz, tt)
+    io.save_rcvfile(str(tmp_path / "our_rcv.dat"), xyz)
+    io.save_rcv_tt(str(tmp_path / "our_tt.dat"), tt)
+    assert (tmp_path / "our_rcv.dat").read_bytes() == (tmp_path / "ref_rcv.dat").read_bytes()
+    assert (tmp_path / "our_tt.dat").read_bytes() == (tmp_path / "ref_tt.dat").read_bytes()
+
+
+def test_fixture_data_files_are_the_reference_files():
+    """tests/files/ holds unmodified copies of the reference's test DATA files"""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "files")
+    for f in sorted(os.listdir(here)):
+        assert open(os.path.join(here, f), "rb").read() == open("/root/reference/tests/files/" + f, "rb").read(), f

@@ -111,6 +111,42 @@ class _GridBase:
         return p.value
 
     # -- source / receiver bookkeeping shared by 3-D and 2-D raytrace()
+    def to_vtk(self, fields, filename):
+        """to_vtk(fields, filename): save node/cell variables to filename + '.vtr' and lists of raypaths
+        to filename + '_' + key + '.vtp' (rgrid.pyx:1201-1312, 2-D :4145-4260).  Arrays may be shaped like
+        the grid or flat in C order; the file is written in VTK order (x fastest), Float64, like the reference."""
+        from . import io as _io
+
+        if self._ndim == 3:
+            nodes, cells = (self._x.size, self._y.size, self._z.size), (self._x.size - 1, self._y.size - 1, self._z.size - 1)
+            xyz = (self._x, self._y, self._z)
+        else:
+            nodes, cells = (self._x.size, self._z.size), (self._x.size - 1, self._z.size - 1)
+            xyz = (self._x, np.array([0.0]), self._z)
+        pd, cd = {}, {}
+        for fn in fields:
+            data = fields[fn]
+            if isinstance(data, list):
+                _io.write_vtp_lines(filename + '_' + fn + '.vtp', data)
+                continue
+            data = np.asarray(data)
+            for shape, dest in ((nodes, pd), (cells, cd)):
+                if data.size == int(np.prod(shape)):
+                    if data.ndim == len(shape):
+                        if data.shape != shape:
+                            raise ValueError('Field {0:s} has incorrect shape'.format(fn))
+                        tmp = data.flatten(order='F')
+                    elif data.ndim == 1 or (data.ndim == 2 and data.shape[0] == data.size):
+                        tmp = data.reshape(shape).flatten(order='F')
+                    else:
+                        raise ValueError('Field {0:s} has incorrect ndim ({1:d})'.format(fn, data.ndim))
+                    dest[fn] = tmp.astype(np.float64)
+                    break
+            else:
+                raise ValueError('Field {0:s} has incorrect size'.format(fn))
+        if pd or cd:
+            _io.write_vtr(filename + '.vtr', xyz[0], xyz[1], xyz[2], point_data=pd, cell_data=cd)
+
     def _split_sources(self, source, rcv, aggregate_src):
         nd = self._ndim
         if source.ndim != 2 or rcv.ndim != 2:
@@ -401,14 +437,32 @@ class _Grid3d(_GridBase):
         return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
 
 
+def _builder3d(cls, filename, n_threads=1, method='FSM', tt_from_rp=1, interp_vel=0, eps=1.e-5, maxit=50, weno=1,
+               nsnx=5, nsny=5, nsnz=5, n_secondary=2, n_tertiary=2, radius_factor_tertiary=3.0, translate_grid=0,
+               device=-1):
+    """builder(filename, n_threads=1, method='FSM', ...): grid from a vtkRectilinearGrid file holding a point
+    or cell array named Slowness, slowness, Velocity, velocity or P-wave velocity (rgrid.pyx:1315-1379)"""
+    from . import io as _io
+
+    m = _io.model_from_vtr(filename)
+    x, y, z = m['x'], m['y'], m['z']
+    dim = (x.size - 1, y.size - 1, z.size - 1) if m['cell_slowness'] else (x.size, y.size, z.size)
+    g = cls(x, y, z, n_threads, m['cell_slowness'], method, tt_from_rp, interp_vel, eps, maxit, weno, nsnx, nsny,
+            nsnz, n_secondary, n_tertiary, radius_factor_tertiary, translate_grid, device=device)
+    g.set_slowness(m['slowness'].reshape(dim, order='F').flatten())
+    return g
+
+
 class Grid3d_d(_Grid3d):
     """double-precision 3-D grid (ttcrpy Grid3d_d)"""
     _dtype = np.float64
+    builder = classmethod(_builder3d)
 
 
 class Grid3d_f(_Grid3d):
     """single-precision 3-D grid (ttcrpy Grid3d_f)"""
     _dtype = np.float32
+    builder = classmethod(_builder3d)
 
 
 def _rebuild3d(cls, x, y, z, p):
@@ -606,3 +660,6 @@ def Grid2d(x, z, n_threads=1, cell_slowness=1, method='SPM', aniso='iso', eps=1.
         raise ValueError('dtype must be np.float32 or np.float64, got {}'.format(dtype))
     return cls(x, z, n_threads, cell_slowness, method, aniso, eps, maxit, weno, rotated_template, nsnx, nsnz,
                n_secondary, n_tertiary, radius_factor_tertiary, tt_from_rp, fsm_gpu, device=device)
+
+
+Grid3d.builder = Grid3d_d.builder
