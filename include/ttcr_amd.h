@@ -128,10 +128,22 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                     1103-1243; 3-D only); 0: trilinear interpolation (getTraveltime).  Default 0.
  *   "interp_vel"   1: the ray integration interpolates velocity instead of slowness (`intVel`
  *                     constructor argument / processVel, ttcr/Grid3Drn.h:2451-2676).  Default 0.
+ *   "return_rays"  1: the raytrace calls follow the overloads with r_data (Grid3D::raytrace(Tx,t0,Rx,tt,
+ *                     r_data,threadNo), ttcr/Grid3D.h:546-586): receiver traveltimes AND raypaths come from
+ *                     Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) (ttcr/Grid3Drn.h:1339-1500); the rays
+ *                     stay in the grid until the next raytrace call, see ttcr_fsm_get_rays.  3-D only.
  *   "skip"         1: persistent kernel skips chunks whose read set (bricks of 16^3 nodes, tracked
  *                     by last-change sweep number) did not change since their last evaluation --
  *                     exact, results and iteration counts are unchanged; 0: evaluate every chunk (default) */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
+
+/* Replaces: the r_data output of the raytrace overloads above (std::vector<std::vector<sxyz<T1>>>&,
+ * src/ttcrpy/rgrid.pxd:60-75).  After a raytrace call with option "return_rays" = 1: one ray per receiver
+ * row of that call, in row order; ray n is points [offsets[n], offsets[n+1]) of pts (x,y,z triples of the
+ * grid's dtype), from the receiver to the source.  Two calls: sizes first, then the copy into caller
+ * buffers of n_rays+1 offsets and 3*n_points coordinates. */
+int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points);
+int ttcr_fsm_get_rays(const ttcr_fsm_grid* g, long long* offsets, void* pts);
 
 typedef struct {
     double sweep_ms;        /* HIP-event time of all sweep launches of the last raytrace call   */

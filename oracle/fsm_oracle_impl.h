@@ -694,6 +694,67 @@ int SFX(fsm_tt_from_raypath3d)(const SFX(fsm_grid3d) * g, const REAL* sn, const 
     return 0;
 }
 
+/* Grid3Drn::getRaypath(Tx, t0, Rx, r_data, tt, threadNo), ttcr/Grid3Drn.h:1339-1500: the same walk as
+ * getTraveltimeFromRaypath, recording every point; `back` is r_data.back().  pts holds xyz triples
+ * (capacity cap points).  Returns 0 ok, 1 ray left the grid (the reference throws), 2 step limit,
+ * 3 capacity exceeded (npts still counts). */
+int SFX(fsm_raypath3d)(const SFX(fsm_grid3d) * g, const REAL* sn, const REAL* T, int n_src, const REAL* src,
+                       const REAL* t0, const REAL rx[3], int iv, long max_steps, REAL* tt_out, REAL* pts, long cap,
+                       long* npts) {
+    REAL tt = 0.0, s1, s2;
+    long np = 0;
+    int over = 0;
+#define FSM_PUSH(P) do { if (np < cap) { pts[3 * np] = (P)[0]; pts[3 * np + 1] = (P)[1]; pts[3 * np + 2] = (P)[2]; } else over = 1; \
+                         back[0] = (P)[0]; back[1] = (P)[1]; back[2] = (P)[2]; ++np; } while (0)
+    REAL back[3], cur[3] = {rx[0], rx[1], rx[2]}, gv[3];
+    FSM_PUSH(rx);
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) { *tt_out = t0[ns]; *npts = np; return 0; }
+    s1 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+    const REAL dx = g->dx;
+    const REAL maxDist = (REAL)sqrt(dx * dx + dx * dx + dx * dx);
+    int reached = 0;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) { *npts = np; return 2; }
+        SFX(grad3d)(g, T, cur[0], cur[1], cur[2], &gv[0], &gv[1], &gv[2]);
+        gv[0] *= (REAL)-1.0; gv[1] *= (REAL)-1.0; gv[2] *= (REAL)-1.0;
+        SFX(step_to_plane)(g, cur, gv);
+        if (cur[0] < g->xmin || cur[0] > g->xmax || cur[1] < g->ymin || cur[1] > g->ymax || cur[2] < g->zmin ||
+            cur[2] > g->zmax) { *npts = np; return 1; }
+        s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+        tt += 0.5 * (s1 + s2) * SFX(dist3)(back, cur);
+        s1 = s2;
+        FSM_PUSH(cur);
+        for (int ns = 0; ns < n_src; ++ns) {
+            const REAL* tx = src + 3 * ns;
+            REAL dist = SFX(dist3)(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1]; gv[2] = tx[2] - cur[2];
+                SFX(step_to_plane)(g, cur, gv);
+                if (SFX(dist3)(cur, back) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(back, tx);
+                    FSM_PUSH(tx);
+                } else {
+                    s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+                    tt += 0.5 * (s1 + s2) * SFX(dist3)(back, cur);
+                    FSM_PUSH(cur);
+                    s1 = s2;
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(cur, tx);
+                    FSM_PUSH(tx);
+                }
+                reached = 1;
+            }
+        }
+    }
+#undef FSM_PUSH
+    *tt_out = tt;
+    *npts = np;
+    return over ? 3 : 0;
+}
+
 /* ------------------------------------------------------------------ 2D -- */
 /* 2D node index is z-fastest: n = i*(ncz+1)+j (ttcr/Grid2Drn.h:720). */
 

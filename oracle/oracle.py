@@ -101,7 +101,8 @@ def _prep_pts(dt, pts, ncol):
 
 
 def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-            cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False):
+            cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False,
+            return_rays=False):
     """Restatement of Grid3Drnfs / Grid3Drcfs ::raytrace (tt_from_rp=False; weno selects the
     two-stage first-order + WENO3 driver).
 
@@ -144,7 +145,36 @@ def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=5
         r = _prep_pts(dt, rcv, 3).copy()
         if translate:
             r -= np.array([g.ox, g.oy, g.oz], dtype=dt)
-        if tt_from_rp:
+        if return_rays:
+            # Grid3D::raytrace(Tx,t0,Rx,tt,r_data,threadNo) (ttcr/Grid3D.h:546-586): getRaypath with tt for
+            # every receiver; rays are shifted back by the origin of a translated grid (:579-584)
+            frp = getattr(L, "fsm_raypath3d_" + sfx)
+            vals = np.empty(r.shape[0], dtype=dt)
+            rays = []
+            cap = 4 * (ncx + ncy + ncz) + 64
+            for n, pnt in enumerate(r):
+                pp = np.ascontiguousarray(pnt, dtype=dt)
+                v = ct(0)
+                while True:
+                    buf = np.empty((cap, 3), dtype=dt)
+                    npts = C.c_long(0)
+                    rc = frp(C.byref(g), _p(sn), _p(T), C.c_int(nsrc), _p(src), _p(t0), _p(pp), C.c_int(int(interp_vel)),
+                             C.c_long(1000000), C.byref(v), _p(buf), C.c_long(cap), C.byref(npts))
+                    if rc != 3:
+                        break
+                    cap *= 4
+                if rc == 1:
+                    raise RuntimeError("Error while computing raypaths: going outside grid")
+                if rc == 2:
+                    raise RuntimeError("raypath did not reach the source")
+                vals[n] = v.value
+                ray = buf[:npts.value].copy()
+                if translate:
+                    ray += np.array([g.ox, g.oy, g.oz], dtype=dt)
+                rays.append(ray)
+            out["tt_rcv"] = vals
+            out["rays"] = rays
+        elif tt_from_rp:
             # Grid3D::raytrace with tt_from_rp (ttcr/Grid3D.h:493-496): traveltime integrated along the ray
             frp = getattr(L, "fsm_tt_from_raypath3d_" + sfx)
             vals = np.empty(r.shape[0], dtype=dt)
@@ -176,7 +206,8 @@ def cells_to_nodes3d(dtype, ncells, sc):
 
 
 def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-                cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False):
+                cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False,
+                return_rays=False):
     """The compiled, unmodified reference (build container only)."""
     dt = np.dtype(dtype)
     sfx, ct = _TYPES[dt][:2]
@@ -191,15 +222,31 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
     tt_rcv = np.empty(r.shape[0], dtype=dt)
     T = np.empty(nn, dtype=dt)
     niter = (C.c_int * 2)()
-    rc = getattr(R, "ref_fsm3d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncy),
-                                        C.c_uint32(ncz), ct(dx), ct(origin[0]), ct(origin[1]), ct(origin[2]),
-                                        ct(eps), C.c_int(maxit), C.c_int(int(weno)), C.c_int(int(translate)),
-                                        C.c_int(int(tt_from_rp)), C.c_int(int(interp_vel)),
-                                        _p(s), C.c_int(nsrc), _p(src), _p(t0), C.c_int(r.shape[0]), _p(r),
-                                        _p(tt_rcv), _p(T), niter)
-    if rc != 0:
-        raise RuntimeError(R.ref_last_error().decode())
-    return dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
+    cap = (4 * (ncx + ncy + ncz) + 64) * max(r.shape[0], 1)
+    while True:
+        if return_rays:
+            rbuf = np.empty((cap, 3), dtype=np.float64)
+            roff = np.zeros(r.shape[0] + 1, dtype=np.int64)
+            R.ref_set_rays(_p(rbuf), C.c_long(cap), _p(roff))
+        try:
+            rc = getattr(R, "ref_fsm3d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncy),
+                                                C.c_uint32(ncz), ct(dx), ct(origin[0]), ct(origin[1]), ct(origin[2]),
+                                                ct(eps), C.c_int(maxit), C.c_int(int(weno)), C.c_int(int(translate)),
+                                                C.c_int(int(tt_from_rp)), C.c_int(int(interp_vel)),
+                                                _p(s), C.c_int(nsrc), _p(src), _p(t0), C.c_int(r.shape[0]), _p(r),
+                                                _p(tt_rcv), _p(T), niter)
+        finally:
+            if return_rays:
+                R.ref_set_rays(None, C.c_long(0), None)
+        if rc != 0:
+            raise RuntimeError(R.ref_last_error().decode())
+        if not return_rays or roff[-1] <= cap:
+            break
+        cap = int(roff[-1])
+    out = dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
+    if return_rays:
+        out["rays"] = [rbuf[roff[n]:roff[n + 1]].astype(dt) for n in range(r.shape[0])]
+    return out
 
 
 # --------------------------------------------------------------------------- 2D

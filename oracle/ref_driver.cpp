@@ -38,6 +38,16 @@ static thread_local std::string g_err;
 // when set, the next solve also calls saveTT(base, all, 0, format) on the reference grid
 static thread_local std::string g_save_base;
 static thread_local int g_save_all = 0, g_save_format = 1;
+// when set, the next 3-D solve uses the raypath overload Grid3D::raytrace(Tx,t0,Rx,tt,r_data,threadNo)
+// (ttcr/Grid3D.h:546-586): ray n occupies points [off[n], off[n+1]) of buf (xyz triples, as double)
+static thread_local double* g_ray_buf = nullptr;
+static thread_local long g_ray_cap = 0;
+static thread_local long* g_ray_off = nullptr;
+extern "C" void ref_set_rays(double* buf, long cap_pts, long* off) {
+    g_ray_buf = buf;
+    g_ray_cap = cap_pts;
+    g_ray_off = off;
+}
 extern "C" void ref_set_save(const char* base, int all, int format) {
     g_save_base = base ? base : "";
     g_save_all = all;
@@ -55,7 +65,21 @@ static int run3d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
         std::vector<T> vt0(t0, t0 + n_src), tt;
         for (int n = 0; n < n_src; ++n) Tx[n] = {src_xyz[3 * n], src_xyz[3 * n + 1], src_xyz[3 * n + 2]};
         for (int n = 0; n < n_rcv; ++n) Rx[n] = {rcv_xyz[3 * n], rcv_xyz[3 * n + 1], rcv_xyz[3 * n + 2]};
-        static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, 0);
+        if (g_ray_buf) {
+            std::vector<std::vector<sxyz<T>>> r_data;
+            static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, r_data, 0);
+            long k = 0;
+            for (int n = 0; n < n_rcv; ++n) {
+                g_ray_off[n] = k;
+                for (const auto& p : r_data[n]) {
+                    if (k < g_ray_cap) { g_ray_buf[3 * k] = p.x; g_ray_buf[3 * k + 1] = p.y; g_ray_buf[3 * k + 2] = p.z; }
+                    ++k;
+                }
+            }
+            g_ray_off[n_rcv] = k;
+        } else {
+            static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, 0);
+        }
         for (int n = 0; n < n_rcv; ++n) tt_rcv[n] = tt[n];
         std::vector<T> grid_tt;
         g.getTT(grid_tt, 0);

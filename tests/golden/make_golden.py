@@ -12,6 +12,8 @@ For every case of tests/cases.py and both dtypes the file holds the reference's 
                           the reference throws "going outside grid" for the case
   <case>/<dtype>/rot_tt, rot_niter, rot_tt_rcv   first-order solve with rotated_template=True (sweep45 after
                           every sweep, ttcr/Grid2Drnfs.h:277-286), for the cases of cases.rot_ok()
+  <case>/<dtype>/rays_tt_rcv, rays_off, rays_pts   weno + return_rays solve: receiver traveltimes and raypaths of
+                          Grid3Drn::getRaypath (ray n = points [off[n], off[n+1])), or rays_error = 1
   <case>/<dtype>/weno_*   the same four outputs (+ niterw) of the two-stage weno=True solve, for the
                           cases of cases.weno_ok()
 and the inputs  <case>/slowness (float64; cast to the dtype under test), so that the
@@ -83,6 +85,20 @@ def main():
                         assert "going outside grid" in str(e)
                         out[key + f"/{tag}_error"] = np.int32(1)
                     print(key, tag, "error" if int(out[key + f"/{tag}_error"]) else "ok")
+            if cases.rp_ok(c):
+                # raytrace(..., return_rays=True): Grid3D::raytrace(Tx,t0,Rx,tt,r_data,threadNo)
+                try:
+                    r = O.ref_solve3d(dt, c["ncells"], c["dx"], c["origin"], c["slowness"], c["src"], c["t0"],
+                                      cell_slowness=c["cell_slowness"], translate=c["translate"], rcv=c["rcv"],
+                                      weno=True, return_rays=True)
+                    out[key + "/rays_tt_rcv"] = r["tt_rcv"]
+                    out[key + "/rays_off"] = np.cumsum([0] + [len(x) for x in r["rays"]]).astype(np.int64)
+                    out[key + "/rays_pts"] = np.vstack(r["rays"])
+                    out[key + "/rays_error"] = np.int32(0)
+                except RuntimeError as e:
+                    assert "going outside grid" in str(e)
+                    out[key + "/rays_error"] = np.int32(1)
+                print(key, "rays", "error" if int(out[key + "/rays_error"]) else "ok")
     path = os.path.join(HERE, "fsm_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -75,6 +75,24 @@ def test_oracle_tt_from_raypath_matches_golden(oracle, golden, c, dt, tag, iv):
     np.testing.assert_array_equal(r["tt_rcv"], golden[key + f"/{tag}_tt_rcv"])
 
 
+@pytest.mark.parametrize("c,dt", RP, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in RP])
+def test_oracle_raypaths_match_golden(oracle, golden, c, dt):
+    """return_rays: Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) -- every point of every ray, bit-exact"""
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    kw = dict(cell_slowness=c["cell_slowness"], translate=c["translate"], rcv=c["rcv"], weno=True, return_rays=True)
+    if int(golden[key + "/rays_error"]):
+        with pytest.raises(RuntimeError, match="going outside grid"):
+            oracle.solve3d(dt, c["ncells"], c["dx"], c["origin"], golden[f"{c['name']}/slowness"], c["src"], c["t0"], **kw)
+        return
+    r = oracle.solve3d(dt, c["ncells"], c["dx"], c["origin"], golden[f"{c['name']}/slowness"], c["src"], c["t0"], **kw)
+    np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/rays_tt_rcv"])
+    off, pts = golden[key + "/rays_off"], golden[key + "/rays_pts"]
+    assert len(r["rays"]) == off.size - 1
+    for n, ray in enumerate(r["rays"]):
+        np.testing.assert_array_equal(ray, pts[off[n]:off[n + 1]])
+        np.testing.assert_array_equal(ray[0], np.asarray(c["rcv"][n], dtype=dt))   # starts on the receiver
+
+
 def test_golden_covers_multi_iteration_cases(golden):
     # the stopping rule / sweep order is only exercised when iterations >= 2 do real work
     assert int(golden["random_24x20x28_node/float32/niter"]) >= 4

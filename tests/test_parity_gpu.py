@@ -249,3 +249,60 @@ def test_hip_multi_source_2d(oracle):
         np.testing.assert_array_equal(tt[2 * n:2 * n + 2], o["tt_rcv"])
         np.testing.assert_array_equal(g.get_grid_traveltimes(n).ravel(), o["tt"])
         assert (g.get_niter(n), g.get_niterw(n)) == (o["niter"], o["niterw"])
+
+
+@pytest.mark.parametrize("c,dt", RP, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in RP])
+def test_hip_raypaths_match_golden(golden, c, dt):
+    """raytrace(..., return_rays=True) -> (tt, rays): the raypaths of Grid3Drn::getRaypath, point for point,
+    and the traveltimes integrated along them; same error when the reference's ray leaves the grid"""
+    import ttcr_amd
+    from gpu_util import source_array
+
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    nc, o = c["ncells"], c["origin"]
+    x, y, z = (o[a] + np.arange(nc[a] + 1) * c["dx"] for a in range(3))
+    g = ttcr_amd.Grid3d(x, y, z, cell_slowness=c["cell_slowness"], method="FSM", tt_from_rp=0, weno=1,
+                        translate_grid=c["translate"], dtype=dt)
+    s = np.asarray(golden[f"{c['name']}/slowness"]).reshape(g.shape, order="F")
+    if int(golden[key + "/rays_error"]):
+        with pytest.raises(RuntimeError, match="going outside grid"):
+            g.raytrace(source_array(c), c["rcv"], slowness=s, aggregate_src=True, return_rays=True)
+        return
+    tt, rays = g.raytrace(source_array(c), c["rcv"], slowness=s, aggregate_src=True, return_rays=True)
+    np.testing.assert_array_equal(tt, golden[key + "/rays_tt_rcv"])
+    off, pts = golden[key + "/rays_off"], golden[key + "/rays_pts"]
+    assert len(rays) == off.size - 1
+    for n, ray in enumerate(rays):
+        np.testing.assert_array_equal(ray, pts[off[n]:off[n + 1]].astype(np.float64))
+    # the option does not stick: the next plain call interpolates again (tt_from_rp=0)
+    tt2 = g.raytrace(source_array(c), c["rcv"], aggregate_src=True)
+    np.testing.assert_array_equal(tt2, golden[key + "/weno_tt_rcv"])
+
+
+def test_hip_raypaths_several_sources_and_to_vtk(tmp_path, oracle):
+    """two events in one call (rows come back in receiver order), rays written by to_vtk and read back"""
+    import ttcr_amd
+    from ttcr_amd import io
+
+    n = 25
+    x = np.arange(n) * 0.5
+    s = np.ascontiguousarray(np.broadcast_to((1.0 / (1.0 + 0.1 * x))[None, None, :], (n, n, n)))
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=2, cell_slowness=0, method="FSM", tt_from_rp=1, weno=1)
+    src = np.array([[1.0, 1.0, 1.0], [10.2, 3.3, 7.1]])
+    rcv = np.array([[11.0, 11.0, 2.0], [3.0, 9.5, 8.0], [6.0, 6.0, 11.5]])
+    srows = np.vstack([src[[0, 1, 0]], src[[1, 0, 1]]])
+    rrows = np.vstack([rcv, rcv])
+    tt, rays = g.raytrace(srows, rrows, slowness=s, return_rays=True)
+    assert len(rays) == 6
+    for k in range(6):
+        np.testing.assert_array_equal(rays[k][0], rrows[k])
+        np.testing.assert_array_equal(rays[k][-1], srows[k])
+        r = oracle.solve3d(np.float64, (n - 1,) * 3, 0.5, (0, 0, 0), s.flatten("F"), [srows[k]], rcv=[rrows[k]], weno=True,
+                           return_rays=True)
+        np.testing.assert_array_equal(rays[k], r["rays"][0])
+        assert tt[k] == r["tt_rcv"][0]
+    g.to_vtk({"rays": rays, "Travel time": g.get_grid_traveltimes(0)}, str(tmp_path / "out"))
+    back = io.read_vtp_lines(str(tmp_path / "out_rays.vtp"))
+    assert len(back) == 6
+    for a, b in zip(rays, back):
+        np.testing.assert_allclose(a, b, rtol=1e-6)   # vtkPoints are Float32

@@ -82,12 +82,15 @@ class GridBase {
     virtual void get_tt(int slot, void* out, size_t n) = 0;
     virtual void* tt_device(int slot) = 0;
     virtual void interp(int slot, int n, const void* pts, void* out) = 0;
+    virtual void rays_size(size_t* n_rays, size_t* n_points) const = 0;
+    virtual void get_rays(long long* offsets, void* pts) const = 0;
     int dim = 3, dtype = 0, n_slots = 1, device = 0;
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter, niterw;
     bool weno = false;
     bool rotated = false;  // 2-D rotated_template: sweep45 after every first-order sweep (ttcr/Grid2Drnfs.h:277-286)
     int ttrp = 0, interp_vel = 0;  // traveltime from raypath (ttcr/Grid3D.h:493-496), processVel
+    int return_rays = 0;           // raytrace overloads with r_data (ttcr/Grid3D.h:546-586): rays kept for get_rays
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
     int skip = 0;  // persistent kernel: 1 = skip chunks whose read set did not change (exact); see DESIGN.md
     int mode = 2;  // 2: persistent kernel, one launch per sweep-iteration, sweeps overlap (default);
@@ -840,16 +843,14 @@ class GridT : public GridBase {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
-    // Grid3Drn::getTraveltimeFromRaypath for every receiver of one source (ttcr/Grid3D.h:493-496)
-    void raypath_grid_coords(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out) {
+    // Grid3Drn::getTraveltimeFromRaypath for every receiver of one source (ttcr/Grid3D.h:493-496); with
+    // `record`, Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) instead (ttcr/Grid3D.h:546-586): the rays are
+    // appended to rays_off / rays_pts (shifted back by the origin of a translated grid, :579-584)
+    void raypath_grid_coords(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out, bool record) {
         if (n <= 0) return;
-        if (dim != 3) throw Unsupported("tt_from_rp=True is only built for 3-D grids");
-        d_rx.reserve((size_t)3 * n);
-        d_out.reserve(n);
-        d_rstat.reserve(n);
+        if (dim != 3) throw Unsupported("tt_from_rp / return_rays are only built for 3-D grids");
         d_rsrc.reserve((size_t)3 * n_tx);
         d_rt0.reserve(n_tx);
-        HIP_CHECK(hipMemcpyAsync(d_rx.p, p, sizeof(T) * 3 * n, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txp, sizeof(T) * 3 * n_tx, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0p, sizeof(T) * n_tx, hipMemcpyHostToDevice, stream));
         RayGeom<T> rg;
@@ -857,26 +858,79 @@ class GridT : public GridBase {
         rg.dx = dx; rg.xmin = xmin; rg.ymin = ymin; rg.zmin = zmin; rg.xmax = xmax; rg.ymax = ymax; rg.zmax = zmax;
         rg.interp_vel = interp_vel;
         const long max_steps = 8L * ((long)ncx + ncy + ncz + 3);  // a ray crosses at most one plane per step
-        fsm_raypath3d<T><<<(n + 63) / 64, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, n,
-                                                            d_out.p, d_rstat.p, max_steps);
-        HIP_CHECK(hipGetLastError());
-        std::vector<int> st(n);
-        HIP_CHECK(hipMemcpyAsync(out, d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        for (int m = 0; m < n; ++m) {
-            if (st[m] == 0) continue;
-            std::ostringstream msg;
-            if (st[m] == 1) {
-                msg << "Error while computing raypaths: going outside grid \n                Rx: " << p[3 * m] << ' '
-                    << p[3 * m + 1] << ' ' << p[3 * m + 2] << "\n                Tx: " << txp[0] << ' ' << txp[1] << ' '
-                    << txp[2] << "\n";
+        const long cap = max_steps + 3;                           // Rx, one point per step, at most two at the source
+        // receivers in chunks: the recording buffer stays below 256 MiB
+        const int chunk = record ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (sizeof(T) * 3 * cap))) : n;
+        std::vector<int> st(chunk), np(chunk);
+        std::vector<long long> off(chunk + 1);
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            const int m = std::min(chunk, n - c0);
+            const T* pc = p + (size_t)3 * c0;
+            d_rx.reserve((size_t)3 * m);
+            d_out.reserve(m);
+            d_rstat.reserve(m);
+            HIP_CHECK(hipMemcpyAsync(d_rx.p, pc, sizeof(T) * 3 * m, hipMemcpyHostToDevice, stream));
+            if (record) {
+                d_raypts.reserve((size_t)m * cap * 3);
+                d_raynp.reserve(m);
+                fsm_raypath3d<T, true><<<(m + 63) / 64, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p,
+                                                                         m, d_out.p, d_rstat.p, max_steps, d_raypts.p, cap, d_raynp.p);
             } else {
-                msg << "Error while computing raypaths: ray from Rx " << p[3 * m] << ' ' << p[3 * m + 1] << ' ' << p[3 * m + 2]
-                    << " did not reach the source within " << max_steps << " steps";
+                fsm_raypath3d<T, false><<<(m + 63) / 64, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p,
+                                                                          m, d_out.p, d_rstat.p, max_steps, nullptr, 0, nullptr);
             }
-            throw std::runtime_error(msg.str());
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(out + c0, d_out.p, sizeof(T) * m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+            if (record) HIP_CHECK(hipMemcpyAsync(np.data(), d_raynp.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            for (int q = 0; q < m; ++q) {
+                if (st[q] == 0) continue;
+                std::ostringstream msg;
+                if (st[q] == 1) {
+                    msg << "Error while computing raypaths: going outside grid \n                Rx: " << pc[3 * q] << ' '
+                        << pc[3 * q + 1] << ' ' << pc[3 * q + 2] << "\n                Tx: " << txp[0] << ' ' << txp[1] << ' '
+                        << txp[2] << "\n";
+                } else {
+                    msg << "Error while computing raypaths: ray from Rx " << pc[3 * q] << ' ' << pc[3 * q + 1] << ' ' << pc[3 * q + 2]
+                        << " did not reach the source within " << max_steps << " steps";
+                }
+                throw std::runtime_error(msg.str());
+            }
+            if (record) {
+                off[0] = 0;
+                for (int q = 0; q < m; ++q) off[q + 1] = off[q] + np[q];
+                const long long tot = off[m];
+                d_rayoff.reserve(m + 1);
+                d_raydense.reserve((size_t)std::max<long long>(tot, 1) * 3);
+                HIP_CHECK(hipMemcpyAsync(d_rayoff.p, off.data(), sizeof(long long) * (m + 1), hipMemcpyHostToDevice, stream));
+                fsm_compact_rays<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p, translate ? ox : (T)0,
+                                                           translate ? oy : (T)0, translate ? oz : (T)0);
+                HIP_CHECK(hipGetLastError());
+                const size_t base = rays_pts.size();
+                rays_pts.resize(base + (size_t)tot * 3);
+                HIP_CHECK(hipMemcpyAsync(rays_pts.data() + base, d_raydense.p, sizeof(T) * 3 * tot, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                const long long prev = rays_off.back();
+                for (int q = 0; q < m; ++q) rays_off.push_back(prev + off[q + 1]);
+            }
         }
+    }
+
+    // rays of the last raytrace call with return_rays on, in the order of the receiver rows of that call
+    std::vector<long long> rays_off{0};
+    std::vector<T> rays_pts;
+    DevBuf<T> d_raypts, d_raydense;
+    DevBuf<int> d_raynp;
+    DevBuf<long long> d_rayoff;
+
+    void rays_size(size_t* n_rays, size_t* n_points) const override {
+        *n_rays = rays_off.size() - 1;
+        *n_points = (size_t)rays_off.back();
+    }
+    void get_rays(long long* offsets, void* pts) const override {
+        std::memcpy(offsets, rays_off.data(), rays_off.size() * sizeof(long long));
+        if (!rays_pts.empty()) std::memcpy(pts, rays_pts.data(), rays_pts.size() * sizeof(T));
     }
 
     // Grid3D::raytrace multi-source overload (ttcr/Grid3D.h:810-853)
@@ -886,6 +940,8 @@ class GridT : public GridBase {
         const auto wall0 = std::chrono::steady_clock::now();
         timing = Timing();
         timing.n_sources = n_src;
+        rays_off.assign(1, 0);
+        rays_pts.clear();
         if (!have_slowness) throw std::runtime_error("Error: slowness has not been assigned.");
         if (n_src <= 0) return;
         if (forced_slot >= 0) {
@@ -925,9 +981,10 @@ class GridT : public GridBase {
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
                 for (size_t b = 0; b < sl.size(); ++b) {
                     const int n = sr[b];
-                    if (ttrp)
+                    if (ttrp || return_rays)
                         raypath_grid_coords(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)nc * tx_off[n], t0 + tx_off[n],
-                                            rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n]);
+                                            rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n],
+                                            return_rays);
                     else
                         interp_grid_coords(sl[b], rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n]);
                 }
@@ -1092,8 +1149,18 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
             if (value != 0 && g->impl->dim != 3) throw Unsupported("tt_from_rp=True is only built for 3-D grids");
             g->impl->ttrp = value != 0;
         } else if (k == "interp_vel") g->impl->interp_vel = value != 0;
-        else throw ValueError("unknown option '" + k + "'");
+        else if (k == "return_rays") {
+            if (value != 0 && g->impl->dim != 3) throw Unsupported("return_rays=True is only built for 3-D grids");
+            g->impl->return_rays = value != 0;
+        } else throw ValueError("unknown option '" + k + "'");
     });
+}
+
+int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points) {
+    return guarded([&] { g->impl->rays_size(n_rays, n_points); });
+}
+int ttcr_fsm_get_rays(const ttcr_fsm_grid* g, long long* offsets, void* pts) {
+    return guarded([&] { g->impl->get_rays(offsets, pts); });
 }
 
 int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out) {

@@ -1801,59 +1801,95 @@ __device__ void step_to_plane(const RayGeom<T>& g, T* cur, const T* gv) {
     }
 }
 
-// status: 0 ok, 1 the ray left the grid (the reference throws), 2 step limit (the reference would not return)
-template <typename T>
+// status: 0 ok, 1 the ray left the grid (the reference throws), 2 step limit (the reference would not
+// return), 3 (RAYS) more than `cap` points -- npts still counts them, the host retries with room.
+// RAYS = false: Grid3Drn::getTraveltimeFromRaypath (ttcr/Grid3Drn.h:1103-1243).
+// RAYS = true:  Grid3Drn::getRaypath(Tx, t0, Rx, r_data, tt, threadNo) (ttcr/Grid3Drn.h:1339-1500): the same
+//               walk, every point recorded in pts[r][cap][3]; `back` is r_data.back() there, prev_pt here.
+template <typename T, bool RAYS>
 __global__ void fsm_raypath3d(const T* __restrict__ Tn, int ts, const T* __restrict__ sn, RayGeom<T> g, int n_src,
                               const T* __restrict__ src, const T* __restrict__ t0, const T* __restrict__ rcv, int n_rcv,
-                              T* __restrict__ out, int* __restrict__ status, long max_steps) {
+                              T* __restrict__ out, int* __restrict__ status, long max_steps, T* __restrict__ pts, long cap,
+                              int* __restrict__ npts) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rcv) return;
     const T rx[3] = {rcv[3 * r], rcv[3 * r + 1], rcv[3 * r + 2]};
     status[r] = 0;
+    long np = 0;
+    T* my_pts = RAYS ? pts + (size_t)r * cap * 3 : nullptr;
+    T back[3] = {rx[0], rx[1], rx[2]}, cur[3] = {rx[0], rx[1], rx[2]}, gv[3];
+    auto push = [&](const T* p) {
+        if (RAYS) {
+            if (np < cap) { my_pts[3 * np] = p[0]; my_pts[3 * np + 1] = p[1]; my_pts[3 * np + 2] = p[2]; }
+            back[0] = p[0]; back[1] = p[1]; back[2] = p[2];
+            ++np;
+        }
+    };
+    auto finish = [&](int st, T tt) {
+        if (RAYS) { npts[r] = (int)np; if (st == 0 && np > cap) st = 3; }
+        status[r] = st;
+        out[r] = tt;
+    };
+    push(rx);
     for (int ns = 0; ns < n_src; ++ns)
-        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) { out[r] = t0[ns]; return; }
+        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) { finish(0, t0[ns]); return; }
     T tt = 0, s1, s2;
-    T prev[3] = {rx[0], rx[1], rx[2]}, cur[3] = {rx[0], rx[1], rx[2]}, gv[3];
     s1 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
     const T dx = g.dx;
     const T maxDist = (T)__builtin_sqrt((double)(dx * dx + dx * dx + dx * dx));
     bool reached = false;
     long steps = 0;
     while (!reached) {
-        if (++steps > max_steps) { status[r] = 2; out[r] = tt; return; }
+        if (++steps > max_steps) { finish(2, tt); return; }
         grad3d(g, Tn, ts, cur[0], cur[1], cur[2], gv);
         gv[0] *= (T)-1.0; gv[1] *= (T)-1.0; gv[2] *= (T)-1.0;
         step_to_plane(g, cur, gv);
         if (cur[0] < g.xmin || cur[0] > g.xmax || cur[1] < g.ymin || cur[1] > g.ymax || cur[2] < g.zmin || cur[2] > g.zmax) {
-            status[r] = 1; out[r] = tt; return;
+            finish(1, tt); return;
         }
         s2 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
-        tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(prev, cur));
+        tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(back, cur));
         s1 = s2;
-        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        if (RAYS) push(cur); else { back[0] = cur[0]; back[1] = cur[1]; back[2] = cur[2]; }
         for (int ns = 0; ns < n_src; ++ns) {
             const T tx[3] = {src[3 * ns], src[3 * ns + 1], src[3 * ns + 2]};
             const T dist = dist3(cur, tx);
             if (dist < maxDist) {
                 gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1]; gv[2] = tx[2] - cur[2];
                 step_to_plane(g, cur, gv);
-                if (dist3(cur, prev) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
+                if (dist3(cur, back) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
                     s2 = slowness_at3d(g, sn, tx[0], tx[1], tx[2]);
-                    tt = (T)((double)tt + ((double)t0[ns] + (0.5 * (double)(s1 + s2)) * (double)dist3(prev, tx)));
+                    tt = (T)((double)tt + ((double)t0[ns] + (0.5 * (double)(s1 + s2)) * (double)dist3(back, tx)));
+                    push(tx);
                 } else {
                     s2 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
-                    tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(prev, cur));
+                    tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(back, cur));
+                    push(cur);
                     s1 = s2;
                     s2 = slowness_at3d(g, sn, tx[0], tx[1], tx[2]);
                     tt = (T)((double)tt + ((double)t0[ns] + (0.5 * (double)(s1 + s2)) * (double)dist3(cur, tx)));
+                    push(tx);
                 }
                 reached = true;
             }
         }
     }
-    out[r] = tt;
+    finish(0, tt);
 }
 
+
+// rays recorded in fixed-capacity rows -> one dense array (ray r occupies points [off[r], off[r+1]))
+template <typename T>
+__global__ void fsm_compact_rays(const T* __restrict__ pts, long cap, const long long* __restrict__ off,
+                                 T* __restrict__ out, T ox, T oy, T oz) {
+    const int r = blockIdx.x;
+    const long long a = off[r], n = off[r + 1] - a;
+    const T* src = pts + (size_t)r * cap * 3;
+    for (long long i = threadIdx.x; i < 3 * n; i += blockDim.x) {
+        const int c = (int)(i % 3);
+        out[3 * a + i] = src[i] + (c == 0 ? ox : (c == 1 ? oy : oz));
+    }
+}
 
 // Grid2Drn::getTraveltime (ttcr/Grid2Drn.h:359-414)
 template <typename T>

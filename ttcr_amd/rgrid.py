@@ -13,7 +13,7 @@ and error behaviour) for the fast-sweeping path:
 weno=True (the reference's default: first-order sweeps, then third-order WENO sweeps) is
 supported, and so is tt_from_rp=True in 3-D (the 3-D default: traveltimes integrated along the
 ray traced back through the field).  What is not on the FSM hot path raises NotImplementedError
-(SPM/DSPM, compute_L/compute_M, return_rays, 2-D tt_from_rp).  There is no CPU fallback.
+(SPM/DSPM, compute_L/compute_M, 2-D return_rays / tt_from_rp).  There is no CPU fallback.
 """
 import ctypes as C
 
@@ -218,7 +218,7 @@ class _GridBase:
                 vRx.append(rcv[iRx[n], :])
         return vTx, vt0, vRx, iRx
 
-    def _run(self, vTx, vt0, vRx, iRx, n_rcv, thread_no):
+    def _run(self, vTx, vt0, vRx, iRx, n_rcv, thread_no, return_rays=False):
         dt = self._dtype
         nd = self._ndim
         nTx = len(vTx)
@@ -241,7 +241,20 @@ class _GridBase:
         tt = np.zeros((n_rcv,), dtype=dt)
         for n in range(nTx):
             tt[iRx[n]] = out[rx_off[n]:rx_off[n + 1]]
-        return tt
+        if not return_rays:
+            return tt
+        # r_data of the raytrace overloads (rgrid.pyx:1096-1107): one (npts, 3) array per receiver row
+        nr, npnt = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(self._lib.ttcr_fsm_rays_size(self._h, C.byref(nr), C.byref(npnt)))
+        off = np.zeros(nr.value + 1, dtype=np.int64)
+        pts = np.empty((max(npnt.value, 1), 3), dtype=dt)
+        _lib.check(self._lib.ttcr_fsm_get_rays(self._h, _ptr(off), _ptr(pts)))
+        rays = [[0.0] for _ in range(n_rcv)]
+        for n in range(nTx):
+            for k, row in enumerate(iRx[n]):
+                a, b = off[rx_off[n] + k], off[rx_off[n] + k + 1]
+                rays[row] = np.array(pts[a:b], dtype=np.float64)
+        return tt, rays
 
 
 # ======================================================================================= 3-D
@@ -429,12 +442,20 @@ class _Grid3d(_GridBase):
             raise NotImplementedError('compute_L defined only for grids with slowness defined for cells')
         if compute_L:
             raise NotImplementedError('compute_L defined for the FSM')
-        if compute_M or return_rays:
-            raise NotImplementedError('compute_M / return_rays (raypaths, ttcr/Grid3Drn.h:1247-2450) are not built yet')
+        if compute_M:
+            raise NotImplementedError('compute_M (ttcr/Grid3Drn.h:1503-1800) is not built yet')
         vTx, vt0, vRx, iRx = self._split_sources(source, rcv, aggregate_src)
         if slowness is not None:
             self.set_slowness(slowness)
-        return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
+        if not return_rays:
+            return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
+        # -> (tt, rays): the overloads with r_data; traveltimes are then integrated along the rays whatever
+        # tt_from_rp says (Grid3D::raytrace, ttcr/Grid3D.h:546-586 -> getRaypath, ttcr/Grid3Drn.h:1339-1500)
+        self.set_option("return_rays", 1)
+        try:
+            return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no, return_rays=True)
+        finally:
+            self.set_option("return_rays", 0)
 
 
 def _builder3d(cls, filename, n_threads=1, method='FSM', tt_from_rp=1, interp_vel=0, eps=1.e-5, maxit=50, weno=1,
