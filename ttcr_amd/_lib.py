@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libttcr_amd.so")
+LIB_PATH = os.environ.get("TTCR_AMD_LIB") or os.path.join(HERE, "libttcr_amd.so")  # override: tuning builds only
 
 TTCR_F32, TTCR_F64 = 0, 1
 OK, ERR_VALUE, ERR_RUNTIME, ERR_DEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4

@@ -102,10 +102,16 @@ class GridBase {
 template <typename T, int DIM> struct TileCfg;
 template <> struct TileCfg<float, 3> { static constexpr int PJ = 16, PK = 16, BL = 16; };
 template <> struct TileCfg<double, 3> { static constexpr int PJ = 16, PK = 8, BL = 16; };
-template <> struct TileCfg<float, 2> { static constexpr int PJ = 128, PK = 1, BL = 32; };
-template <> struct TileCfg<double, 2> { static constexpr int PJ = 128, PK = 1, BL = 32; };
+#ifndef FSM_PJ2
+#define FSM_PJ2 64
+#endif
+#ifndef FSM_CHUNK2
+#define FSM_CHUNK2 16
+#endif
+template <> struct TileCfg<float, 2> { static constexpr int PJ = FSM_PJ2, PK = 1, BL = 32; };
+template <> struct TileCfg<double, 2> { static constexpr int PJ = FSM_PJ2, PK = 1, BL = 32; };
 // chunk length of the persistent kernel
-template <typename T, int DIM> struct ChunkCfg { static constexpr int C = DIM == 3 ? FSM_CHUNK3 : 16; };
+template <typename T, int DIM> struct ChunkCfg { static constexpr int C = DIM == 3 ? FSM_CHUNK3 : FSM_CHUNK2; };
 
 template <typename T>
 class GridT : public GridBase {
