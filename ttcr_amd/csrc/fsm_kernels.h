@@ -154,9 +154,9 @@ __device__ __forceinline__ float update2_fh(float a, float b, float fh) {
     if (__builtin_fabsf(d) >= fh) return (a < b ? a : b) + fh;
     const float d2 = d * d;
     const double dfh = fh;
-    const double disc = __builtin_fma(2.0 * dfh, dfh, -(double)d2);
+    const double disc = __builtin_fma(2.0 * dfh, dfh, -(double)d2);   // finite: |d| < fh here (or NaN)
     const float sab = a + b;
-    return (float)(0.5 * ((double)sab + __builtin_sqrt(disc)));
+    return (float)(0.5 * ((double)sab + sqrt_disc(disc)));
 }
 __device__ __forceinline__ double update2_fh(double a, double b, double fh) {
     if (__builtin_fabs(a - b) >= fh) return (a < b ? a : b) + fh;
