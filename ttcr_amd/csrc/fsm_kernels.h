@@ -904,6 +904,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     bool have_prev = false;   // carry[] is valid (the previous chunk was evaluated)
     bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
+    int pending = 0;            // progress value of the previous chunk, published once its stores have drained
     if (XS && dir > 0) {
         // previous sweep of this iteration: wait for the patches (of ITS oriented partition) that own
         // a column within 2H of ours -- at most 3 x 3 of them, one lane each
@@ -1007,9 +1008,11 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             // nothing in the read set changed since this chunk was last evaluated: no-op
             have_prev = false;
             quiet = true;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores of the chunk before, if any
             __syncthreads();  // s_skip is rewritten by the next chunk
             if (tid == 0)
                 __hip_atomic_store(my_prog, Lc + C > Le ? 0x3fffffff : Lc + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending = 0;
             continue;
         }
         if (pref_for != L0) issue_static(L0);
@@ -1050,11 +1053,16 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         }
 #pragma unroll
         for (int q = 0; q < 2 * H; ++q) Tt[row * RS + q] = carry[q];
+        // the halo loads have to land anyway: the same wait drains the write-back of the previous chunk,
+        // whose progress value goes out right after the barrier (store drain and halo latency overlap)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < NUPI; ++it)
             if (ulrow[it] >= 0) Tt[ulrow[it]] = uv[it];
         if (H == 2 && xlrow >= 0) Tt[xlrow] = xv;
         __syncthreads();
+        if (tid == 0 && pending) __hip_atomic_store(my_prog, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = 0;
 
         bool near_src[NS];
         {
@@ -1205,12 +1213,15 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                 }
             }
         }
-        // (6) publish: every wave drains its stores, barrier, one lane moves the counter
+        // (6) publish later: the counter moves once every wave has drained these stores -- at the
+        //     staging barrier of the next chunk, or right after the loop
+        pending = Lc + C > Le ? 0x3fffffff : Lc + C;
+        FSM_PROF_MARK(4)
+    }
+    if (pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(my_prog, Lc + C > Le ? 0x3fffffff : Lc + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        FSM_PROF_MARK(4)
+        if (tid == 0) __hip_atomic_store(my_prog, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // L1 decrease of every source of the unit: wavefront reduction, one atomic per wave and source
