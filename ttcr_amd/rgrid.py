@@ -443,7 +443,8 @@ class _Grid3d(_GridBase):
         if compute_L:
             raise NotImplementedError('compute_L defined for the FSM')
         if compute_M:
-            raise NotImplementedError('compute_M (ttcr/Grid3Drn.h:1503-1800) is not built yet')
+            raise NotImplementedError('compute_M is not built: the reference overload (ttcr/Grid3Drn.h:1503-1800) '
+                                      'yields zero weights for every interior ray segment (see DESIGN.md section 1)')
         vTx, vt0, vRx, iRx = self._split_sources(source, rcv, aggregate_src)
         if slowness is not None:
             self.set_slowness(slowness)
