@@ -1127,9 +1127,13 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
 #pragma unroll
             for (int l = 0; l < NS; ++l) {
                 bool active = in_grid & ((lm >> l) & 1);
-                if (near_src[l] && active) {
-                    const uint32_t n = colbase + (rf ? NF - 1 - ip : ip);
-                    active = !((Fz[(size_t)l * a.mask_words + (n >> 5)] >> (n & 31)) & 1u);
+                if (near_src[l]) {   // block-uniform and rare: keep the index arithmetic out of the common path
+                    int ipn = ip;
+                    asm volatile("" : "+v"(ipn));
+                    if (active) {
+                        const uint32_t n = colbase + (rf ? NF - 1 - ipn : ipn);
+                        active = !((Fz[(size_t)l * a.mask_words + (n >> 5)] >> (n & 31)) & 1u);
+                    }
                 }
                 T t;
                 if (H == 1) {
