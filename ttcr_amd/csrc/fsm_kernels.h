@@ -57,6 +57,12 @@ __device__ __forceinline__ double rmin(double a, double b) { return a < b ? a : 
 __device__ __forceinline__ float rmax(float a, float b) { return a < b ? b : a; }
 __device__ __forceinline__ double rmax(double a, double b) { return a < b ? b : a; }
 
+// wave-uniform "any lane" tests.  A ballot of a general bool goes through a VALU select + compare;
+// a compare builtin writes the lane mask straight into a scalar pair, and masks combine on the SALU.
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ unsigned long long lanes_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2); }   // FCMP_OGT
+__device__ __forceinline__ unsigned long long lanes_gt(double a, double b) { return __builtin_amdgcn_fcmp(a, b, 2); }
+
 // ---- 3-D local solver: Grid3Drn::update_node, ttcr/Grid3Drn.h:2936-2956 -------------------
 // inputs: the three axis minima (any order), node slowness s, cell size dx. Returns candidate t.
 // fp64 square root for the discriminants: the same Goldschmidt sequence the compiler emits for
@@ -77,10 +83,10 @@ __device__ __forceinline__ double sqrt_disc(double x) {
     return x == 0.0 ? x : g;
 }
 
-// `live`: lanes whose result is used.  When no live lane of the wavefront leaves the 1-D branch
+// `live_lanes`: lane mask of the results that are used.  When no live lane of the wavefront leaves the 1-D branch
 // (t1 <= a2: unreached regions, where every neighbour is still FLT_MAX, and grazing fronts) the
 // fp64 work is skipped for the whole wave -- a wave-uniform branch, values unchanged.
-__device__ __forceinline__ float update3(float ax, float ay, float az, float s, float dx, bool live) {
+__device__ __forceinline__ float update3(float ax, float ay, float az, float s, float dx, unsigned long long live_lanes) {
     // sort (std::swap network of :2936-2938; values only, so min/max/med3 is equivalent)
     const float a1 = __builtin_fminf(__builtin_fminf(ax, ay), az);
     const float a3 = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
@@ -88,8 +94,8 @@ __device__ __forceinline__ float update3(float ax, float ay, float az, float s, 
     const float fh = s * dx;
     const float t1 = a1 + fh;
     float t = t1;
-    const bool beyond1d = live && t1 > a2;
-    if (__any(beyond1d)) {
+    const unsigned long long beyond1d = lanes_gt(t1, a2) & live_lanes;
+    if (beyond1d != 0ull) {
         const double d1 = a1, d2 = a2, d3 = a3, dfh = fh;
         // -2.*a1*a1 + 2.*a1*a2 - 2.*a2*a2 + 2.*a1*a3 + 2.*a2*a3 - 2.*a3*a3 + 3.*fh*fh, left to
         // right.  Every product is exact in double, so fma(x,y,acc) rounds exactly like the
@@ -115,8 +121,7 @@ __device__ __forceinline__ float update3(float ax, float ay, float az, float s, 
         const float u = a3 - a1, v = a3 - a2;
         const float slack = fh * fh - (u * u + v * v);
         const float thr = 4e-6f * fh * (__builtin_fabsf(a1) + __builtin_fabsf(a3) + fh);
-        const bool clear3 = slack > thr;
-        if (__any(beyond1d && !clear3)) {
+        if ((beyond1d & ~lanes_gt(slack, thr)) != 0ull) {
             // 2.*fh*fh - (a1-a2)*(a1-a2): fh*fh exact in double, (a1-a2)^2 rounded in float
             const float df = a1 - a2;
             const float df2 = df * df;
@@ -130,14 +135,14 @@ __device__ __forceinline__ float update3(float ax, float ay, float az, float s, 
     return t;
 }
 
-__device__ __forceinline__ double update3(double ax, double ay, double az, double s, double dx, bool live) {
+__device__ __forceinline__ double update3(double ax, double ay, double az, double s, double dx, unsigned long long live_lanes) {
     const double a1 = __builtin_fmin(__builtin_fmin(ax, ay), az);
     const double a3 = __builtin_fmax(__builtin_fmax(ax, ay), az);
     const double a2 = __builtin_fmax(__builtin_fmin(ax, ay), __builtin_fmin(__builtin_fmax(ax, ay), az));
     const double fh = s * dx;
     const double t1 = a1 + fh;
     double t = t1;
-    if (__any(live && t1 > a2)) {
+    if ((lanes_gt(t1, a2) & live_lanes) != 0ull) {
         const double t2 = 0.5 * (a1 + a2 + __builtin_sqrt(2. * fh * fh - (a1 - a2) * (a1 - a2)));
         const double t3 = 1. / 3. * ((a1 + a2 + a3) + __builtin_sqrt(-2. * a1 * a1 + 2. * a1 * a2 - 2. * a2 * a2 +
                                                                       2. * a1 * a3 + 2. * a2 * a3 -
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
         T t;
         if (IS3D) {
             const T ak = vmin(Tt[(row - RJ) * RS + q - 1], Tt[(row + RJ) * RS + q + 1]);
-            t = update3(ak, aj, af, s, dx, active);
+            t = update3(ak, aj, af, s, dx, __builtin_amdgcn_ballot_w64(active));
         } else {
             // 2-D: J axis is x (a), F axis is z (b)
             t = variant == 1 ? update2(aj, af, s, dx) : update2_xz(aj, af, s, dx, dz);
@@ -1109,6 +1114,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         for (int ee = 0; ee < C; ++ee) {
             const int q = ee + H;
             const bool in_grid = (ee >= ea) & (ee <= eb);
+            // the same as a lane mask: compare builtins write scalar pairs, no VALU select/compare round trip
+            const unsigned long long grid_lanes = __builtin_amdgcn_sicmp(ea, ee, 41) & __builtin_amdgcn_sicmp(eb, ee, 39);   // SLE, SGE
             const int ip = L0 + ee - jp - kp;
             const P c = own[q];
             // neighbour values of both sources arrive with one LDS access each
@@ -1127,6 +1134,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
 #pragma unroll
             for (int l = 0; l < NS; ++l) {
                 bool active = in_grid & ((lm >> l) & 1);
+                unsigned long long live_lanes = ((lm >> l) & 1) ? grid_lanes : 0ull;
                 if (near_src[l]) {   // block-uniform and rare: keep the index arithmetic out of the common path
                     int ipn = ip;
                     asm volatile("" : "+v"(ipn));
@@ -1134,6 +1142,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                         const uint32_t n = colbase + (rf ? NF - 1 - ipn : ipn);
                         active = !((Fz[(size_t)l * a.mask_words + (n >> 5)] >> (n & 31)) & 1u);
                     }
+                    live_lanes = __builtin_amdgcn_ballot_w64(active);
                 }
                 T t;
                 if (H == 1) {
@@ -1141,7 +1150,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                     const T aj = vmin(jm1.v[l], jp1.v[l]);
                     if (IS3D) {
                         const T ak = vmin(km1.v[l], kp1.v[l]);
-                        t = update3(ak, aj, af, sc[ee], dx, active);
+                        t = update3(ak, aj, af, sc[ee], dx, live_lanes);
                     } else {
                         t = variant == 1 ? update2(aj, af, sc[ee], dx) : update2_xz(aj, af, sc[ee], dx, dz);
                     }
