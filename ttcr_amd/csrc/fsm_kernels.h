@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                 }
                 const bool acc = active & (t < c.v[l]);
                 nv.v[l] = acc ? t : c.v[l];
-                dec[l] += acc ? c.v[l] - t : (T)0;
+                dec[l] += acc ? c.v[l] - t : (T)0;   // (c - nv would be inf - inf on the out-of-grid entries)
                 changed |= acc;
                 chg_a |= acc & (ee < e_split);
                 chg_b |= acc & (ee >= e_split);
