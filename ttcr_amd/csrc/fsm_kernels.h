@@ -506,7 +506,17 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
 // 1078-1125).  Every named intermediate of the reference is a T1 and its double literals make the
 // right-hand sides double: reproduced operation by operation (no fused shortcuts: the divisions
 // are IEEE divisions).  v1..v4 / v0..v3 are in NATURAL index order along the axis.
-__device__ __forceinline__ float weno_fwd(float v1, float v2, float v3, float v4, float h) {
+// x / h2 for h2 = 2*(double)h with h a float, r2 = RN(1/h2) (one true division per kernel).  h2 has a
+// 24-bit significand, so the residual x - q0*h2 is exact and x/h2 can never sit closer than 2^-25 ulp to
+// a rounding boundary, while q0 + res*r2 is off by < 2^-52 ulp: ONE fused correction gives the
+// correctly rounded quotient (3 ops instead of the ~17 of an IEEE division).  x is finite or NaN here
+// (sums of a few float-range terms in double), so no infinity fix-up is needed.
+__device__ __forceinline__ double div_h2(double x, double h2, double r2) {
+    const double q0 = x * r2;
+    return __builtin_fma(__builtin_fma(-q0, h2, x), r2, q0);
+}
+
+__device__ __forceinline__ float weno_fwd(float v1, float v2, float v3, float v4, float h, double r2) {
     const float eps = 1.1920928955078125e-07f;
     const float num = (float)(((double)v4 - 2.0 * (double)v3) + (double)v2);
     const float den = (float)(((double)v3 - 2.0 * (double)v2) + (double)v1);
@@ -514,11 +524,11 @@ __device__ __forceinline__ float weno_fwd(float v1, float v2, float v3, float v4
     const float w = (float)(1.0 / (1.0 + (2.0 * (double)r) * (double)r));
     const float d31 = v3 - v1;
     const double h2 = 2.0 * (double)h;
-    const double ap = ((1.0 - (double)w) * (double)d31) / h2 +
-                      ((double)w * ((-(double)v4 + 4.0 * (double)v3) - 3.0 * (double)v2)) / h2;
+    const double ap = div_h2((1.0 - (double)w) * (double)d31, h2, r2) +
+                      div_h2((double)w * ((-(double)v4 + 4.0 * (double)v3) - 3.0 * (double)v2), h2, r2);
     return v2 + h * (float)ap;
 }
-__device__ __forceinline__ float weno_bwd(float v0, float v1, float v2, float v3, float h) {
+__device__ __forceinline__ float weno_bwd(float v0, float v1, float v2, float v3, float h, double r2) {
     const float eps = 1.1920928955078125e-07f;
     const float num = (float)(((double)v2 - 2.0 * (double)v1) + (double)v0);
     const float den = (float)(((double)v3 - 2.0 * (double)v2) + (double)v1);
@@ -526,11 +536,11 @@ __device__ __forceinline__ float weno_bwd(float v0, float v1, float v2, float v3
     const float w = (float)(1.0 / (1.0 + (2.0 * (double)r) * (double)r));
     const float d31 = v3 - v1;
     const double h2 = 2.0 * (double)h;
-    const double am = ((1.0 - (double)w) * (double)d31) / h2 +
-                      ((double)w * ((3.0 * (double)v2 - 4.0 * (double)v1) + (double)v0)) / h2;
+    const double am = div_h2((1.0 - (double)w) * (double)d31, h2, r2) +
+                      div_h2((double)w * ((3.0 * (double)v2 - 4.0 * (double)v1) + (double)v0), h2, r2);
     return v2 - h * (float)am;
 }
-__device__ __forceinline__ double weno_fwd(double v1, double v2, double v3, double v4, double h) {
+__device__ __forceinline__ double weno_fwd(double v1, double v2, double v3, double v4, double h, double) {
     const double eps = 2.220446049250313e-16;
     const double num = (v4 - 2.0 * v3 + v2);
     const double den = (v3 - 2.0 * v2 + v1);
@@ -539,7 +549,7 @@ __device__ __forceinline__ double weno_fwd(double v1, double v2, double v3, doub
     const double ap = (1.0 - w) * (v3 - v1) / (2.0 * h) + w * (-v4 + 4.0 * v3 - 3.0 * v2) / (2.0 * h);
     return v2 + h * ap;
 }
-__device__ __forceinline__ double weno_bwd(double v0, double v1, double v2, double v3, double h) {
+__device__ __forceinline__ double weno_bwd(double v0, double v1, double v2, double v3, double h, double) {
     const double eps = 2.220446049250313e-16;
     const double num = (v2 - 2.0 * v1 + v0);
     const double den = (v3 - 2.0 * v2 + v1);
@@ -552,23 +562,23 @@ __device__ __forceinline__ double weno_bwd(double v0, double v1, double v2, doub
 // One axis of update_node_weno3 (ttcr/Grid3Drn.h:3084-3196): m2..p2 are the values at natural
 // offsets -2..+2 along the axis, idx the node's natural index, n the last index.
 template <typename T>
-__device__ __forceinline__ T weno_axis(T m2, T m1, T c, T p1, T p2, int idx, int n, T h) {
+__device__ __forceinline__ T weno_axis(T m2, T m1, T c, T p1, T p2, int idx, int n, T h, double r2) {
     T a, t;
     if (idx == 0) {
         a = p1;
     } else if (idx == 1) {
-        a = weno_fwd(m1, c, p1, p2, h);
+        a = weno_fwd(m1, c, p1, p2, h, r2);
         t = m1;
         a = a < t ? a : t;
     } else if (idx == n) {
         a = m1;
     } else if (idx == n - 1) {
-        a = weno_bwd(m2, m1, c, p1, h);
+        a = weno_bwd(m2, m1, c, p1, h, r2);
         t = p1;
         a = a < t ? a : t;
     } else {
-        a = weno_fwd(m1, c, p1, p2, h);
-        t = weno_bwd(m2, m1, c, p1, h);
+        a = weno_fwd(m1, c, p1, p2, h, r2);
+        t = weno_bwd(m2, m1, c, p1, h, r2);
         a = a < t ? a : t;
     }
     return a;
@@ -749,6 +759,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     const int kn = rk ? NK - 1 - kp : kp;
     const uint32_t colbase = ((uint32_t)kn * NJ + jn) * NF;
     const T dx = a.dx, dz = a.dz;
+    // WENO stage: correctly rounded 1/(2h), the one true division of the axis derivatives (see div_h2)
+    const double r2x = H == 2 ? 1.0 / (2.0 * (double)dx) : 0.0, r2z = H == 2 ? 1.0 / (2.0 * (double)dz) : 0.0;
     const int variant = a.variant;
     const uint32_t* __restrict__ Fz = a.frozen + (size_t)grp * NS * a.mask_words;   // + l * mask_words
     const int* bb = a.bbox + 6 * grp * NS;                                           // + 6 * l
@@ -1159,14 +1171,15 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                     // offset -d is natural offset -d when the axis is swept upwards, +d otherwise.
                     const int in = rf ? NF - 1 - ip : ip;
                     const T hF = IS3D ? dx : (variant == 2 ? dz : dx);
+                    const double r2F = IS3D ? r2x : (variant == 2 ? r2z : r2x);
                     const T cc = c.v[l];
-                    const T aF = rf ? weno_axis(fp2.v[l], fp1.v[l], cc, fm1.v[l], fm2.v[l], in, NF - 1, hF)
-                                    : weno_axis(fm2.v[l], fm1.v[l], cc, fp1.v[l], fp2.v[l], in, NF - 1, hF);
-                    const T aJ = rj ? weno_axis(jp2.v[l], jp1.v[l], cc, jm1.v[l], jm2.v[l], jn, NJ - 1, dx)
-                                    : weno_axis(jm2.v[l], jm1.v[l], cc, jp1.v[l], jp2.v[l], jn, NJ - 1, dx);
+                    const T aF = rf ? weno_axis(fp2.v[l], fp1.v[l], cc, fm1.v[l], fm2.v[l], in, NF - 1, hF, r2F)
+                                    : weno_axis(fm2.v[l], fm1.v[l], cc, fp1.v[l], fp2.v[l], in, NF - 1, hF, r2F);
+                    const T aJ = rj ? weno_axis(jp2.v[l], jp1.v[l], cc, jm1.v[l], jm2.v[l], jn, NJ - 1, dx, r2x)
+                                    : weno_axis(jm2.v[l], jm1.v[l], cc, jp1.v[l], jp2.v[l], jn, NJ - 1, dx, r2x);
                     if (IS3D) {
-                        const T aK = rk ? weno_axis(kp2.v[l], kp1.v[l], cc, km1.v[l], km2.v[l], kn, NK - 1, dx)
-                                        : weno_axis(km2.v[l], km1.v[l], cc, kp1.v[l], kp2.v[l], kn, NK - 1, dx);
+                        const T aK = rk ? weno_axis(kp2.v[l], kp1.v[l], cc, km1.v[l], km2.v[l], kn, NK - 1, dx, r2x)
+                                        : weno_axis(km2.v[l], km1.v[l], cc, kp1.v[l], kp2.v[l], kn, NK - 1, dx, r2x);
                         // a1 <- K axis, a2 <- J axis, a3 <- F axis, as in the reference (k, j, i)
                         t = solve3_literal(aK, aJ, aF, sc[ee] * dx);
                     } else {
