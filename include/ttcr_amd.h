@@ -125,13 +125,15 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "tt_from_rp"   1: receiver traveltimes are integrated along the ray traced back through the
  *                     traveltime field (replaces setTraveltimeFromRaypath(bool), ttcr/Grid3D.h, and the
  *                     `ttrp` constructor argument; Grid3Drn::getTraveltimeFromRaypath, ttcr/Grid3Drn.h:
- *                     1103-1243; 3-D only); 0: trilinear interpolation (getTraveltime).  Default 0.
+ *                     1103-1243; 2-D: Grid2Drn::getTraveltimeFromRaypath, ttcr/Grid2Drn.h:1478-1661);
+ *                     0: tri/bilinear interpolation (getTraveltime).  Default 0.
  *   "interp_vel"   1: the ray integration interpolates velocity instead of slowness (`intVel`
  *                     constructor argument / processVel, ttcr/Grid3Drn.h:2451-2676).  Default 0.
  *   "return_rays"  1: the raytrace calls follow the overloads with r_data (Grid3D::raytrace(Tx,t0,Rx,tt,
  *                     r_data,threadNo), ttcr/Grid3D.h:546-586): receiver traveltimes AND raypaths come from
  *                     Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) (ttcr/Grid3Drn.h:1339-1500); the rays
- *                     stay in the grid until the next raytrace call, see ttcr_fsm_get_rays.  3-D only.
+ *                     stay in the grid until the next raytrace call, see ttcr_fsm_get_rays (2-D: Grid2Drn::
+ *                     getRaypath, ttcr/Grid2Drn.h:1663-1850, points are (x, z) pairs).
  *   "skip"         1: persistent kernel skips chunks whose read set (bricks of 16^3 nodes, tracked
  *                     by last-change sweep number) did not change since their last evaluation --
  *                     exact, results and iteration counts are unchanged; 0: evaluate every chunk (default) */
@@ -139,9 +141,9 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 /* Replaces: the r_data output of the raytrace overloads above (std::vector<std::vector<sxyz<T1>>>&,
  * src/ttcrpy/rgrid.pxd:60-75).  After a raytrace call with option "return_rays" = 1: one ray per receiver
- * row of that call, in row order; ray n is points [offsets[n], offsets[n+1]) of pts (x,y,z triples of the
+ * row of that call, in row order; ray n is points [offsets[n], offsets[n+1]) of pts (x,y,z triples -- x,z pairs in 2-D -- of the
  * grid's dtype), from the receiver to the source.  Two calls: sizes first, then the copy into caller
- * buffers of n_rays+1 offsets and 3*n_points coordinates. */
+ * buffers of n_rays+1 offsets and 3*n_points (2-D: 2*n_points) coordinates. */
 int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points);
 int ttcr_fsm_get_rays(const ttcr_fsm_grid* g, long long* offsets, void* pts);
 

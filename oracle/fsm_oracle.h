@@ -40,7 +40,10 @@ extern "C" {
     int fsm_solve2d_##S(const fsm_grid2d_##S* g, const REAL* s, int n_src, const REAL* src,          \
                         const REAL* t0, REAL eps, int maxit, int weno, REAL* T, REAL* change_hist,   \
                         int* niterw_out);                                                            \
-    REAL fsm_interp2d_##S(const fsm_grid2d_##S* g, const REAL* T, REAL px, REAL pz);
+    REAL fsm_interp2d_##S(const fsm_grid2d_##S* g, const REAL* T, REAL px, REAL pz);                 \
+    int fsm_raypath2d_##S(const fsm_grid2d_##S* g, const REAL* sn, const REAL* sc, const REAL* T,    \
+                          int n_src, const REAL* src, const REAL* t0, const REAL rx[2], int record,  \
+                          long max_steps, REAL* tt_out, REAL* pts, long cap, long* npts);
 
 FSM_ORACLE_DECL(float, f32)
 FSM_ORACLE_DECL(double, f64)

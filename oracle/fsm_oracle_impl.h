@@ -1122,5 +1122,152 @@ REAL SFX(fsm_interp2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL p
     return tt;
 }
 
+/* ---- 2-D raypath family ----------------------------------------------------------------------
+ * Grid2Drn::grad(g, pt, nt), ttcr/Grid2Drn.h:606-632: centred difference of interpolated traveltimes
+ * over one cell, window clamped to the grid. */
+static void SFX(grad2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL pz, REAL* gx, REAL* gz) {
+    const REAL dx = g->dx, dz = g->dz;
+    REAL p1 = px - dx / 2.0;
+    if (p1 < g->xmin) p1 = g->xmin;
+    REAL p2 = p1 + dx;
+    if (p2 > g->xmax) {
+        p2 = g->xmax;
+        p1 = g->xmax - dx;
+    }
+    *gx = (SFX(fsm_interp2d)(g, T, p2, pz) - SFX(fsm_interp2d)(g, T, p1, pz)) / dx;
+    p1 = pz - dz / 2.0;
+    if (p1 < g->zmin) p1 = g->zmin;
+    p2 = p1 + dz;
+    if (p2 > g->zmax) {
+        p2 = g->zmax;
+        p1 = g->zmax - dz;
+    }
+    *gz = (SFX(fsm_interp2d)(g, T, px, p2) - SFX(fsm_interp2d)(g, T, px, p1)) / dz;
+}
+
+/* Grid2Drn::getCellNo, ttcr/Grid2Drn.h:170-176 */
+static uint32_t SFX(cellno2d)(const SFX(fsm_grid2d) * g, REAL px, REAL pz) {
+    const REAL x = g->xmax - px < FSM_SMALL ? (REAL)(g->xmax - .5 * g->dx) : px;
+    const REAL z = g->zmax - pz < FSM_SMALL ? (REAL)(g->zmax - .5 * g->dz) : pz;
+    const uint32_t nx = (uint32_t)(FSM_SMALL + (x - g->xmin) / g->dx);
+    const uint32_t nz = (uint32_t)(FSM_SMALL + (z - g->zmin) / g->dz);
+    return nx * (uint32_t)(g->nnz - 1) + nz;
+}
+
+/* "advance curr along gv to the next grid line of cell (i,k)" (ttcr/Grid2Drn.h:1510-1533 and twins);
+ * (i,k) is the cell index taken at the START of the walk step -- the reference does not refresh it */
+static void SFX(step2d)(const SFX(fsm_grid2d) * g, ptrdiff_t i, ptrdiff_t k, REAL cur[2], const REAL gv[2]) {
+    const REAL dx = g->dx, dz = g->dz;
+    REAL xp = g->xmin + dx * (i + (SFX(sgn)(gv[0]) > 0.0 ? 1.0 : 0.0));
+    REAL zp = g->zmin + dz * (k + (SFX(sgn)(gv[1]) > 0.0 ? 1.0 : 0.0));
+    if (FABS(xp - cur[0]) < FSM_SMALL) xp += dx * SFX(sgn)(gv[0]);
+    if (FABS(zp - cur[1]) < FSM_SMALL) zp += dz * SFX(sgn)(gv[1]);
+    REAL tx = gv[0] != 0.0 ? (xp - cur[0]) / gv[0] : REAL_MAX;
+    REAL tz = gv[1] != 0.0 ? (zp - cur[1]) / gv[1] : REAL_MAX;
+    if (tx < tz) {
+        cur[0] += tx * gv[0]; cur[1] += tx * gv[1];
+        cur[0] = xp;
+    } else {
+        cur[0] += tz * gv[0]; cur[1] += tz * gv[1];
+        cur[1] = zp;
+    }
+}
+
+/* record == 0: Grid2Drn::getTraveltimeFromRaypath (ttcr/Grid2Drn.h:1478-1661)
+ * record == 1: Grid2Drn::getRaypath(Tx, t0, Rx, r_data, tt, threadNo) (:1663-1850): the same walk with every
+ *              point recorded, `back` being r_data.back() (prev_pt in the other one).
+ * sn: node slowness; sc: cell slowness of a Grid2Drcfs (hasCellSlowness, ttcr/Grid2Drcfs.h:62-68) or NULL.
+ * Returns 0 ok, 1 ray left the grid twice (the reference throws), 2 step limit, 3 capacity exceeded. */
+int SFX(fsm_raypath2d)(const SFX(fsm_grid2d) * g, const REAL* sn, const REAL* sc, const REAL* T, int n_src,
+                       const REAL* src, const REAL* t0, const REAL rx[2], int record, long max_steps, REAL* tt_out,
+                       REAL* pts, long cap, long* npts) {
+    REAL tt = 0.0;
+    REAL s1 = 0.0, s2 = 0.0, slown = 0.0;
+    long np = 0;
+    int over = 0;
+    REAL back[2] = {rx[0], rx[1]}, cur[2] = {rx[0], rx[1]}, gv[2];
+#define FSM_PUSH2(P) do { if (record) { if (np < cap) { pts[2 * np] = (P)[0]; pts[2 * np + 1] = (P)[1]; } else over = 1; \
+                                         back[0] = (P)[0]; back[1] = (P)[1]; ++np; } } while (0)
+    FSM_PUSH2(rx);
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[2 * ns] && rx[1] == src[2 * ns + 1]) { *tt_out = t0[ns]; if (npts) *npts = np; return 0; }
+    if (!sc) s1 = SFX(fsm_interp2d)(g, sn, cur[0], cur[1]);   /* getSlowness has the shape of getTraveltime */
+    const REAL dx = g->dx, dz = g->dz;
+    const REAL maxDist = (REAL)sqrt(dx * dx + dz * dz);
+    int reached = 0;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) { if (npts) *npts = np; return 2; }
+        SFX(grad2d)(g, T, cur[0], cur[1], &gv[0], &gv[1]);
+        gv[0] *= (REAL)-1.0; gv[1] *= (REAL)-1.0;
+        const ptrdiff_t i = (ptrdiff_t)(FSM_SMALL + (cur[0] - g->xmin) / dx);
+        const ptrdiff_t k = (ptrdiff_t)(FSM_SMALL + (cur[1] - g->zmin) / dz);
+        SFX(step2d)(g, i, k, cur, gv);
+        if (cur[0] < g->xmin || cur[0] > g->xmax || cur[1] < g->zmin || cur[1] > g->zmax) {
+            /* going outside: slide along the face instead (:1536-1581) */
+            /* the reference writes an unqualified abs() here, which binds to the C int overload:
+             * both components are truncated to integers before the comparison (:1538) */
+            if (abs((int)gv[0]) > abs((int)gv[1])) { gv[0] = (REAL)SFX(sgn)(gv[0]); gv[1] = 0.0; }
+            else { gv[1] = (REAL)SFX(sgn)(gv[1]); gv[0] = 0.0; }
+            cur[0] = back[0]; cur[1] = back[1];
+            SFX(step2d)(g, i, k, cur, gv);
+            if (cur[0] < g->xmin || cur[0] > g->xmax || cur[1] < g->zmin || cur[1] > g->zmax) { if (npts) *npts = np; return 1; }
+        }
+        if (sc) {
+            const REAL mx = (REAL)0.5 * (back[0] + cur[0]), mz = (REAL)0.5 * (back[1] + cur[1]);
+            slown = sc[SFX(cellno2d)(g, mx, mz)];
+        } else {
+            s2 = SFX(fsm_interp2d)(g, sn, cur[0], cur[1]);
+            slown = 0.5 * (s1 + s2);
+            s1 = s2;
+        }
+        tt += slown * SFX(dist2d)(back[0], back[1], cur[0], cur[1]);
+        if (record) FSM_PUSH2(cur); else { back[0] = cur[0]; back[1] = cur[1]; }
+        for (int ns = 0; ns < n_src; ++ns) {
+            const REAL* tx = src + 2 * ns;
+            const REAL dist = SFX(dist2d)(cur[0], cur[1], tx[0], tx[1]);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1];
+                SFX(step2d)(g, i, k, cur, gv);
+                if (SFX(dist2d)(cur[0], cur[1], back[0], back[1]) > dist || (cur[0] == tx[0] && cur[1] == tx[1])) {
+                    if (sc) {
+                        const REAL mx = (REAL)0.5 * (back[0] + tx[0]), mz = (REAL)0.5 * (back[1] + tx[1]);
+                        slown = sc[SFX(cellno2d)(g, mx, mz)];
+                    } else {
+                        s2 = SFX(fsm_interp2d)(g, sn, tx[0], tx[1]);
+                        slown = 0.5 * (s1 + s2);
+                    }
+                    tt += slown * SFX(dist2d)(back[0], back[1], tx[0], tx[1]);
+                    FSM_PUSH2(tx);
+                } else {
+                    if (sc) {
+                        REAL mx = (REAL)0.5 * (back[0] + cur[0]), mz = (REAL)0.5 * (back[1] + cur[1]);
+                        slown = sc[SFX(cellno2d)(g, mx, mz)];
+                        tt += slown * SFX(dist2d)(back[0], back[1], cur[0], cur[1]);
+                        mx = (REAL)0.5 * (cur[0] + tx[0]); mz = (REAL)0.5 * (cur[1] + tx[1]);
+                        slown = sc[SFX(cellno2d)(g, mx, mz)];
+                        tt += slown * SFX(dist2d)(cur[0], cur[1], tx[0], tx[1]);
+                        /* (the reference records neither point in this branch, :1826-1831) */
+                    } else {
+                        s2 = SFX(fsm_interp2d)(g, sn, cur[0], cur[1]);
+                        tt += 0.5 * (s1 + s2) * SFX(dist2d)(back[0], back[1], cur[0], cur[1]);
+                        FSM_PUSH2(cur);
+                        s1 = s2;
+                        s2 = SFX(fsm_interp2d)(g, sn, tx[0], tx[1]);
+                        tt += 0.5 * (s1 + s2) * SFX(dist2d)(cur[0], cur[1], tx[0], tx[1]);
+                        FSM_PUSH2(tx);
+                    }
+                }
+                tt += t0[ns];
+                reached = 1;
+            }
+        }
+    }
+#undef FSM_PUSH2
+    *tt_out = tt;
+    if (npts) *npts = np;
+    return over ? 3 : 0;
+}
+
 #undef FSM_SMALL
 #undef FSM_SMALL2

@@ -253,8 +253,9 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
 
 
 def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-            cell_slowness=False, rcv=None, weno=False, rotated=False):
-    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (rotated: sweep45 after every sweep, ttcr/Grid2Drnfs.h:277-286)."""
+            cell_slowness=False, rcv=None, weno=False, rotated=False, tt_from_rp=False, return_rays=False):
+    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (rotated: sweep45 after every sweep, ttcr/Grid2Drnfs.h:277-286;
+    tt_from_rp / return_rays: Grid2Drn::getTraveltimeFromRaypath / getRaypath, ttcr/Grid2Drn.h:1478-1850)."""
     dt = np.dtype(dtype)
     sfx, ct, _, G2 = _TYPES[dt]
     L = lib()
@@ -284,7 +285,34 @@ def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, max
                                              C.byref(nw))
     out = dict(tt=T, niter=int(niter), niterw=int(nw.value), change=hist[:niter].copy(),
                changew=hist[maxit:maxit + nw.value].copy(), node_slowness=sn)
-    if rcv is not None:
+    if rcv is not None and (tt_from_rp or return_rays):
+        r = _prep_pts(dt, rcv, 2)
+        frp = getattr(L, "fsm_raypath2d_" + sfx)
+        vals = np.empty(r.shape[0], dtype=dt)
+        rays = []
+        cap = 4 * (ncx + ncz) + 64
+        sc_p = _p(s) if cell_slowness else None   # Grid2Drcfs keeps the cell slowness (hasCellSlowness)
+        for n, pnt in enumerate(r):
+            pp = np.ascontiguousarray(pnt, dtype=dt)
+            v = ct(0)
+            while True:
+                buf = np.empty((cap, 2), dtype=dt)
+                npts = C.c_long(0)
+                rc = frp(C.byref(g), _p(sn), sc_p, _p(T), C.c_int(nsrc), _p(src), _p(t0), _p(pp), C.c_int(int(return_rays)),
+                         C.c_long(1000000), C.byref(v), _p(buf), C.c_long(cap), C.byref(npts))
+                if rc != 3:
+                    break
+                cap *= 4
+            if rc == 1:
+                raise RuntimeError("Error while computing raypaths: going outside grid")
+            if rc == 2:
+                raise RuntimeError("raypath did not reach the source")
+            vals[n] = v.value
+            rays.append(buf[:npts.value].copy())
+        out["tt_rcv"] = vals
+        if return_rays:
+            out["rays"] = rays
+    elif rcv is not None:
         r = _prep_pts(dt, rcv, 2)
         f = getattr(L, "fsm_interp2d_" + sfx)
         out["tt_rcv"] = np.array([f(C.byref(g), _p(T), ct(p[0]), ct(p[1])) for p in r], dtype=dt)
@@ -292,7 +320,7 @@ def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, max
 
 
 def ref_solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-                cell_slowness=False, rcv=None, weno=False, rotated=False):
+                cell_slowness=False, rcv=None, weno=False, rotated=False, tt_from_rp=False, return_rays=False):
     dt = np.dtype(dtype)
     sfx, ct = _TYPES[dt][:2]
     R = ref()
@@ -306,13 +334,30 @@ def ref_solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5,
     tt_rcv = np.empty(r.shape[0], dtype=dt)
     T = np.empty(nn, dtype=dt)
     niter = (C.c_int * 2)()
-    rc = getattr(R, "ref_fsm2d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncz), ct(dx),
-                                        ct(dz), ct(origin[0]), ct(origin[1]), ct(eps), C.c_int(maxit),
-                                        C.c_int(int(weno)), C.c_int(int(rotated)), _p(s), C.c_int(nsrc), _p(src),
-                                        _p(t0), C.c_int(r.shape[0]), _p(r), _p(tt_rcv), _p(T), niter)
-    if rc != 0:
-        raise RuntimeError(R.ref_last_error().decode())
-    return dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
+    cap = (4 * (ncx + ncz) + 64) * max(r.shape[0], 1)
+    while True:
+        if return_rays:
+            rbuf = np.empty((cap, 2), dtype=np.float64)
+            roff = np.zeros(r.shape[0] + 1, dtype=np.int64)
+            R.ref_set_rays(_p(rbuf), C.c_long(cap), _p(roff))
+        try:
+            rc = getattr(R, "ref_fsm2d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncz), ct(dx),
+                                                ct(dz), ct(origin[0]), ct(origin[1]), ct(eps), C.c_int(maxit),
+                                                C.c_int(int(weno)), C.c_int(int(rotated)), _p(s), C.c_int(nsrc), _p(src),
+                                                _p(t0), C.c_int(r.shape[0]), _p(r), _p(tt_rcv), _p(T), niter,
+                                                C.c_int(int(tt_from_rp)))
+        finally:
+            if return_rays:
+                R.ref_set_rays(None, C.c_long(0), None)
+        if rc != 0:
+            raise RuntimeError(R.ref_last_error().decode())
+        if not return_rays or roff[-1] <= cap:
+            break
+        cap = int(roff[-1])
+    out = dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
+    if return_rays:
+        out["rays"] = [rbuf[roff[n]:roff[n + 1]].astype(dt) for n in range(r.shape[0])]
+    return out
 
 
 # --------------------------------------------------------------------------- file formats (reference side)

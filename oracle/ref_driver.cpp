@@ -105,7 +105,21 @@ static int run2d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
         std::vector<T> vt0(t0, t0 + n_src), tt;
         for (int n = 0; n < n_src; ++n) Tx[n] = {src_xz[2 * n], src_xz[2 * n + 1]};
         for (int n = 0; n < n_rcv; ++n) Rx[n] = {rcv_xz[2 * n], rcv_xz[2 * n + 1]};
-        static_cast<Grid2D<T, uint32_t, sxz<T>>&>(g).raytrace(Tx, vt0, Rx, tt, 0);
+        if (g_ray_buf) {   // Grid2D::raytrace(Tx,t0,Rx,tt,r_data,threadNo): xz pairs
+            std::vector<std::vector<sxz<T>>> r_data;
+            static_cast<Grid2D<T, uint32_t, sxz<T>>&>(g).raytrace(Tx, vt0, Rx, tt, r_data, 0);
+            long k = 0;
+            for (int n = 0; n < n_rcv; ++n) {
+                g_ray_off[n] = k;
+                for (const auto& p : r_data[n]) {
+                    if (k < g_ray_cap) { g_ray_buf[2 * k] = p.x; g_ray_buf[2 * k + 1] = p.z; }
+                    ++k;
+                }
+            }
+            g_ray_off[n_rcv] = k;
+        } else {
+            static_cast<Grid2D<T, uint32_t, sxz<T>>&>(g).raytrace(Tx, vt0, Rx, tt, 0);
+        }
         for (int n = 0; n < n_rcv; ++n) tt_rcv[n] = tt[n];
         std::vector<T> grid_tt;
         g.getTT(grid_tt, 0);
@@ -151,18 +165,18 @@ REF3D(ref_fsm3d_f64, double)
     extern "C" int NAME(int cell_slowness, uint32_t ncx, uint32_t ncz, T dx, T dz, T xmin, T zmin, \
                         T eps, int maxit, int weno, int rotated, const T* slowness, int n_src,     \
                         const T* src_xz, const T* t0, int n_rcv, const T* rcv_xz, T* tt_rcv,       \
-                        T* tt_grid, int* niter) {                                                  \
+                        T* tt_grid, int* niter, int ttrp) {                                        \
         try {                                                                                      \
             if (cell_slowness) {                                                                   \
                 ttcr::Grid2Drcfs<T, uint32_t, ttcr::sxz<T>> g(ncx, ncz, dx, dz, xmin, zmin, eps,   \
                                                               maxit, weno != 0, rotated != 0,      \
-                                                              false, 1);                           \
+                                                              ttrp != 0, 1);                       \
                 return run2d<T>(g, slowness, (size_t)ncx * ncz, n_src, src_xz, t0, n_rcv, rcv_xz,  \
                                 tt_rcv, tt_grid, niter);                                           \
             }                                                                                      \
             ttcr::Grid2Drnfs<T, uint32_t, ttcr::sxz<T>> g(ncx, ncz, dx, dz, xmin, zmin, eps,       \
-                                                          maxit, weno != 0, rotated != 0, false,   \
-                                                          1);                                      \
+                                                          maxit, weno != 0, rotated != 0,          \
+                                                          ttrp != 0, 1);                           \
             return run2d<T>(g, slowness, (size_t)(ncx + 1) * (ncz + 1), n_src, src_xz, t0, n_rcv,  \
                             rcv_xz, tt_rcv, tt_grid, niter);                                       \
         } catch (std::exception & e) {                                                             \

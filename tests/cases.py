@@ -211,6 +211,12 @@ def _rcv2(nc, dx, dz, origin, rng):
     return np.vstack([on, off, mixed, hi[None, :], lo[None, :]])
 
 
+def rp2_ok(c):
+    """2-D cases used for the raypath family (tt_from_rp / return_rays): smooth media and the cell models; on the
+    rough node-slowness random media the reference's steepest-descent walk does not terminate"""
+    return c["dim"] == 2 and not c["name"].startswith("random2d")
+
+
 def rot_ok(c):
     """Cases run with rotated_template=True as well (sweep45 only exists for 2-D square cells)"""
     return c["dim"] == 2 and c["dx"] == c["dz"]

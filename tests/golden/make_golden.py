@@ -14,6 +14,8 @@ For every case of tests/cases.py and both dtypes the file holds the reference's 
                           every sweep, ttcr/Grid2Drnfs.h:277-286), for the cases of cases.rot_ok()
   <case>/<dtype>/rays_tt_rcv, rays_off, rays_pts   weno + return_rays solve: receiver traveltimes and raypaths of
                           Grid3Drn::getRaypath (ray n = points [off[n], off[n+1])), or rays_error = 1
+  <case>/<dtype>/rp2_tt_rcv, rays2_tt_rcv, rays2_off, rays2_pts   2-D cases of cases.rp2_ok(): receiver traveltimes of
+                          Grid2Drn::getTraveltimeFromRaypath, and traveltimes + raypaths ((x, z) points) of Grid2Drn::getRaypath
   <case>/<dtype>/weno_*   the same four outputs (+ niterw) of the two-stage weno=True solve, for the
                           cases of cases.weno_ok()
 and the inputs  <case>/slowness (float64; cast to the dtype under test), so that the
@@ -99,6 +101,23 @@ def main():
                     assert "going outside grid" in str(e)
                     out[key + "/rays_error"] = np.int32(1)
                 print(key, "rays", "error" if int(out[key + "/rays_error"]) else "ok")
+            if cases.rp2_ok(c):
+                # 2-D raypath family: Grid2d(..., tt_from_rp=1) and raytrace(..., return_rays=True), weno as in ttcrpy
+                w = cases.weno_ok(c)
+                kw = dict(cell_slowness=c["cell_slowness"], rcv=c["rcv"], weno=w)
+                for tag, extra in (("rp2", dict(tt_from_rp=True)), ("rays2", dict(return_rays=True))):
+                    try:
+                        r = O.ref_solve2d(dt, c["ncells"], c["dx"], c["dz"], c["origin"], c["slowness"], c["src"], c["t0"],
+                                          **kw, **extra)
+                        out[key + f"/{tag}_tt_rcv"] = r["tt_rcv"]
+                        if tag == "rays2":
+                            out[key + "/rays2_off"] = np.cumsum([0] + [len(x) for x in r["rays"]]).astype(np.int64)
+                            out[key + "/rays2_pts"] = np.vstack(r["rays"])
+                        out[key + f"/{tag}_error"] = np.int32(0)
+                    except RuntimeError as e:
+                        assert "going outside grid" in str(e)
+                        out[key + f"/{tag}_error"] = np.int32(1)
+                    print(key, tag, "error" if int(out[key + f"/{tag}_error"]) else "ok", flush=True)
     path = os.path.join(HERE, "fsm_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

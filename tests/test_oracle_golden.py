@@ -93,6 +93,26 @@ def test_oracle_raypaths_match_golden(oracle, golden, c, dt):
         np.testing.assert_array_equal(ray[0], np.asarray(c["rcv"][n], dtype=dt))   # starts on the receiver
 
 
+RP2 = [(c, dt) for c, dt in ALL if cases.rp2_ok(c)]
+
+
+@pytest.mark.parametrize("c,dt", RP2, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in RP2])
+def test_oracle_raypaths_2d_match_golden(oracle, golden, c, dt):
+    """2-D: Grid2Drn::getTraveltimeFromRaypath (tt_from_rp) and Grid2Drn::getRaypath (return_rays), node and cell grids"""
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    kw = dict(cell_slowness=c["cell_slowness"], rcv=c["rcv"], weno=cases.weno_ok(c))
+    args = (dt, c["ncells"], c["dx"], c["dz"], c["origin"], golden[f"{c['name']}/slowness"], c["src"], c["t0"])
+    assert int(golden[key + "/rp2_error"]) == 0 and int(golden[key + "/rays2_error"]) == 0
+    r = oracle.solve2d(*args, tt_from_rp=True, **kw)
+    np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/rp2_tt_rcv"])
+    r = oracle.solve2d(*args, return_rays=True, **kw)
+    np.testing.assert_array_equal(r["tt_rcv"], golden[key + "/rays2_tt_rcv"])
+    off, pts = golden[key + "/rays2_off"], golden[key + "/rays2_pts"]
+    assert len(r["rays"]) == off.size - 1
+    for n, ray in enumerate(r["rays"]):
+        np.testing.assert_array_equal(ray, pts[off[n]:off[n + 1]])
+
+
 def test_golden_covers_multi_iteration_cases(golden):
     # the stopping rule / sweep order is only exercised when iterations >= 2 do real work
     assert int(golden["random_24x20x28_node/float32/niter"]) >= 4

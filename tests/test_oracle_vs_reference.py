@@ -55,6 +55,35 @@ def test_rotated_template_bit_exact_vs_reference(O, dt):
             np.testing.assert_array_equal(a["tt"], b["tt"])
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_raypaths_2d_bit_exact_vs_reference(O, dt):
+    """2-D raypath family on fresh smooth models (gradient with a lens, node and cell grids, dx != dz), receivers on
+    the faces so that the walk also slides along the boundary"""
+    nx, nz = 37, 29
+    x, z = np.arange(nx) * 0.5, np.arange(nz) * 0.4
+    X, Z = np.meshgrid(x, z, indexing="ij")
+    sn = 1.0 / (1.0 + 0.08 * Z) * (1.0 + 0.3 * np.exp(-((X - 9) ** 2 + (Z - 5) ** 2) / 8.0))
+    rcv = np.array([[0.0, 0.0], [0.0, 11.2], [18.0, 0.0], [4.3, 0.0], [17.9, 6.05], [9.1, 11.2], [3.0, 3.0]])
+    for cell in (False, True):
+        s = sn[:-1, :-1].ravel() if cell else sn.ravel()
+        for src in ([[7.3, 4.1]], [[0.0, 0.0]], [[5.0, 4.0]]):
+            kw = dict(dtype=dt, ncells=(nx - 1, nz - 1), dx=0.5, dz=0.4, origin=(0, 0), slowness=s, src=src,
+                      cell_slowness=cell, rcv=rcv, weno=False)
+            a, b = O.solve2d(tt_from_rp=True, **kw), O.ref_solve2d(tt_from_rp=True, **kw)
+            np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
+            a, b = O.solve2d(return_rays=True, **kw), O.ref_solve2d(return_rays=True, **kw)
+            np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
+            for u, v in zip(a["rays"], b["rays"]):
+                np.testing.assert_array_equal(u, v)
+    # a receiver on the far corner: the walk leaves the grid, and the retry along the face picks the z
+    # direction because the reference compares the gradient components through the integer abs() -- both throw
+    kw = dict(dtype=dt, ncells=(nx - 1, nz - 1), dx=0.5, dz=0.4, origin=(0, 0), slowness=sn.ravel(), src=[[0.0, 0.0]],
+              rcv=[[18.0, 11.2]], weno=False, tt_from_rp=True)
+    for f in (O.solve2d, O.ref_solve2d):
+        with pytest.raises(RuntimeError, match="going outside grid"):
+            f(**kw)
+
+
 def test_reference_rejects_outside_point(O):
     with pytest.raises(RuntimeError, match="outside grid"):
         O.ref_solve3d(np.float64, (4, 4, 4), 1.0, (0, 0, 0), np.ones(125), [[5.0, 1.0, 1.0]])

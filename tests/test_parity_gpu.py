@@ -306,3 +306,33 @@ def test_hip_raypaths_several_sources_and_to_vtk(tmp_path, oracle):
     assert len(back) == 6
     for a, b in zip(rays, back):
         np.testing.assert_allclose(a, b, rtol=1e-6)   # vtkPoints are Float32
+
+
+RP2 = [(c, dt) for c, dt in ALL if cases.rp2_ok(c)]
+
+
+@pytest.mark.parametrize("c,dt", RP2, ids=[f"{c['name']}-{np.dtype(dt).name}" for c, dt in RP2])
+def test_hip_raypaths_2d_match_golden(golden, c, dt):
+    """Grid2d(tt_from_rp=1) and raytrace(return_rays=True) in 2-D (node and cell grids, dx != dz): traveltimes and
+    every ray point bit-exact vs the reference"""
+    import ttcr_amd
+    from gpu_util import source_array
+
+    key = f"{c['name']}/{np.dtype(dt).name}"
+    nc, o = c["ncells"], c["origin"]
+    x, z = o[0] + np.arange(nc[0] + 1) * c["dx"], o[1] + np.arange(nc[1] + 1) * c["dz"]
+    w = int(cases.weno_ok(c))
+    g = ttcr_amd.Grid2d(x, z, cell_slowness=c["cell_slowness"], method="FSM", weno=w, tt_from_rp=1, dtype=dt)
+    s = np.asarray(golden[f"{c['name']}/slowness"]).reshape(g.shape)
+    tt = g.raytrace(source_array(c), c["rcv"], slowness=s, aggregate_src=True)
+    np.testing.assert_array_equal(tt, golden[key + "/rp2_tt_rcv"])
+    tt, rays = g.raytrace(source_array(c), c["rcv"], aggregate_src=True, return_rays=True)
+    np.testing.assert_array_equal(tt, golden[key + "/rays2_tt_rcv"])
+    off, pts = golden[key + "/rays2_off"], golden[key + "/rays2_pts"]
+    assert len(rays) == off.size - 1
+    for n, ray in enumerate(rays):
+        assert ray.shape[1] == 2
+        np.testing.assert_array_equal(ray, pts[off[n]:off[n + 1]].astype(np.float64))
+    g.set_traveltime_from_raypath(False)
+    tt0 = g.raytrace(source_array(c), c["rcv"], aggregate_src=True)
+    np.testing.assert_array_equal(tt0, golden[key + ("/weno_tt_rcv" if w else "/tt_rcv")])

@@ -854,36 +854,49 @@ class GridT : public GridBase {
     // appended to rays_off / rays_pts (shifted back by the origin of a translated grid, :579-584)
     void raypath_grid_coords(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out, bool record) {
         if (n <= 0) return;
-        if (dim != 3) throw Unsupported("tt_from_rp / return_rays are only built for 3-D grids");
-        d_rsrc.reserve((size_t)3 * n_tx);
+        const int nc = ncoord();   // 3-D: Grid3Drn::getRaypath family; 2-D: Grid2Drn (ttcr/Grid2Drn.h:1478-1850)
+        d_rsrc.reserve((size_t)nc * n_tx);
         d_rt0.reserve(n_tx);
-        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txp, sizeof(T) * 3 * n_tx, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txp, sizeof(T) * nc * n_tx, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0p, sizeof(T) * n_tx, hipMemcpyHostToDevice, stream));
         RayGeom<T> rg;
         rg.nnx = ncx + 1; rg.nny = ncy + 1; rg.nnz = ncz + 1;
         rg.dx = dx; rg.xmin = xmin; rg.ymin = ymin; rg.zmin = zmin; rg.xmax = xmax; rg.ymax = ymax; rg.zmax = zmax;
         rg.interp_vel = interp_vel;
+        RayGeom2<T> rg2;
+        rg2.nnx = ncx + 1; rg2.nnz = ncz + 1;
+        rg2.dx = dx; rg2.dz = dz; rg2.xmin = xmin; rg2.zmin = zmin; rg2.xmax = xmax; rg2.zmax = zmax;
+        const T* cell_s = (dim == 2 && cell) ? d_cells.p : nullptr;   // Grid2Drcfs integrates the CELL slowness
         const long max_steps = 8L * ((long)ncx + ncy + ncz + 3);  // a ray crosses at most one plane per step
         const long cap = max_steps + 3;                           // Rx, one point per step, at most two at the source
         // receivers in chunks: the recording buffer stays below 256 MiB
-        const int chunk = record ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (sizeof(T) * 3 * cap))) : n;
+        const int chunk = record ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (sizeof(T) * nc * cap))) : n;
         std::vector<int> st(chunk), np(chunk);
         std::vector<long long> off(chunk + 1);
         for (int c0 = 0; c0 < n; c0 += chunk) {
             const int m = std::min(chunk, n - c0);
-            const T* pc = p + (size_t)3 * c0;
-            d_rx.reserve((size_t)3 * m);
+            const T* pc = p + (size_t)nc * c0;
+            d_rx.reserve((size_t)nc * m);
             d_out.reserve(m);
             d_rstat.reserve(m);
-            HIP_CHECK(hipMemcpyAsync(d_rx.p, pc, sizeof(T) * 3 * m, hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(d_rx.p, pc, sizeof(T) * nc * m, hipMemcpyHostToDevice, stream));
+            const dim3 rgrid((m + 63) / 64), rblock(64);
             if (record) {
-                d_raypts.reserve((size_t)m * cap * 3);
+                d_raypts.reserve((size_t)m * cap * nc);
                 d_raynp.reserve(m);
-                fsm_raypath3d<T, true><<<(m + 63) / 64, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p,
-                                                                         m, d_out.p, d_rstat.p, max_steps, d_raypts.p, cap, d_raynp.p);
+                if (dim == 3)
+                    fsm_raypath3d<T, true><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m,
+                                                                         d_out.p, d_rstat.p, max_steps, d_raypts.p, cap, d_raynp.p);
+                else
+                    fsm_raypath2d<T, true><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, cell_s, rg2, n_tx, d_rsrc.p, d_rt0.p,
+                                                                         d_rx.p, m, d_out.p, d_rstat.p, max_steps, d_raypts.p, cap,
+                                                                         d_raynp.p);
+            } else if (dim == 3) {
+                fsm_raypath3d<T, false><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m,
+                                                                      d_out.p, d_rstat.p, max_steps, nullptr, 0, nullptr);
             } else {
-                fsm_raypath3d<T, false><<<(m + 63) / 64, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p,
-                                                                          m, d_out.p, d_rstat.p, max_steps, nullptr, 0, nullptr);
+                fsm_raypath2d<T, false><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, cell_s, rg2, n_tx, d_rsrc.p, d_rt0.p,
+                                                                      d_rx.p, m, d_out.p, d_rstat.p, max_steps, nullptr, 0, nullptr);
             }
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(out + c0, d_out.p, sizeof(T) * m, hipMemcpyDeviceToHost, stream));
@@ -893,13 +906,17 @@ class GridT : public GridBase {
             for (int q = 0; q < m; ++q) {
                 if (st[q] == 0) continue;
                 std::ostringstream msg;
+                auto pt = [&](const T* v) { for (int c = 0; c < nc; ++c) msg << (c ? " " : "") << v[c]; };
                 if (st[q] == 1) {
-                    msg << "Error while computing raypaths: going outside grid \n                Rx: " << pc[3 * q] << ' '
-                        << pc[3 * q + 1] << ' ' << pc[3 * q + 2] << "\n                Tx: " << txp[0] << ' ' << txp[1] << ' '
-                        << txp[2] << "\n";
+                    msg << "Error while computing raypaths: going outside grid \n                Rx: ";
+                    pt(pc + (size_t)nc * q);
+                    msg << "\n                Tx: ";
+                    pt(txp);
+                    msg << "\n";
                 } else {
-                    msg << "Error while computing raypaths: ray from Rx " << pc[3 * q] << ' ' << pc[3 * q + 1] << ' ' << pc[3 * q + 2]
-                        << " did not reach the source within " << max_steps << " steps";
+                    msg << "Error while computing raypaths: ray from Rx ";
+                    pt(pc + (size_t)nc * q);
+                    msg << " did not reach the source within " << max_steps << " steps";
                 }
                 throw std::runtime_error(msg.str());
             }
@@ -908,14 +925,17 @@ class GridT : public GridBase {
                 for (int q = 0; q < m; ++q) off[q + 1] = off[q] + np[q];
                 const long long tot = off[m];
                 d_rayoff.reserve(m + 1);
-                d_raydense.reserve((size_t)std::max<long long>(tot, 1) * 3);
+                d_raydense.reserve((size_t)std::max<long long>(tot, 1) * nc);
                 HIP_CHECK(hipMemcpyAsync(d_rayoff.p, off.data(), sizeof(long long) * (m + 1), hipMemcpyHostToDevice, stream));
-                fsm_compact_rays<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p, translate ? ox : (T)0,
-                                                           translate ? oy : (T)0, translate ? oz : (T)0);
+                if (dim == 3)
+                    fsm_compact_rays<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p, translate ? ox : (T)0,
+                                                               translate ? oy : (T)0, translate ? oz : (T)0);
+                else
+                    fsm_compact_rays2<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p);
                 HIP_CHECK(hipGetLastError());
                 const size_t base = rays_pts.size();
-                rays_pts.resize(base + (size_t)tot * 3);
-                HIP_CHECK(hipMemcpyAsync(rays_pts.data() + base, d_raydense.p, sizeof(T) * 3 * tot, hipMemcpyDeviceToHost, stream));
+                rays_pts.resize(base + (size_t)tot * nc);
+                HIP_CHECK(hipMemcpyAsync(rays_pts.data() + base, d_raydense.p, sizeof(T) * nc * tot, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
                 const long long prev = rays_off.back();
                 for (int q = 0; q < m; ++q) rays_off.push_back(prev + off[q + 1]);
@@ -1152,11 +1172,9 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
         else if (k == "mode") g->impl->mode = (int)value;
         else if (k == "skip") g->impl->skip = (int)value;
         else if (k == "tt_from_rp") {
-            if (value != 0 && g->impl->dim != 3) throw Unsupported("tt_from_rp=True is only built for 3-D grids");
             g->impl->ttrp = value != 0;
         } else if (k == "interp_vel") g->impl->interp_vel = value != 0;
         else if (k == "return_rays") {
-            if (value != 0 && g->impl->dim != 3) throw Unsupported("return_rays=True is only built for 3-D grids");
             g->impl->return_rays = value != 0;
         } else throw ValueError("unknown option '" + k + "'");
     });

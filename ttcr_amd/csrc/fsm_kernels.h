@@ -1928,14 +1928,11 @@ __global__ void fsm_compact_rays(const T* __restrict__ pts, long cap, const long
     }
 }
 
-// Grid2Drn::getTraveltime (ttcr/Grid2Drn.h:359-414)
+// Grid2Drn::getTraveltime (ttcr/Grid2Drn.h:359-414); Grid2Drn::getSlowness (:1421-1476) has the same
+// shape on the node slowness (stride 1)
 template <typename T>
-__global__ void fsm_interp2d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
-                             int nnz, T dx, T dz, T xmin, T zmin) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+__device__ __forceinline__ T interp2d_pt(const T* __restrict__ Tn, int ts, int nnz, T dx, T dz, T xmin, T zmin, T px, T pz) {
     const double small = 1.e-4;
-    const T px = pts[2 * r], pz = pts[2 * r + 1];
     const uint32_t i = (uint32_t)(small + (double)((px - xmin) / dx));
     const uint32_t j = (uint32_t)(small + (double)((pz - zmin) / dz));
     auto ab = [](T v) { return v < 0 ? -v : v; };
@@ -1962,7 +1959,196 @@ __global__ void fsm_interp2d(const T* __restrict__ Tn, int ts, const T* __restri
         w2 = (pz - (zmin + (T)j * dz)) / dz;
         tt = t1 * w1 + t2 * w2;
     }
-    out[r] = tt;
+    return tt;
+}
+
+template <typename T>
+__global__ void fsm_interp2d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
+                             int nnz, T dx, T dz, T xmin, T zmin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    out[r] = interp2d_pt(Tn, ts, nnz, dx, dz, xmin, zmin, pts[2 * r], pts[2 * r + 1]);
+}
+
+// ---- 2-D raypath family: Grid2Drn::getTraveltimeFromRaypath (ttcr/Grid2Drn.h:1478-1661) and
+// Grid2Drn::getRaypath(Tx, t0, Rx, r_data, tt, threadNo) (:1663-1850) -------------------------------
+template <typename T>
+struct RayGeom2 {
+    int nnx, nnz;
+    T dx, dz, xmin, zmin, xmax, zmax;
+};
+
+// Grid2Drn::grad(g, pt, nt), ttcr/Grid2Drn.h:606-632
+template <typename T>
+__device__ void grad2d(const RayGeom2<T>& g, const T* __restrict__ Tn, int ts, T px, T pz, T* gv) {
+    T p1 = (T)((double)px - (double)g.dx / 2.0);
+    if (p1 < g.xmin) p1 = g.xmin;
+    T p2 = p1 + g.dx;
+    if (p2 > g.xmax) {
+        p2 = g.xmax;
+        p1 = g.xmax - g.dx;
+    }
+    gv[0] = (interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, p2, pz) -
+             interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, p1, pz)) / g.dx;
+    p1 = (T)((double)pz - (double)g.dz / 2.0);
+    if (p1 < g.zmin) p1 = g.zmin;
+    p2 = p1 + g.dz;
+    if (p2 > g.zmax) {
+        p2 = g.zmax;
+        p1 = g.zmax - g.dz;
+    }
+    gv[1] = (interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, p2) -
+             interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, p1)) / g.dz;
+}
+
+// Grid2Drn::getCellNo, ttcr/Grid2Drn.h:170-176
+template <typename T>
+__device__ uint32_t cellno2d(const RayGeom2<T>& g, T px, T pz) {
+    const double small = 1.e-4;
+    const T x = (double)(g.xmax - px) < small ? (T)((double)g.xmax - .5 * (double)g.dx) : px;
+    const T z = (double)(g.zmax - pz) < small ? (T)((double)g.zmax - .5 * (double)g.dz) : pz;
+    const uint32_t nx = (uint32_t)(small + (double)((x - g.xmin) / g.dx));
+    const uint32_t nz = (uint32_t)(small + (double)((z - g.zmin) / g.dz));
+    return nx * (uint32_t)(g.nnz - 1) + nz;
+}
+
+// advance cur along gv to the next grid line of cell (i,k); (i,k) is taken once per walk step, the
+// reference does not refresh it for the retry along the face or for the last hop to the source
+template <typename T>
+__device__ void step2d(const RayGeom2<T>& g, long i, long k, T* cur, const T* gv) {
+    const double small = 1.e-4;
+    T xp = (T)((double)g.xmin + (double)g.dx * ((double)i + (sgn_boost(gv[0]) > 0 ? 1.0 : 0.0)));
+    T zp = (T)((double)g.zmin + (double)g.dz * ((double)k + (sgn_boost(gv[1]) > 0 ? 1.0 : 0.0)));
+    if ((double)rabs(xp - cur[0]) < small) xp += g.dx * (T)sgn_boost(gv[0]);
+    if ((double)rabs(zp - cur[1]) < small) zp += g.dz * (T)sgn_boost(gv[1]);
+    const T big = real_traits<T>::max();
+    const T tx = gv[0] != 0 ? (xp - cur[0]) / gv[0] : big;
+    const T tz = gv[1] != 0 ? (zp - cur[1]) / gv[1] : big;
+    if (tx < tz) {
+        cur[0] += tx * gv[0]; cur[1] += tx * gv[1];
+        cur[0] = xp;
+    } else {
+        cur[0] += tz * gv[0]; cur[1] += tz * gv[1];
+        cur[1] = zp;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T dist2(const T* a, const T* b) {
+    return (T)__builtin_sqrt((double)((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1])));
+}
+
+// sn: node slowness; sc: the cell slowness a Grid2Drcfs keeps (hasCellSlowness, ttcr/Grid2Drcfs.h:62-68) or null.
+// status as in fsm_raypath3d (1: the ray left the grid twice in one step, the reference throws).
+template <typename T, bool RAYS>
+__global__ void fsm_raypath2d(const T* __restrict__ Tn, int ts, const T* __restrict__ sn, const T* __restrict__ sc,
+                              RayGeom2<T> g, int n_src, const T* __restrict__ src, const T* __restrict__ t0,
+                              const T* __restrict__ rcv, int n_rcv, T* __restrict__ out, int* __restrict__ status,
+                              long max_steps, T* __restrict__ pts, long cap, int* __restrict__ npts) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rcv) return;
+    const T rx[2] = {rcv[2 * r], rcv[2 * r + 1]};
+    status[r] = 0;
+    long np = 0;
+    T* my_pts = RAYS ? pts + (size_t)r * cap * 2 : nullptr;
+    T back[2] = {rx[0], rx[1]}, cur[2] = {rx[0], rx[1]}, gv[2];
+    auto push = [&](const T* p) {
+        if (RAYS) {
+            if (np < cap) { my_pts[2 * np] = p[0]; my_pts[2 * np + 1] = p[1]; }
+            back[0] = p[0]; back[1] = p[1];
+            ++np;
+        }
+    };
+    auto finish = [&](int st, T tt) {
+        if (RAYS) { npts[r] = (int)np; if (st == 0 && np > cap) st = 3; }
+        status[r] = st;
+        out[r] = tt;
+    };
+    auto slow = [&](T px, T pz) { return interp2d_pt(sn, 1, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, pz); };
+    push(rx);
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[2 * ns] && rx[1] == src[2 * ns + 1]) { finish(0, t0[ns]); return; }
+    T tt = 0, s1 = 0, s2 = 0, slown = 0;
+    if (!sc) s1 = slow(cur[0], cur[1]);
+    const T maxDist = (T)__builtin_sqrt((double)(g.dx * g.dx + g.dz * g.dz));
+    bool reached = false;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) { finish(2, tt); return; }
+        grad2d(g, Tn, ts, cur[0], cur[1], gv);
+        gv[0] *= (T)-1.0; gv[1] *= (T)-1.0;
+        const double small = 1.e-4;
+        const long i = (long)(small + (double)((cur[0] - g.xmin) / g.dx));
+        const long k = (long)(small + (double)((cur[1] - g.zmin) / g.dz));
+        step2d(g, i, k, cur, gv);
+        if (cur[0] < g.xmin || cur[0] > g.xmax || cur[1] < g.zmin || cur[1] > g.zmax) {
+            // going outside: follow the face instead (:1536-1581)
+            // (the reference's unqualified abs() binds to the C int overload: components truncated first, :1538)
+            const int agx = (int)gv[0], agz = (int)gv[1];
+            if ((agx < 0 ? -agx : agx) > (agz < 0 ? -agz : agz)) { gv[0] = (T)sgn_boost(gv[0]); gv[1] = 0; }
+            else { gv[1] = (T)sgn_boost(gv[1]); gv[0] = 0; }
+            cur[0] = back[0]; cur[1] = back[1];
+            step2d(g, i, k, cur, gv);
+            if (cur[0] < g.xmin || cur[0] > g.xmax || cur[1] < g.zmin || cur[1] > g.zmax) { finish(1, tt); return; }
+        }
+        if (sc) {
+            const T mx = (T)0.5 * (back[0] + cur[0]), mz = (T)0.5 * (back[1] + cur[1]);
+            slown = sc[cellno2d(g, mx, mz)];
+        } else {
+            s2 = slow(cur[0], cur[1]);
+            slown = (T)(0.5 * (double)(s1 + s2));
+            s1 = s2;
+        }
+        tt += slown * dist2(back, cur);
+        if (RAYS) push(cur); else { back[0] = cur[0]; back[1] = cur[1]; }
+        for (int ns = 0; ns < n_src; ++ns) {
+            const T tx[2] = {src[2 * ns], src[2 * ns + 1]};
+            const T dist = dist2(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1];
+                step2d(g, i, k, cur, gv);
+                if (dist2(cur, back) > dist || (cur[0] == tx[0] && cur[1] == tx[1])) {
+                    if (sc) {
+                        const T mx = (T)0.5 * (back[0] + tx[0]), mz = (T)0.5 * (back[1] + tx[1]);
+                        slown = sc[cellno2d(g, mx, mz)];
+                    } else {
+                        s2 = slow(tx[0], tx[1]);
+                        slown = (T)(0.5 * (double)(s1 + s2));
+                    }
+                    tt += slown * dist2(back, tx);
+                    push(tx);
+                } else if (sc) {
+                    T mx = (T)0.5 * (back[0] + cur[0]), mz = (T)0.5 * (back[1] + cur[1]);
+                    slown = sc[cellno2d(g, mx, mz)];
+                    tt += slown * dist2(back, cur);
+                    mx = (T)0.5 * (cur[0] + tx[0]); mz = (T)0.5 * (cur[1] + tx[1]);
+                    slown = sc[cellno2d(g, mx, mz)];
+                    tt += slown * dist2(cur, tx);
+                    // (the reference records neither point in this branch, :1826-1831)
+                } else {
+                    s2 = slow(cur[0], cur[1]);
+                    tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist2(back, cur));
+                    push(cur);
+                    s1 = s2;
+                    s2 = slow(tx[0], tx[1]);
+                    tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist2(cur, tx));
+                    push(tx);
+                }
+                tt += t0[ns];
+                reached = true;
+            }
+        }
+    }
+    finish(0, tt);
+}
+
+// rays recorded in fixed-capacity rows -> one dense array, 2-D (x, z) pairs
+template <typename T>
+__global__ void fsm_compact_rays2(const T* __restrict__ pts, long cap, const long long* __restrict__ off, T* __restrict__ out) {
+    const int r = blockIdx.x;
+    const long long a = off[r], n = off[r + 1] - a;
+    const T* src = pts + (size_t)r * cap * 2;
+    for (long long i = threadIdx.x; i < 2 * n; i += blockDim.x) out[2 * a + i] = src[i];
 }
 
 }  // namespace ttcr_amd

@@ -13,7 +13,7 @@ and error behaviour) for the fast-sweeping path:
 weno=True (the reference's default: first-order sweeps, then third-order WENO sweeps) is
 supported, and so is tt_from_rp=True in 3-D (the 3-D default: traveltimes integrated along the
 ray traced back through the field).  What is not on the FSM hot path raises NotImplementedError
-(SPM/DSPM, compute_L/compute_M, 2-D return_rays / tt_from_rp).  There is no CPU fallback.
+(SPM/DSPM, compute_L/compute_M).  There is no CPU fallback.
 """
 import ctypes as C
 
@@ -247,7 +247,7 @@ class _GridBase:
         nr, npnt = C.c_size_t(0), C.c_size_t(0)
         _lib.check(self._lib.ttcr_fsm_rays_size(self._h, C.byref(nr), C.byref(npnt)))
         off = np.zeros(nr.value + 1, dtype=np.int64)
-        pts = np.empty((max(npnt.value, 1), 3), dtype=dt)
+        pts = np.empty((max(npnt.value, 1), nd), dtype=dt)
         _lib.check(self._lib.ttcr_fsm_get_rays(self._h, _ptr(off), _ptr(pts)))
         rays = [[0.0] for _ in range(n_rcv)]
         for n in range(nTx):
@@ -548,14 +548,14 @@ class _Grid2d(_GridBase):
             raise ValueError('Method {0:s} undefined'.format(method))
         if aniso != 'iso':
             raise NotImplementedError('Anisotropic raytracing implemented only for SPM')
-        if self.tt_from_rp:
-            raise NotImplementedError("tt_from_rp=True is not built yet; pass tt_from_rp=False")
         self._lib = _lib.load()
         st = self._lib.ttcr_fsm2d_create(C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
                                          int(self.cell_slowness), x.size - 1, z.size - 1, self._dx, self._dz,
                                          float(x[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
                                          int(self.rotated_template), self._n_threads, self._device)
         _lib.check(st)
+        if self.tt_from_rp:   # Grid2Drn::getTraveltimeFromRaypath (ttcr/Grid2Drn.h:1478-1661)
+            self.set_option("tt_from_rp", 1)
 
     def __reduce__(self):
         params = (self.n_threads, self.cell_slowness, self.method, self.aniso, self.eps, self.maxit, self.weno,
@@ -650,12 +650,19 @@ class _Grid2d(_GridBase):
             raise NotImplementedError('Anisotropic raytracing implemented only for SPM')
         if compute_L and not self.cell_slowness:
             raise NotImplementedError('compute_L defined only for grids with slowness defined for cells')
-        if compute_L or return_rays:
-            raise NotImplementedError('compute_L / return_rays are not on the FSM hot path built here')
+        if compute_L:
+            raise NotImplementedError('compute_L is not built for the FSM grids (straight-ray L: data_kernel_straight_rays)')
         vTx, vt0, vRx, iRx = self._split_sources(source, rcv, aggregate_src)
         if slowness is not None:
             self.set_slowness(slowness)
-        return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
+        if not return_rays:
+            return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
+        # -> (tt, rays): Grid2D::raytrace(Tx,t0,Rx,tt,r_data,threadNo) -> Grid2Drn::getRaypath (ttcr/Grid2Drn.h:1663-1850)
+        self.set_option("return_rays", 1)
+        try:
+            return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no, return_rays=True)
+        finally:
+            self.set_option("return_rays", 0)
 
 
 class Grid2d_d(_Grid2d):
