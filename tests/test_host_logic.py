@@ -37,8 +37,8 @@ def test_constructor_checks():
         ttcr_amd.Grid3d(x, x, x, method="XYZ")
     with pytest.raises(NotImplementedError):
         ttcr_amd.Grid3d(x, x, x, method="SPM")
-    with pytest.raises(NotImplementedError, match="tt_from_rp"):
-        ttcr_amd.Grid2d(x, x, method="FSM", tt_from_rp=1)  # 2-D raypath traveltimes are not built
+    with pytest.raises(NotImplementedError, match="SPM"):
+        ttcr_amd.Grid2d(x, x, method="FSM", aniso="elliptical")  # anisotropy only exists for the SPM grids
     with pytest.raises(ValueError, match="dtype"):
         ttcr_amd.Grid3d(x, x, x, method="FSM", dtype=np.int32)
     with pytest.raises(NotImplementedError):
