@@ -699,11 +699,26 @@ class GridT : public GridBase {
         HIP_CHECK(hipMemcpyAsync(d_pts.p, pts.data(), pts.size() * sizeof(InitPoint<T>), hipMemcpyHostToDevice, stream));
         for (int b = 0; b < nb; ++b)  // dirty-brick stamps: one set per slot group, "never changed"
             HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)(slot_ids[b] / NS) * n_bricks, 0xFF, n_bricks * sizeof(int), stream));
+        // reinit (Node3Dn::reinit): T = max() everywhere.  When every source of an interleaved group is
+        // (re)started in this batch the group is one contiguous fill (full-line stores) instead of NS
+        // strided passes.
+        std::vector<char> group_filled(n_groups(), 0);
+        if (NS > 1) {
+            std::vector<int> cnt(n_groups(), 0);
+            for (int b = 0; b < nb; ++b) cnt[slot_ids[b] / NS] += 1;
+            for (int gi = 0; gi < n_groups(); ++gi) {
+                if (cnt[gi] != NS) continue;
+                const size_t n_el = n_nodes * (size_t)NS;
+                const int blocks = (int)std::min<size_t>((n_el + 255) / 256, 16384);
+                fsm_fill<T><<<blocks, 256, 0, stream>>>(d_tt.p + (size_t)gi * n_el, n_el, real_traits<T>::max(), 1);
+                group_filled[gi] = 1;
+            }
+        }
         for (int b = 0; b < nb; ++b) {
             const int slot = slot_ids[b];
             T* tt = tt_ptr(slot);
             const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
-            fsm_fill<T><<<blocks, 256, 0, stream>>>(tt, n_nodes, real_traits<T>::max(), NS);
+            if (!group_filled[slot / NS]) fsm_fill<T><<<blocks, 256, 0, stream>>>(tt, n_nodes, real_traits<T>::max(), NS);
             HIP_CHECK(hipMemsetAsync(d_mask.p + (size_t)slot * mask_words, 0, mask_words * sizeof(uint32_t), stream));
             InitArgs<T> ia;
             ia.tt = tt;
