@@ -631,6 +631,26 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 #define FSM_MINW 1
 #endif
 // NS sources of a slot group marched together (field layout T[group][node][NS]): one element type
+// value held by the lane below / above (DPP wave shift, one VALU op; the end lanes get `edge`)
+__device__ __forceinline__ float lane_below(float x, float edge) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(edge), (int)__float_as_uint(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_above(float x, float edge) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(edge), (int)__float_as_uint(x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_below(double x, double edge) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x), e = (unsigned long long)__double_as_longlong(edge);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)e, (int)(unsigned)u, 0x138, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(e >> 32), (int)(unsigned)(u >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_above(double x, double edge) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x), e = (unsigned long long)__double_as_longlong(edge);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)e, (int)(unsigned)u, 0x130, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(e >> 32), (int)(unsigned)(u >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 template <typename T, int NS> struct Pack;
 template <typename T> struct Pack<T, 1> { T v[1]; };
 template <typename T> struct alignas(2 * sizeof(T)) Pack<T, 2> { T v[2]; };
@@ -1120,83 +1140,57 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             const int rem = rf ? (i0n - b0 * FSM_BRICK) + 1 : (b0 + 1) * FSM_BRICK - i0n;
             e_split = rem;
         }
+        // 2-D first-order patches are ONE wavefront: the J neighbours are the adjacent lanes, so the march
+        // exchanges values with DPP wave shifts instead of an LDS write -> read round trip per level; the
+        // two halo columns are static within the chunk and sit in registers (used by the end lanes only)
+        constexpr bool WAVE2D = !IS3D && NT == 64 && H == 1;
+        P hup[WAVE2D ? C : 1], hdn[WAVE2D ? C : 1];
+        if (WAVE2D) {
+#pragma unroll
+            for (int ee = 0; ee < C; ++ee) {
+                hup[ee] = Tt[(H - 1) * RS + ee + H - 1];        // column -1 at tile q-1
+                hdn[ee] = Tt[(PJ + H) * RS + ee + H + 1];       // column PJ at tile q+1
+            }
+        }
         bool chg_a = false, chg_b = false;
         bool changed = false;
+        // A lone wavefront issues in order, so where the march is latency bound (the one-wave 2-D patches) its
+        // length IS the instruction count.  The 2-D kernels carry specialised copies of the level march
+        // (fsm_march_levels.inc) for wavefronts whose lanes all have a node at every level of the chunk, far
+        // from the frozen nodes (almost every chunk): no grid masks, no frozen-bit path, local solver fixed.
+        // (Not for the 3-D kernels: the extra registers cost a resident wave per SIMD there -- paired: -22 %,
+        // unpaired 512^3: -2 %.)
+        constexpr bool DUP = H == 1 && !IS3D;
+        if constexpr (!DUP) {
+#define FSM_SIMPLE false
+#define FSM_VAR 0
+#include "fsm_march_levels.inc"
+#undef FSM_SIMPLE
+#undef FSM_VAR
+        } else {
+            bool near_any = false;
 #pragma unroll
-        for (int ee = 0; ee < C; ++ee) {
-            const int q = ee + H;
-            const bool in_grid = (ee >= ea) & (ee <= eb);
-            // the same as a lane mask: compare builtins write scalar pairs, no VALU select/compare round trip
-            const unsigned long long grid_lanes = __builtin_amdgcn_sicmp(ea, ee, 41) & __builtin_amdgcn_sicmp(eb, ee, 39);   // SLE, SGE
-            const int ip = L0 + ee - jp - kp;
-            const P c = own[q];
-            // neighbour values of both sources arrive with one LDS access each
-            const P fm1 = own[q - 1], fp1 = own[q + 1];
-            const P jm1 = Tt[(row - 1) * RS + q - 1], jp1 = Tt[(row + 1) * RS + q + 1];
-            P km1 = PINF, kp1 = PINF;
-            if (IS3D) { km1 = Tt[(row - RJ) * RS + q - 1]; kp1 = Tt[(row + RJ) * RS + q + 1]; }
-            constexpr int HH = H == 2 ? 2 : 1;  // (keeps the H == 1 instantiation in bounds)
-            P fm2 = PINF, fp2 = PINF, jm2 = PINF, jp2 = PINF, km2 = PINF, kp2 = PINF;
-            if (H == 2) {
-                fm2 = own[q - HH]; fp2 = own[q + HH];
-                jm2 = Tt[(row - HH) * RS + q - HH]; jp2 = Tt[(row + HH) * RS + q + HH];
-                if (IS3D) { km2 = Tt[(row - HH * RJ) * RS + q - HH]; kp2 = Tt[(row + HH * RJ) * RS + q + HH]; }
+            for (int l = 0; l < NS; ++l) near_any |= near_src[l];
+            const bool full_wave = !near_any && __builtin_amdgcn_ballot_w64(ea == 0 && eb == C - 1) == ~0ull;
+            if (!full_wave) {
+#define FSM_SIMPLE false
+#define FSM_VAR 0
+#include "fsm_march_levels.inc"
+#undef FSM_SIMPLE
+#undef FSM_VAR
+            } else if (variant == 1) {
+#define FSM_SIMPLE true
+#define FSM_VAR 1
+#include "fsm_march_levels.inc"
+#undef FSM_SIMPLE
+#undef FSM_VAR
+            } else {
+#define FSM_SIMPLE true
+#define FSM_VAR 2
+#include "fsm_march_levels.inc"
+#undef FSM_SIMPLE
+#undef FSM_VAR
             }
-            P nv;
-#pragma unroll
-            for (int l = 0; l < NS; ++l) {
-                bool active = in_grid & ((lm >> l) & 1);
-                unsigned long long live_lanes = ((lm >> l) & 1) ? grid_lanes : 0ull;
-                if (near_src[l]) {   // block-uniform and rare: keep the index arithmetic out of the common path
-                    int ipn = ip;
-                    asm volatile("" : "+v"(ipn));
-                    if (active) {
-                        const uint32_t n = colbase + (rf ? NF - 1 - ipn : ipn);
-                        active = !((Fz[(size_t)l * a.mask_words + (n >> 5)] >> (n & 31)) & 1u);
-                    }
-                    live_lanes = __builtin_amdgcn_ballot_w64(active);
-                }
-                T t;
-                if (H == 1) {
-                    const T af = vmin(fm1.v[l], fp1.v[l]);
-                    const T aj = vmin(jm1.v[l], jp1.v[l]);
-                    if (IS3D) {
-                        const T ak = vmin(km1.v[l], kp1.v[l]);
-                        t = update3(ak, aj, af, sc[ee], dx, live_lanes);
-                    } else {
-                        t = variant == 1 ? update2(aj, af, sc[ee], dx) : update2_xz(aj, af, sc[ee], dx, dz);
-                    }
-                } else {
-                    // WENO3: five-point stencils in NATURAL index order along every axis.  Oriented
-                    // offset -d is natural offset -d when the axis is swept upwards, +d otherwise.
-                    const int in = rf ? NF - 1 - ip : ip;
-                    const T hF = IS3D ? dx : (variant == 2 ? dz : dx);
-                    const double r2F = IS3D ? r2x : (variant == 2 ? r2z : r2x);
-                    const T cc = c.v[l];
-                    const T aF = rf ? weno_axis(fp2.v[l], fp1.v[l], cc, fm1.v[l], fm2.v[l], in, NF - 1, hF, r2F)
-                                    : weno_axis(fm2.v[l], fm1.v[l], cc, fp1.v[l], fp2.v[l], in, NF - 1, hF, r2F);
-                    const T aJ = rj ? weno_axis(jp2.v[l], jp1.v[l], cc, jm1.v[l], jm2.v[l], jn, NJ - 1, dx, r2x)
-                                    : weno_axis(jm2.v[l], jm1.v[l], cc, jp1.v[l], jp2.v[l], jn, NJ - 1, dx, r2x);
-                    if (IS3D) {
-                        const T aK = rk ? weno_axis(kp2.v[l], kp1.v[l], cc, km1.v[l], km2.v[l], kn, NK - 1, dx, r2x)
-                                        : weno_axis(km2.v[l], km1.v[l], cc, kp1.v[l], kp2.v[l], kn, NK - 1, dx, r2x);
-                        // a1 <- K axis, a2 <- J axis, a3 <- F axis, as in the reference (k, j, i)
-                        t = solve3_literal(aK, aJ, aF, sc[ee] * dx);
-                    } else {
-                        // 2-D: a = x axis (J here), b = z axis (F here)
-                        t = variant == 1 ? update2(aJ, aF, sc[ee], dx) : update2_xz(aJ, aF, sc[ee], dx, dz);
-                    }
-                }
-                const bool acc = active & (t < c.v[l]);
-                nv.v[l] = acc ? t : c.v[l];
-                dec[l] += acc ? c.v[l] - t : (T)0;   // (c - nv would be inf - inf on the out-of-grid entries)
-                changed |= acc;
-                chg_a |= acc & (ee < e_split);
-                chg_b |= acc & (ee >= e_split);
-            }
-            own[q] = nv;
-            Tt[row * RS + q] = nv;
-            __syncthreads();
         }
 #pragma unroll
         for (int q = 0; q < 2 * H; ++q) carry[q] = own[C + q];
