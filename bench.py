@@ -9,7 +9,7 @@ tt_from_rp=False, eps=1e-5, maxit=50), 441 receivers (rcv.dat lattice), block-di
 the N GPUs like get_blk_size (64 on one GPU, 8 per GPU on eight).  One "step" = one full solve
 (init + sweep iterations to convergence + receiver interpolation) of the rank's sources.  Inputs are
 resident in HBM before the timed region (slowness is broadcast over RCCL and handed to the
-solver as a device pointer); the receiver traveltimes are gathered to rank 0 over RCCL inside
+solver as a device pointer); the receiver traveltimes are all-gathered over RCCL inside
 every step (a few KB).
 
   python bench.py --gpus 1 --steps 5 --warmup 1
@@ -194,7 +194,8 @@ def main():
 
     # equal-sized gather buffers (ranks own at most ceil(n_total/world) sources)
     max_rows = -(-n_total // world) * rcv1.shape[0]
-    gathered = [torch.empty(max_rows, dtype=torch.float32, device=cdev) for _ in range(world)] if rank == 0 else None
+    # (all_gather rather than gather: a few KB, and the one collective every backend implements natively)
+    gathered = [torch.empty(max_rows, dtype=torch.float32, device=cdev) for _ in range(world)]
 
     def step():
         tt = grid.raytrace(src_rows, rcv_rows)
@@ -202,7 +203,7 @@ def main():
         if world > 1:
             t_dev = torch.zeros(max_rows, dtype=torch.float32, device=cdev)
             t_dev[:tt.shape[0]] = torch.from_numpy(tt).to(cdev)
-            dist.gather(t_dev, gathered, dst=0)
+            dist.all_gather(gathered, t_dev)
         return tt, tm
 
     def fence():
@@ -270,7 +271,7 @@ def main():
                                    f"weno=False, tt_from_rp=False",
                        "grid_nodes": n_nodes, "sources_total": n_total, "sources_rank0": S,
                        "sweep_iterations_per_source": sorted(set(iters_per_src)),
-                       "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, gather of traveltimes)"},
+                       "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, all_gather of receiver traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,

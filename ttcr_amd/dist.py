@@ -85,8 +85,8 @@ def raytrace_sharded(source, rcv, solve_fn, group=None, device=None, dtype=np.fl
     buf = torch.zeros(source.shape[0], dtype=tdt, device=device)
     if mine.size:
         buf[torch.as_tensor(mine, device=device)] = torch.as_tensor(tt_local, dtype=tdt, device=device)
-    gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, gathered, dst=0, group=group)
+    gathered = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)   # KB-sized; the collective every backend implements natively
     if rank != 0:
         return None
     out = np.zeros(source.shape[0], dtype=dtype)
