@@ -1,0 +1,16 @@
+"""default-path throughput: weno=1, several sources at once (pairing on/off via TTCR_FSM_PAIR)"""
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np, ttcr_amd, cases
+n = int(sys.argv[1]); ns = int(sys.argv[2])
+dx = 20.0 / (n - 1); x = np.arange(n) * dx
+s = np.ascontiguousarray(np.broadcast_to((1.0 / (1.0 + 0.1 * x))[None, None, :], (n, n, n)))
+rc = cases.rcv_lattice3d(); srcs = cases.mt_sources(64)[:ns]
+g = ttcr_amd.Grid3d(x, x, x, n_threads=ns, cell_slowness=0, method='FSM', tt_from_rp=0, weno=1, dtype=np.float32)
+g.set_slowness(s)
+best = 1e9
+for _ in range(2):
+    g.raytrace(np.repeat(srcs, len(rc), axis=0), np.tile(rc, (ns, 1)))
+    best = min(best, g.timing()['sweep_ms'])
+it = sum(g.get_niter(i) + g.get_niterw(i) for i in range(ns))
+print(f"weno {n}^3 x{ns}: sweeps {best:.1f} ms, iterations (first-order + weno, summed) {it}, {n**3*it/best/1e3:.0f} Mnodes/s/iter, {ns/best*1e3:.1f} sources/s", flush=True)

@@ -195,6 +195,30 @@ def test_hip_weno_matches_oracle_multi_patch(oracle, kind):
     np.testing.assert_array_equal(r["tt"], o["tt"])
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hip_weno_wide_batch(oracle, dt):
+    """16 sources in 16 slots = 8 slot groups swept together: the WENO stage then runs its short-chunk
+    kernel (4 levels per chunk); every field and both iteration counts must equal the oracle's"""
+    import ttcr_amd
+
+    rng = np.random.default_rng(23)
+    nn = (37, 41, 33)
+    x, y, z = (np.arange(n) * 0.5 for n in nn)
+    X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
+    s = (1.0 / (1.0 + 0.05 * Z)) * (1.0 + 0.2 * np.sin(0.4 * X) * np.cos(0.3 * Y))
+    srcs = np.column_stack([rng.uniform(0.5, 17.5, 16), rng.uniform(0.5, 19.5, 16), rng.uniform(0.5, 15.5, 16)])
+    srcs[3] = [4.0, 6.5, 8.0]   # one source on a node
+    rcv1 = np.array([[1.0, 2.0, 3.0], [18.0, 20.0, 16.0]])
+    g = ttcr_amd.Grid3d(x, y, z, n_threads=16, cell_slowness=0, method="FSM", tt_from_rp=0, weno=1, maxit=15, dtype=dt)
+    tt = g.raytrace(np.repeat(srcs, 2, axis=0), np.tile(rcv1, (16, 1)), slowness=s)
+    for k in (0, 3, 7, 8, 15):
+        o = oracle.solve3d(dt, tuple(n - 1 for n in nn), g.dx, (0, 0, 0), s.flatten("F"), [srcs[k]], rcv=rcv1,
+                           weno=True, maxit=15)
+        np.testing.assert_array_equal(g.get_grid_traveltimes(k).flatten("F"), o["tt"])
+        assert (g.get_niter(k), g.get_niterw(k)) == (o["niter"], o["niterw"])
+        np.testing.assert_array_equal(tt[2 * k:2 * k + 2], o["tt_rcv"])
+
+
 @pytest.mark.parametrize("weno", [0, 1], ids=["first-order", "weno3"])
 @pytest.mark.parametrize("n_threads", [2, 3])
 def test_hip_multi_source_batches(oracle, weno, n_threads):
