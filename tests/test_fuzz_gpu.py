@@ -1,0 +1,84 @@
+"""Randomised GPU-vs-oracle parity: random small grids and option combinations (node / cell slowness, translated
+origin, multi-point sources with origin times, WENO, tt_from_rp / interp_vel, return_rays, 2-D dx != dz, rotated
+template), every field / iteration count / receiver value / ray bit-exact.  Smooth media whenever a raypath is
+walked (the reference's walk does not terminate on rough ones).  TTCR_FUZZ_SECONDS sets the budget (default 25)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _smooth(axes, rng):
+    g = np.meshgrid(*axes, indexing="ij")
+    z = g[-1] - axes[-1][0]
+    s = 1.0 / (1.0 + rng.uniform(0.02, 0.1) * z)
+    c = [rng.uniform(a[0], a[-1]) for a in axes]
+    r2 = sum((gi - ci) ** 2 for gi, ci in zip(g, c))
+    return s * (1.0 + rng.uniform(0.0, 0.25) * np.exp(-r2 / rng.uniform(4.0, 30.0)))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_configurations_match_the_oracle(oracle, seed):
+    import ttcr_amd
+
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + float(os.environ.get("TTCR_FUZZ_SECONDS", "25")) / 2
+    n_done = 0
+    while time.time() < t_end or n_done < 6:
+        dim = 3 if rng.random() < 0.6 else 2
+        dt = np.float32 if rng.random() < 0.5 else np.float64
+        cell = bool(rng.random() < 0.4)
+        weno = bool(rng.random() < 0.4)
+        walk = rng.random() < 0.5                       # raypath options
+        rays = walk and rng.random() < 0.5
+        iv = dim == 3 and walk and rng.random() < 0.3
+        translate = dim == 3 and rng.random() < 0.2
+        rotated = dim == 2 and not weno and rng.random() < 0.3
+        nc = tuple(int(v) for v in rng.integers(4 if weno else 2, 28 if dim == 3 else 70, dim))
+        dx = float(rng.choice([0.25, 0.5, 1.0]))
+        dz = dx if (dim == 3 or rng.random() < 0.6 or rotated) else float(rng.choice([0.125, 0.75]))
+        steps = (dx,) * 3 if dim == 3 else (dx, dz)
+        org = tuple(float(np.round(rng.uniform(-4, 4) * 8) / 8) for _ in range(dim))
+        axes = [o + np.arange(n + 1) * h for o, n, h in zip(org, nc, steps)]
+        caxes = [0.5 * (a[1:] + a[:-1]) for a in axes]
+        s = _smooth(caxes if cell else axes, rng) if (walk or rng.random() < 0.5) else rng.uniform(0.3, 1.0, [a.size for a in (caxes if cell else axes)])
+        npt = int(rng.integers(1, 3))
+        src = np.column_stack([rng.uniform(a[1] if a.size > 2 else a[0], a[-2] if a.size > 2 else a[-1], npt) for a in axes])
+        if rng.random() < 0.4:
+            src[0] = [a[int(rng.integers(0, a.size))] for a in axes]
+        t0 = np.round(rng.uniform(0, 0.5, npt), 3) if rng.random() < 0.5 else np.zeros(npt)
+        rcv = np.column_stack([rng.uniform(a[0], a[-1], 4) for a in axes])
+        rcv[0] = [a[int(rng.integers(0, a.size))] for a in axes]
+        source = np.hstack([t0[:, None], src])
+        # oracle first: cases whose walk leaves the grid / does not end are skipped (the reference throws / hangs)
+        kw = dict(cell_slowness=cell, rcv=rcv, weno=weno)
+        try:
+            if dim == 3:
+                o = oracle.solve3d(dt, nc, dx, org, s.flatten("F"), src, t0, translate=translate, tt_from_rp=walk and not rays,
+                                   interp_vel=iv, return_rays=rays, **kw)
+            else:
+                o = oracle.solve2d(dt, nc, dx, dz, org, s.ravel(), src, t0, rotated=rotated, tt_from_rp=walk and not rays,
+                                   return_rays=rays, **kw)
+        except RuntimeError:
+            continue
+        if dim == 3:
+            g = ttcr_amd.Grid3d(*axes, cell_slowness=cell, method="FSM", tt_from_rp=int(walk and not rays), interp_vel=int(iv),
+                                weno=int(weno), translate_grid=translate, dtype=dt)
+        else:
+            g = ttcr_amd.Grid2d(*axes, cell_slowness=cell, method="FSM", tt_from_rp=int(walk and not rays), weno=int(weno),
+                                rotated_template=int(rotated), dtype=dt)
+        out = g.raytrace(source, rcv, slowness=s, aggregate_src=True, return_rays=rays)
+        tt, got_rays = out if rays else (out, None)
+        tag = (dim, np.dtype(dt).name, nc, cell, weno, walk, rays, iv, translate, rotated)
+        field = g.get_grid_traveltimes()
+        np.testing.assert_array_equal(field.flatten("F") if dim == 3 else field.ravel(), o["tt"], err_msg=str(tag))
+        assert (g.get_niter(), g.get_niterw()) == (o["niter"], o["niterw"]), tag
+        np.testing.assert_array_equal(tt, o["tt_rcv"], err_msg=str(tag))
+        if rays:
+            for a, b in zip(got_rays, o["rays"]):
+                np.testing.assert_array_equal(a, b.astype(np.float64), err_msg=str(tag))
+        n_done += 1
+    assert n_done >= 6
