@@ -72,10 +72,14 @@ def test_hip_rotated_template_matches_golden_bit_exact(golden, c, dt):
 @pytest.mark.parametrize("dt,shape", [(np.float32, (1201, 150)), (np.float64, (600, 210)), (np.float32, (254, 700)),
                                       (np.float64, (511, 300))],
                          ids=["f32-2strips", "f64-2strips", "f32-1strip-256", "f64-2strips-edge"])
-def test_hip_rotated_template_strips_vs_oracle(oracle, dt, shape):
-    """grids wider than one column strip of the sweep45 kernel (1022 / 510 columns), random medium,
-    off-node source, two slots solved concurrently: bit-exact vs the CPU oracle"""
+@pytest.mark.parametrize("kernel", ["rows", "strips"])
+def test_hip_rotated_template_strips_vs_oracle(oracle, monkeypatch, dt, shape, kernel):
+    """larger grids, random medium, off-node source, two slots solved concurrently: bit-exact vs the CPU oracle,
+    with the row-parallel sweep45 kernel and with the strip kernel kept for grids too wide for its LDS rows
+    (strips of 1022 / 510 columns: the shapes cross a strip boundary)"""
     import ttcr_amd
+
+    monkeypatch.setenv("TTCR_FSM_SWEEP45", kernel)
 
     nx, nz = shape
     rng = np.random.default_rng(77)

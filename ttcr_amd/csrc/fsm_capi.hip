@@ -88,6 +88,7 @@ class GridBase {
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter, niterw;
     bool weno = false;
+    bool sweep45_strips = false;  // force the strip kernel of sweep45 (env TTCR_FSM_SWEEP45=strips; tests)
     bool rotated = false;  // 2-D rotated_template: sweep45 after every first-order sweep (ttcr/Grid2Drnfs.h:277-286)
     int ttrp = 0, interp_vel = 0;  // traveltime from raypath (ttcr/Grid3D.h:493-496), processVel
     int return_rays = 0;           // raytrace overloads with r_data (ttcr/Grid3D.h:546-586): rays kept for get_rays
@@ -250,6 +251,10 @@ class GridT : public GridBase {
         d_stamp.reserve(n_bricks * n_slots);  // one set per slot group is used
         d_iter.reserve(1);
         d_evals.reserve(n_slots);
+        if (dim == 2)   // the row-parallel sweep45 kernel keeps four rows in (dynamic) LDS
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fsm_sweep45_rows<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        if (const char* e = std::getenv("TTCR_FSM_SWEEP45")) sweep45_strips = std::string(e) == "strips";
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
     }
@@ -634,12 +639,18 @@ class GridT : public GridBase {
         a.n_nodes = n_nodes;
         a.mask_words = (uint32_t)mask_words;
         a.dx = dx;
-        // strips of NT-2 columns; 64 KB of LDS for the level ring.  Measured at 4096^2 fp32: 1024 threads
-        // 0.29 s per sweep-iteration, 256 threads (4x the strips, a quarter of the waves) 0.35 s
-        constexpr int NTMAX = sizeof(T) == 4 ? 1024 : 512;
         const int blocks = a.by_group ? batch * NS : batch;
-        if (a.nnx + 2 <= 256) fsm_sweep45<T, 256><<<blocks, 256, 0, stream>>>(a);
-        else fsm_sweep45<T, NTMAX><<<blocks, NTMAX, 0, stream>>>(a);
+        // rows in sequence, a row in parallel: four row buffers of nnz+2 values in LDS (fits up to ~10 000 fp32 /
+        // ~5 000 fp64 nodes along z); wider grids take the strip kernel with its level ring
+        const size_t smem = 4 * ((size_t)a.nnz + 2) * sizeof(T);
+        if (smem <= 156 * 1024 && !sweep45_strips) {
+            const int threads = (int)std::min<size_t>(1024, (((size_t)a.nnz + 63) / 64) * 64);
+            fsm_sweep45_rows<T><<<blocks, threads, smem, stream>>>(a);
+        } else {
+            constexpr int NTMAX = sizeof(T) == 4 ? 1024 : 512;
+            if (a.nnx + 2 <= 256) fsm_sweep45<T, 256><<<blocks, 256, 0, stream>>>(a);
+            else fsm_sweep45<T, NTMAX><<<blocks, NTMAX, 0, stream>>>(a);
+        }
         HIP_CHECK(hipGetLastError());
     }
 

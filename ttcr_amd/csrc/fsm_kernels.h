@@ -1406,6 +1406,84 @@ __global__ __launch_bounds__(NT) void fsm_sweep45(const Sweep45Args<T> a) {
     if ((threadIdx.x & 63) == 0 && accd != 0.0) atomicAdd(a.change + slot, accd);
 }
 
+// Row-parallel form of the same sweep.  update_node45 reads rows i-1 and i+1 only -- never its own row --
+// so inside one pass of the outer loop the nodes of a row do not depend on each other: the Gauss-Seidel
+// order of sweep45 is "rows in sequence, any order within a row" (the inner-loop direction of the four
+// sweeps is immaterial).  One workgroup per source walks the rows with four row buffers in LDS: A = the row
+// before (already updated), B = this row (updated in place), C = the next row (old values), D = being
+// filled with the row after next.  One barrier per row; global accesses are whole rows (z is contiguous).
+template <typename T>
+__global__ __launch_bounds__(1024) void fsm_sweep45_rows(const Sweep45Args<T> a) {
+    extern __shared__ unsigned char fsm_smem45[];
+    int slot;
+    if (a.by_group) {
+        const int z = blockIdx.x / a.ts, l = blockIdx.x % a.ts;
+        const int grp = a.slots[z];
+        if (grp < 0 || !((a.lmask[z] >> l) & 1)) return;
+        slot = grp * a.ts + l;
+    } else {
+        slot = a.slots[blockIdx.x];
+        if (slot < 0) return;
+    }
+    T* __restrict__ Tg = a.tt + ((size_t)(slot / a.ts) * a.n_nodes * a.ts + slot % a.ts);
+    const uint32_t* __restrict__ Fz = a.frozen + (size_t)slot * a.mask_words;
+    const int nnx = a.nnx, nnz = a.nnz, ts = a.ts;
+    const int W = nnz + 2;                       // one padding entry (max()) at either end of a row
+    T* buf = reinterpret_cast<T*>(fsm_smem45);
+    const T TMAX = real_traits<T>::max();
+    const int tid = threadIdx.x, NT = blockDim.x;
+    auto load_row = [&](int b, int i) {          // row i of the field (or max() outside the grid) into buffer b
+        T* dst = buf + (size_t)b * W;
+        if (i < 0 || i >= nnx) {
+            for (int j = tid; j < W; j += NT) dst[j] = TMAX;
+        } else {
+            const T* src = Tg + (size_t)i * nnz * ts;
+            for (int j = tid; j < nnz; j += NT) dst[j + 1] = ld_sc1(src + (size_t)j * ts);
+            if (tid == 0) { dst[0] = TMAX; dst[W - 1] = TMAX; }
+        }
+    };
+    T dec = 0;
+    for (int dir = 0; dir < 4; ++dir) {
+        const int di = (dir == 1 || dir == 2) ? -1 : 1;          // outer loop direction (ttcr/Grid2Drn.h:760-793)
+        int i = di > 0 ? 0 : nnx - 1;
+        int bA = 0, bB = 1, bC = 2, bD = 3;
+        load_row(bA, -1);
+        load_row(bB, i);
+        load_row(bC, i + di);
+        __syncthreads();
+        for (int r = 0; r < nnx; ++r, i += di) {
+            load_row(bD, i + 2 * di);
+            const T* __restrict__ A = buf + (size_t)bA * W;
+            T* __restrict__ B = buf + (size_t)bB * W;
+            const T* __restrict__ Cc = buf + (size_t)bC * W;
+            for (int j = tid; j < nnz; j += NT) {
+                const uint32_t n = (uint32_t)i * nnz + j;
+                if ((Fz[n >> 5] >> (n & 31)) & 1u) continue;
+                // the two diagonals: (next row, j+1) with (previous row, j-1), and (next row, j-1) with (previous
+                // row, j+1); which of them the reference calls a and b depends on the direction, the solver is symmetric
+                const T d1 = Cc[j + 2] < A[j] ? Cc[j + 2] : A[j];
+                const T d2 = Cc[j] < A[j + 2] ? Cc[j] : A[j + 2];
+                const T c = B[j + 1];
+                const T t = update2_fh(d1, d2, fh45(a.s[n], a.dx));
+                if (t < c) {
+                    B[j + 1] = t;
+                    st_sc1(Tg + (size_t)n * ts, t);
+                    dec += c - t;
+                }
+            }
+            __syncthreads();
+            const int o = bA; bA = bB; bB = bC; bC = bD; bD = o;
+        }
+        // the next sweep reads rows this one stored
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    double accd = (double)dec;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
+    if ((threadIdx.x & 63) == 0 && accd != 0.0) atomicAdd(a.change + slot, accd);
+}
+
 // ---- small kernels -------------------------------------------------------------------------
 
 template <typename T>
