@@ -251,8 +251,11 @@ struct SweepArgs {
 };
 
 // debug phase timer: 100 MHz constant clock, thread 0 of every block accumulates phase sums
+#ifndef FSM_ENABLE_PROF
+#define FSM_ENABLE_PROF 0   // build with -DFSM_ENABLE_PROF=1 to get the per-phase timers (TTCR_FSM_PROF=1)
+#endif
 #define FSM_PROF_MARK(slot_)                                                      \
-    if (a.prof && tid == 0) {                                                     \
+    if (FSM_ENABLE_PROF && a.prof && tid == 0) {                                  \
         const unsigned long long now_ = wall_clock64();                           \
         atomicAdd(a.prof + (slot_), now_ - prof_t);                               \
         prof_t = now_;                                                            \
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
     __shared__ T Tt[NROWS * RS];
 
     const int tid = threadIdx.x;
-    unsigned long long prof_t = a.prof ? wall_clock64() : 0ull;
+    unsigned long long prof_t = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
     const uint32_t tile = a.tiles[blockIdx.x];
     const int TJ = tile & 0xffffu, TK = tile >> 16;
     const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
     }
 
     FSM_PROF_MARK(2)  // level march
-    if (a.prof && tid == 0) atomicAdd(a.prof + 4, 1ull);
+    if (FSM_ENABLE_PROF && a.prof && tid == 0) atomicAdd(a.prof + 4, 1ull);
     // ---- write back (only when something in the tile changed)
     if (__syncthreads_or(changed)) {
         for (int f = tid; f < NT * BL; f += NT) {
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     __shared__ int s_chg[64];  // bricks of the read set changed by this chunk
 
     const int tid = threadIdx.x;
-    unsigned long long prof_t = a.prof ? wall_clock64() : 0ull;
+    unsigned long long prof_t = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
     if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
     __syncthreads();
     const int ticket = s_ticket;
@@ -1202,7 +1205,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             if (chg_b && bb2 >= 0 && bb2 < rs_nf) s_chg[base + bb2] = 1;
         }
         FSM_PROF_MARK(3)
-        if (a.prof && tid == 0) atomicAdd(a.prof + 7, 1ull);
+        if (FSM_ENABLE_PROF && a.prof && tid == 0) atomicAdd(a.prof + 7, 1ull);
 
         // (5) write back levels L0..L0+C-1 (tile q = H..H+C-1); the columns a downstream patch reads
         //     go out write-through (sc1)
