@@ -990,12 +990,13 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         // (1) wait until both upwind patches have published every level <= L0+C-2
         if (tid == 0 && (up_j || up_k)) {
             const int need = L0 + C - 1;
-            const unsigned long long t0 = wall_clock64();
+            unsigned long long t0 = 0;   // the clock is only read once a poll has failed (the common case: none does)
             int spins = 0;
             for (;;) {
                 const int vj = up_j ? __hip_atomic_load(up_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 const int vk = up_k ? __hip_atomic_load(up_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 if (vj >= need && vk >= need) break;
+                if (spins == 0) t0 = wall_clock64();
                 if ((++spins & 63) == 0) {
                     if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                     if (wall_clock64() - t0 > pa.timeout_ticks) {
