@@ -945,6 +945,22 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
     int pending = 0;            // progress value of the previous chunk, published once its stores have drained
+    // Chunks that may hold frozen nodes of source l: the patch overlaps the bounding box of the frozen nodes in
+    // J and K, and the chunk start L0 lies in [near_lo, near_hi] (the F extent of a chunk, clamped to the grid,
+    // is [L0 - jmaxp - kmaxp, L0 + C-1 - j0 - k0] in oriented i').  Worked out once per unit.
+    int near_lo[NS], near_hi[NS];
+    {
+        const int jlo = rj ? NJ - 1 - jmaxp : j0, jhi = rj ? NJ - 1 - j0 : jmaxp;
+        const int klo = rk ? NK - 1 - kmaxp : k0, khi = rk ? NK - 1 - k0 : kmaxp;
+#pragma unroll
+        for (int l = 0; l < NS; ++l) {
+            const int* b6 = bb + 6 * l;
+            const int b0 = rf ? NF - 1 - b6[1] : b6[0], b1 = rf ? NF - 1 - b6[0] : b6[1];   // oriented F range of the box
+            const bool jk = !(jhi < b6[2] || jlo > b6[3] || khi < b6[4] || klo > b6[5]) && b0 <= NF - 1 && b1 >= 0;
+            near_lo[l] = jk ? b0 - (C - 1) + j0 + k0 : 1;
+            near_hi[l] = jk ? b1 + jmaxp + kmaxp : 0;
+        }
+    }
     if (XS && dir > 0) {
         // previous sweep of this iteration: wait for the patches (of ITS oriented partition) that own
         // a column within 2H of ours -- at most 3 x 3 of them, one lane each
@@ -1106,19 +1122,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         pending = 0;
 
         bool near_src[NS];
-        {
-            int ilo = L0 - jmaxp - kmaxp, ihi = L0 + C - 1 - j0 - k0;
-            ilo = ilo < 0 ? 0 : ilo;
-            ihi = ihi > NF - 1 ? NF - 1 : ihi;
-            const int flo = rf ? NF - 1 - ihi : ilo, fhi = rf ? NF - 1 - ilo : ihi;
-            const int jlo = rj ? NJ - 1 - jmaxp : j0, jhi = rj ? NJ - 1 - j0 : jmaxp;
-            const int klo = rk ? NK - 1 - kmaxp : k0, khi = rk ? NK - 1 - k0 : kmaxp;
 #pragma unroll
-            for (int l = 0; l < NS; ++l) {
-                const int* b6 = bb + 6 * l;
-                near_src[l] = !(fhi < b6[0] || flo > b6[1] || jhi < b6[2] || jlo > b6[3] || khi < b6[4] || klo > b6[5]);
-            }
-        }
+        for (int l = 0; l < NS; ++l) near_src[l] = L0 >= near_lo[l] && L0 <= near_hi[l];
 
         P own[NQ];
 #pragma unroll
