@@ -718,6 +718,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     __shared__ P Tt[NROWS * RS];
     __shared__ int s_ticket;
     __shared__ int s_skip;
+    __shared__ int s_anychg;
     __shared__ int s_chg[64];  // bricks of the read set changed by this chunk
 
     const int tid = threadIdx.x;
@@ -1060,6 +1061,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             s_skip = 0;
         }
         __syncthreads();  // also: every read of the previous chunk's LDS tile is done
+        if (tid == 0) s_anychg = 0;   // (read last before this barrier; written again only after the staging barrier)
         FSM_PROF_MARK(1)
         if (s_skip) {
             // nothing in the read set changed since this chunk was last evaluated: no-op
@@ -1215,7 +1217,12 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
 
         // (5) write back levels L0..L0+C-1 (tile q = H..H+C-1); the columns a downstream patch reads
         //     go out write-through (sc1)
-        const bool any_changed = __syncthreads_or(changed);
+        // block-wide "did anything change": one LDS flag (cleared before the staging barrier), a ballot per wave.
+        // (__syncthreads_or is a library routine with a dispatch-packet load, DPP and LDS reductions and two
+        // barriers: measurable at once per chunk.)
+        if (wave_any(changed) && (tid & 63) == 0) s_anychg = 1;
+        __syncthreads();
+        const bool any_changed = s_anychg != 0;
         quiet = !any_changed;
         if (any_changed) {
 #pragma unroll
