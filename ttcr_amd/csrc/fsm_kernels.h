@@ -889,14 +889,22 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     // and the not-yet-swept values at levels L+H..L+C+H-1 of the own and downwind-halo columns
     T sv[C];
     P tv[NOWN + NHI];
+    int xs_next = 0, xs_level = -(1 << 30);
     auto issue_static = [&](int L) {
         const int eoff = jp + kp - L;  // e at which i' == 0
         const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;
         const int eb = eoff + NF - 1 < C - 1 ? eoff + NF - 1 : C - 1;
-        int x = L - kp;  // i' + j' at level L
-        x = rev ? NF + NJ - 2 - x : x;
-        x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
-        x = x < 0 ? x + M : x;
+        // position in the sheared copy, (i' + j') mod M (backwards for the opposite direction).  Consecutive
+        // chunks continue the walk where the previous call stopped; only a fresh start pays the modulo.
+        int x;
+        if (L == xs_level) {
+            x = xs_next;
+        } else {
+            x = L - kp;  // i' + j' at level L
+            x = rev ? NF + NJ - 2 - x : x;
+            x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
+            x = x < 0 ? x + M : x;
+        }
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             T v = 0;
@@ -904,6 +912,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             sv[q] = v;
             if (rev) { x = x == 0 ? M - 1 : x - 1; } else { x = x + 1 == M ? 0 : x + 1; }
         }
+        xs_next = x;
+        xs_level = L + C;
         const int sL = sf * L;
 #pragma unroll
         for (int it = 0; it < NOWN + NHI; ++it) {
