@@ -1067,13 +1067,11 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                 if (tid == 0) s_skip = mx < thr;
                 s_chg[tid] = 0;
             }
-        } else if (tid == 0) {
-            s_skip = 0;
         }
         __syncthreads();  // also: every read of the previous chunk's LDS tile is done
         if (tid == 0) s_anychg = 0;   // (read last before this barrier; written again only after the staging barrier)
         FSM_PROF_MARK(1)
-        if (s_skip) {
+        if (SKIP && s_skip) {
             // nothing in the read set changed since this chunk was last evaluated: no-op
             have_prev = false;
             quiet = true;
