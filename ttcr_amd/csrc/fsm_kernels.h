@@ -905,12 +905,20 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
             x = x < 0 ? x + M : x;
         }
+        // walk x by +-1 modulo M without a branch or a 64-bit multiply per element: xo = x * NJ alongside
+        const T* __restrict__ Sp = Sg + sbase;
+        const int step = rev ? -1 : 1, x_edge = rev ? -1 : M, x_reset = rev ? M - 1 : 0;
+        const uint32_t xo_step = (uint32_t)(step * NJ), xo_reset = (uint32_t)x_reset * (uint32_t)NJ;
+        uint32_t xo = (uint32_t)x * (uint32_t)NJ;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             T v = 0;
-            if (q >= ea && q <= eb) v = Sg[sbase + (size_t)x * NJ];
+            if (q >= ea && q <= eb) v = Sp[xo];
             sv[q] = v;
-            if (rev) { x = x == 0 ? M - 1 : x - 1; } else { x = x + 1 == M ? 0 : x + 1; }
+            x += step;
+            const bool wrap = x == x_edge;
+            x = wrap ? x_reset : x;
+            xo = wrap ? xo_reset : xo + xo_step;
         }
         xs_next = x;
         xs_level = L + C;
