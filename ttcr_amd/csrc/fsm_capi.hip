@@ -101,7 +101,13 @@ class GridBase {
 
 // tile shapes (threads = PJ*PK); see DESIGN.md section 4 for the LDS budget
 template <typename T, int DIM> struct TileCfg;
-template <> struct TileCfg<float, 3> { static constexpr int PJ = 16, PK = 16, BL = 16; };
+#ifndef FSM_PJ3
+#define FSM_PJ3 16
+#endif
+#ifndef FSM_PK3
+#define FSM_PK3 16
+#endif
+template <> struct TileCfg<float, 3> { static constexpr int PJ = FSM_PJ3, PK = FSM_PK3, BL = 16; };
 template <> struct TileCfg<double, 3> { static constexpr int PJ = 16, PK = 8, BL = 16; };
 #ifndef FSM_PJ2
 #define FSM_PJ2 64
