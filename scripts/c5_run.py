@@ -1,6 +1,6 @@
 """BASELINE config 5 (Grid2d 4096^2 nodes, 16 sources, fp32) + a single source, for 2-D tuning"""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd, cases
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dx = 20.0/(n-1); x = np.arange(n)*dx

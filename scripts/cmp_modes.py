@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd, cases
 n=int(sys.argv[1]) if len(sys.argv)>1 else 200
 rng=np.random.default_rng(1)

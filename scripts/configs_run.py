@@ -1,6 +1,6 @@
 """BASELINE.json configs 1, 2, 4, 5 on one MI355X (config 3 is bench.py). Prints one line each."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd, cases
 
 def run(g, src, rcv, reps=3):

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, cases
 from gpu_util import run_case
 from oracle import oracle as O

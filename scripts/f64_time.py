@@ -1,6 +1,6 @@
 """fp64 (the reference's default precision): 256^3 / 384^3 gradient, 1 and 8 sources"""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd, cases
 for n in (256, 384):
     dx = 20.0 / (n - 1); x = np.arange(n) * dx

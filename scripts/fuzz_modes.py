@@ -2,7 +2,7 @@
 overlapping-sweeps driver (mode 2, default), the per-sweep persistent driver (mode 1) and the launch-per-tile
 driver (mode 0, first-order stage only); all fields must be bit-identical.  usage: fuzz_modes.py <seconds> [seed]"""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0

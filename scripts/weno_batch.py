@@ -1,6 +1,6 @@
 """default-path throughput: weno=1, several sources at once (pairing on/off via TTCR_FSM_PAIR)"""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd, cases
 n = int(sys.argv[1]); ns = int(sys.argv[2])
 dx = 20.0 / (n - 1); x = np.arange(n) * dx

@@ -1,6 +1,6 @@
 """mode 1 (launch per sweep) vs mode 2 (one launch per iteration, overlapping sweeps): bit equality + speed"""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd, cases
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
