@@ -282,7 +282,7 @@ def main():
                          "launches": int(launches), "avg_launch_us_hip_events": round(sweep_ms * 1e3 / max(launches, 1), 3),
                          "algorithmic_bytes_per_launch": round(bytes_total / max(launches, 1), 1)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
