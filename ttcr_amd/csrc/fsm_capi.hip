@@ -323,6 +323,7 @@ class GridT : public GridBase {
         pa.nbf = nbf; pa.nbj = nbj; pa.nbk = nbk;
         pa.ndir = DIM == 3 ? 8 : 4;
         pa.skip = skip;
+
         const dim3 block(C::PJ * C::PK), grid((unsigned)n_patches * batch);
         const int ndir = DIM == 3 ? 8 : 4;
         if (mode == 2) {
@@ -338,6 +339,8 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
             if (skip)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
+            else if (DIM == 2 || batch >= 4)   // counters sampled one chunk ahead (template PRE)
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, 0, stream>>>(pa);
             else
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
             HIP_CHECK(hipGetLastError());
