@@ -134,6 +134,7 @@ class GridT : public GridBase {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
+    DevBuf<int> d_rslot;
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
     DevBuf<int> d_rstat;
@@ -892,6 +893,44 @@ class GridT : public GridBase {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
+    // the same for every source of a batch: one upload, one launch, one read-back
+    void interp_batch(const std::vector<int>& sl, const std::vector<int>& sr, const int* rx_off, const T* rx, T* tt_out) {
+        const int nc = ncoord();
+        size_t n = 0;
+        for (int s2 : sr) n += (size_t)(rx_off[s2 + 1] - rx_off[s2]);
+        if (n == 0) return;
+        std::vector<T> p(nc * n), o(n);
+        std::vector<int> so(n);
+        size_t k = 0;
+        for (size_t b = 0; b < sl.size(); ++b) {
+            const int m = rx_off[sr[b] + 1] - rx_off[sr[b]];
+            std::memcpy(p.data() + nc * k, rx + (size_t)nc * rx_off[sr[b]], sizeof(T) * nc * m);
+            std::fill(so.begin() + k, so.begin() + k + m, sl[b]);
+            k += m;
+        }
+        d_rx.reserve(nc * n);
+        d_out.reserve(n);
+        d_rslot.reserve(n);
+        HIP_CHECK(hipMemcpyAsync(d_rx.p, p.data(), sizeof(T) * nc * n, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rslot.p, so.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream));
+        const int blocks = (int)((n + 127) / 128);
+        if (dim == 3)
+            fsm_interp3d_batch<T><<<blocks, 128, 0, stream>>>(d_tt.p, NS, n_nodes, d_rslot.p, d_rx.p, d_out.p, (int)n, (int)ncx + 1,
+                                                              (int)ncy + 1, dx, xmin, ymin, zmin);
+        else
+            fsm_interp2d_batch<T><<<blocks, 128, 0, stream>>>(d_tt.p, NS, n_nodes, d_rslot.p, d_rx.p, d_out.p, (int)n, (int)ncz + 1, dx,
+                                                              dz, xmin, zmin);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(o.data(), d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        k = 0;
+        for (size_t b = 0; b < sl.size(); ++b) {
+            const int m = rx_off[sr[b] + 1] - rx_off[sr[b]];
+            std::memcpy(tt_out + rx_off[sr[b]], o.data() + k, sizeof(T) * m);
+            k += m;
+        }
+    }
+
     // Grid3Drn::getTraveltimeFromRaypath for every receiver of one source (ttcr/Grid3D.h:493-496); with
     // `record`, Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) instead (ttcr/Grid3D.h:546-586): the rays are
     // appended to rays_off / rays_pts (shifted back by the origin of a translated grid, :579-584)
@@ -1048,14 +1087,15 @@ class GridT : public GridBase {
                 const size_t c1 = std::min(slots.size(), c0 + mb);
                 std::vector<int> sl(slots.begin() + c0, slots.begin() + c1), sr(srcs.begin() + c0, srcs.begin() + c1);
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
+                if (!(ttrp || return_rays)) {
+                    interp_batch(sl, sr, rx_off, rx.data(), tt_out);
+                    continue;
+                }
                 for (size_t b = 0; b < sl.size(); ++b) {
                     const int n = sr[b];
-                    if (ttrp || return_rays)
-                        raypath_grid_coords(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)nc * tx_off[n], t0 + tx_off[n],
-                                            rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n],
-                                            return_rays);
-                    else
-                        interp_grid_coords(sl[b], rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n]);
+                    raypath_grid_coords(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)nc * tx_off[n], t0 + tx_off[n],
+                                        rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n],
+                                        return_rays);
                 }
             }
         }

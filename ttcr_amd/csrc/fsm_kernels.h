@@ -1793,6 +1793,19 @@ __global__ void fsm_interp3d(const T* __restrict__ Tn, int ts, const T* __restri
     out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, dx, xmin, ymin, zmin);
 }
 
+// the receivers of a whole batch of sources in one launch: receiver r reads the field of slot slot_of[r]
+// (fields of a group interleaved: element stride ts, group stride ts * n_nodes)
+template <typename T>
+__global__ void fsm_interp3d_batch(const T* __restrict__ tt0, int ts, size_t n_nodes, const int* __restrict__ slot_of,
+                                   const T* __restrict__ pts, T* __restrict__ out, int n, int nnx, int nny, T dx,
+                                   T xmin, T ymin, T zmin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int slot = slot_of[r];
+    const T* Tn = tt0 + (size_t)(slot / ts) * n_nodes * ts + slot % ts;
+    out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, dx, xmin, ymin, zmin);
+}
+
 // ---- traveltime from raypath (tt_from_rp, the 3-D default of ttcrpy) --------------------------
 // Grid3Drn::getTraveltimeFromRaypath (ttcr/Grid3Drn.h:1103-1243): steepest-descent walk from the
 // receiver to the source through the traveltime field -- gradient by the 4th-order centred
@@ -2083,6 +2096,17 @@ __global__ void fsm_interp2d(const T* __restrict__ Tn, int ts, const T* __restri
                              int nnz, T dx, T dz, T xmin, T zmin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    out[r] = interp2d_pt(Tn, ts, nnz, dx, dz, xmin, zmin, pts[2 * r], pts[2 * r + 1]);
+}
+
+template <typename T>
+__global__ void fsm_interp2d_batch(const T* __restrict__ tt0, int ts, size_t n_nodes, const int* __restrict__ slot_of,
+                                   const T* __restrict__ pts, T* __restrict__ out, int n, int nnz, T dx, T dz, T xmin,
+                                   T zmin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int slot = slot_of[r];
+    const T* Tn = tt0 + (size_t)(slot / ts) * n_nodes * ts + slot % ts;
     out[r] = interp2d_pt(Tn, ts, nnz, dx, dz, xmin, zmin, pts[2 * r], pts[2 * r + 1]);
 }
 
