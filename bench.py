@@ -89,8 +89,8 @@ def cpu_baseline(n=256, n_src=3):
     return out
 
 
-KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,true> (one launch per sweep-iteration)",
-           "1": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,false> (one launch per directional sweep)",
+KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,true,true> (one launch per sweep-iteration)",
+           "1": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,false,false> (one launch per directional sweep)",
            "0": "fsm_sweep_tile<float,16,16,16,true> (one launch per tile wavefront)"}
 
 
