@@ -563,28 +563,24 @@ __device__ __forceinline__ double weno_bwd(double v0, double v1, double v2, doub
 }
 
 // One axis of update_node_weno3 (ttcr/Grid3Drn.h:3084-3196): m2..p2 are the values at natural
-// offsets -2..+2 along the axis, idx the node's natural index, n the last index.
+// offsets -2..+2 along the axis, idx the node's natural index, n the last index.  The reference's
+// if / else-if chain (first node, second, last, last but one, interior) as selects on ONE forward and
+// ONE backward stencil: the stencils of the cases that do not apply are evaluated on whatever the
+// out-of-range entries hold and dropped (no traps on the GPU), every case keeps its own operands and
+// its own `a < t ? a : t`.  One copy of the stencil arithmetic instead of four keeps the unrolled level
+// loop of the WENO kernel inside the instruction cache.
 template <typename T>
 __device__ __forceinline__ T weno_axis(T m2, T m1, T c, T p1, T p2, int idx, int n, T h, double r2) {
-    T a, t;
-    if (idx == 0) {
-        a = p1;
-    } else if (idx == 1) {
-        a = weno_fwd(m1, c, p1, p2, h, r2);
-        t = m1;
-        a = a < t ? a : t;
-    } else if (idx == n) {
-        a = m1;
-    } else if (idx == n - 1) {
-        a = weno_bwd(m2, m1, c, p1, h, r2);
-        t = p1;
-        a = a < t ? a : t;
-    } else {
-        a = weno_fwd(m1, c, p1, p2, h, r2);
-        t = weno_bwd(m2, m1, c, p1, h, r2);
-        a = a < t ? a : t;
-    }
-    return a;
+    const bool c0 = idx == 0;
+    const bool c1 = !c0 && idx == 1;
+    const bool cn = !c0 && !c1 && idx == n;
+    const bool cm = !c0 && !c1 && !cn && idx == n - 1;
+    const T F = weno_fwd(m1, c, p1, p2, h, r2);
+    const T B = weno_bwd(m2, m1, c, p1, h, r2);
+    T a = cm ? B : F;
+    const T t = c1 ? m1 : (cm ? p1 : B);
+    a = a < t ? a : t;
+    return c0 ? p1 : (cn ? m1 : a);
 }
 
 // Local solver of the WENO stage: the reference's literal compare/swap network and nested ifs
