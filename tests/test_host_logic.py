@@ -87,6 +87,36 @@ def test_source_dedup_keeps_first_occurrence_order():
     assert all(t.shape == (1,) and t[0] == 0 for t in vt0)
 
 
+def test_source_grouping_matches_the_reference_procedure():
+    """_split_sources against the literal steps of rgrid.pyx:926-938 / :1000-1007 (np.unique over the rows, then one
+    row mask per unique source) on random row sets: repeated blocks, shuffled rows, -0.0, equal points with
+    different origin times"""
+    rng = np.random.default_rng(8)
+    g = bare3d(11)
+    for trial in range(60):
+        ns, per = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+        pts = rng.integers(0, 4, (ns, 3)).astype(float)
+        t0 = rng.integers(0, 2, ns).astype(float)
+        src = np.repeat(np.column_stack([t0, pts]), per, axis=0)
+        if trial % 3 == 0:
+            src = src[rng.permutation(src.shape[0])]
+        src[rng.random(src.shape) < 0.05] *= -1.0          # -0.0 entries (coordinates stay inside: only zeros flip
+        src = np.where(src < 0, 0.0 * src, src)            # sign; the rest is restored)
+        rcv = rng.uniform(0, 10, (src.shape[0], 3))
+        _, ind = np.unique(src, axis=0, return_index=True)
+        tmp = src[np.sort(ind)]
+        if tmp.shape[0] == 1:
+            continue                                        # (single-source branch: tested below)
+        vTx, vt0, vRx, iRx = g._split_sources(src, rcv, False)
+        assert len(vTx) == tmp.shape[0]
+        for n in range(tmp.shape[0]):
+            rows = np.nonzero(np.sum(tmp[n, 1:] == src[:, 1:], axis=1) == 3)[0]
+            np.testing.assert_array_equal(iRx[n], rows)
+            np.testing.assert_array_equal(vRx[n], rcv[rows])
+            np.testing.assert_array_equal(vTx[n], tmp[n:n + 1, 1:])
+            assert vt0[n][0] == tmp[n, 0]
+
+
 def test_single_source_gets_all_receivers_and_aggregate():
     g = bare3d(11)
     rcv = np.array([[0., 0, 0], [1, 0, 0], [2, 0, 0]])
