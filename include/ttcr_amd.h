@@ -76,6 +76,11 @@ void ttcr_fsm_destroy(ttcr_fsm_grid* g);
  * that is already resident in HBM on the grid's device (no PCIe copy). */
 int ttcr_fsm_set_slowness(ttcr_fsm_grid* g, const void* s, size_t n);
 int ttcr_fsm_set_slowness_device(ttcr_fsm_grid* g, const void* d_s, size_t n);
+/* The same for a 3-D model that lies in host memory as an (nx, ny, nz) array in C order (z fastest) -- what
+ * the Python classes receive (src/ttcrpy/rgrid.pyx:532-569 flattens it to x-fastest on the host before
+ * Grid3D::setSlowness): uploaded as it lies, permuted on the device.  2-D grids: identical to
+ * ttcr_fsm_set_slowness (their flat order is C order already). */
+int ttcr_fsm_set_slowness_c_order(ttcr_fsm_grid* g, const void* s, size_t n);
 
 /* Replaces: Grid3Drn::getSlowness (ttcr/Grid3Drn.h:90-97): NODE slowness, n = node count. */
 int ttcr_fsm_get_slowness(ttcr_fsm_grid* g, void* out, size_t n);

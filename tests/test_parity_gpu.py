@@ -364,3 +364,42 @@ def test_hip_raypaths_2d_match_golden(golden, c, dt):
     g.set_traveltime_from_raypath(False)
     tt0 = g.raytrace(source_array(c), c["rcv"], aggregate_src=True)
     np.testing.assert_array_equal(tt0, golden[key + ("/weno_tt_rcv" if w else "/tt_rcv")])
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(5, 7, 9), (33, 34, 70), (64, 31, 32), (2, 2, 130)])
+def test_hip_c_order_model_upload(dt, shape):
+    """set_slowness / set_velocity hand the (nx, ny, nz) array over in C order and the device permutes it
+    (ttcr_fsm_set_slowness_c_order): same solver state as the host-side flatten('F') of rgrid.pyx:562-565 through
+    the plain entry point -- node slowness read back, and for a cell grid the solved field, bit for bit"""
+    import ttcr_amd
+    from ttcr_amd import _lib
+    from ttcr_amd.rgrid import _ptr
+
+    rng = np.random.default_rng(sum(shape))
+    axes = [np.arange(n + 1) * 0.5 for n in shape]
+    # node grid: what the solver holds is the array itself
+    a = rng.uniform(0.2, 1.0, [n + 1 for n in shape])
+    g = ttcr_amd.Grid3d(*axes, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    g.set_slowness(a)
+    np.testing.assert_array_equal(g.get_slowness(), a.astype(dt))
+    g.set_slowness(a.ravel())                    # flat C order in
+    np.testing.assert_array_equal(g.get_slowness(), a.astype(dt))
+    g.set_velocity(1.0 / a)
+    np.testing.assert_array_equal(g.get_slowness(), (1.0 / (1.0 / a)).astype(dt))
+    # cell grid: against the plain entry point fed with the host-side permutation
+    c = rng.uniform(0.2, 1.0, shape)
+    src = np.array([[axes[0][1], axes[1][1], axes[2][2]]])
+    rcv = np.array([[axes[0][-1], axes[1][-1], axes[2][-1]]])
+    fields = []
+    for plain in (False, True):
+        gc = ttcr_amd.Grid3d(*axes, cell_slowness=1, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+        if plain:
+            s = np.ascontiguousarray(c.flatten("F"), dtype=dt)
+            _lib.check(gc._lib.ttcr_fsm_set_slowness(gc._h, _ptr(s), s.size))
+        else:
+            gc.set_slowness(c)
+        gc.raytrace(src, rcv)
+        fields.append((gc.get_slowness(), gc.get_grid_traveltimes()))
+    np.testing.assert_array_equal(fields[0][0], fields[1][0])
+    np.testing.assert_array_equal(fields[0][1], fields[1][1])

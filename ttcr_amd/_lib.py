@@ -34,6 +34,7 @@ SYMBOLS = {
     "ttcr_fsm_destroy": (None, [_P]),
     "ttcr_fsm_set_slowness": (_I, [_P, _P, C.c_size_t]),
     "ttcr_fsm_set_slowness_device": (_I, [_P, _P, C.c_size_t]),
+    "ttcr_fsm_set_slowness_c_order": (_I, [_P, _P, C.c_size_t]),
     "ttcr_fsm_get_slowness": (_I, [_P, _P, C.c_size_t]),
     "ttcr_fsm_raytrace": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
     "ttcr_fsm_raytrace_multi": (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),

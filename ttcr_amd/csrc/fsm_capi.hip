@@ -75,7 +75,7 @@ struct Timing {
 class GridBase {
    public:
     virtual ~GridBase() {}
-    virtual void set_slowness(const void* s, size_t n, bool on_device) = 0;
+    virtual void set_slowness(const void* s, size_t n, bool on_device, bool c_order = false) = 0;
     virtual void get_slowness(void* out, size_t n) = 0;
     virtual void raytrace_multi(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
                                 const void* rx, void* tt_out, int forced_slot) = 0;
@@ -423,16 +423,26 @@ class GridT : public GridBase {
     }
 
     // ---- slowness ---------------------------------------------------------------------
-    void set_slowness(const void* s, size_t n, bool on_device) override {
+    // c_order (3-D): `s` is the (nx, ny, nz) array in C order; it is uploaded as it lies and permuted to the
+    // solver's x-fastest order on the device (the strided host-side flatten('F') of a 512^3 model takes 0.8 s)
+    void set_slowness(const void* s, size_t n, bool on_device, bool c_order) override {
         HIP_CHECK(hipSetDevice(device));
         const size_t expect = cell ? n_cells : n_nodes;
         if (n != expect) throw std::length_error("Error: slowness vectors of incompatible size.");
         const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-        if (!cell) {
-            HIP_CHECK(hipMemcpyAsync(d_s.p, s, n * sizeof(T), kind, stream));
+        if (cell) d_cells.reserve(n_cells);
+        T* dst = cell ? d_cells.p : d_s.p;
+        DevBuf<T> staged;
+        if (c_order && dim == 3) {
+            const int ax = (int)ncx + (cell ? 0 : 1), ay = (int)ncy + (cell ? 0 : 1), az = (int)ncz + (cell ? 0 : 1);
+            staged.reserve(n);
+            HIP_CHECK(hipMemcpyAsync(staged.p, s, n * sizeof(T), kind, stream));
+            fsm_c_to_x_fastest<T><<<dim3((az + 31) / 32, (ax + 31) / 32, ay), dim3(32, 8), 0, stream>>>(staged.p, dst, ax, ay, az);
+            HIP_CHECK(hipGetLastError());
         } else {
-            d_cells.reserve(n_cells);
-            HIP_CHECK(hipMemcpyAsync(d_cells.p, s, n * sizeof(T), kind, stream));
+            HIP_CHECK(hipMemcpyAsync(dst, s, n * sizeof(T), kind, stream));
+        }
+        if (cell) {
             const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 4096);
             if (dim == 3)
                 fsm_cells_to_nodes3d<T><<<blocks, 256, 0, stream>>>(d_cells.p, d_s.p, (int)ncx, (int)ncy, (int)ncz);
@@ -1204,6 +1214,9 @@ void ttcr_fsm_destroy(ttcr_fsm_grid* g) { delete g; }
 
 int ttcr_fsm_set_slowness(ttcr_fsm_grid* g, const void* s, size_t n) {
     return guarded([&] { g->impl->set_slowness(s, n, false); });
+}
+int ttcr_fsm_set_slowness_c_order(ttcr_fsm_grid* g, const void* s, size_t n) {
+    return guarded([&] { g->impl->set_slowness(s, n, false, true); });
 }
 int ttcr_fsm_set_slowness_device(ttcr_fsm_grid* g, const void* d_s, size_t n) {
     return guarded([&] { g->impl->set_slowness(d_s, n, true); });

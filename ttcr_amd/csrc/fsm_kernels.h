@@ -1789,6 +1789,24 @@ __global__ void fsm_interp3d(const T* __restrict__ Tn, int ts, const T* __restri
     out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, dx, xmin, ymin, zmin);
 }
 
+// (nx, ny, nz) array in C order (z fastest, what numpy hands over) -> the solver's flat order (x fastest):
+// 32 x 32 tiles of an (i, k) plane through LDS, reads coalesced along k, writes along i.  blockDim = (32, 8).
+template <typename T>
+__global__ void fsm_c_to_x_fastest(const T* __restrict__ in, T* __restrict__ out, int nx, int ny, int nz) {
+    __shared__ T tile[32][33];
+    const int j = blockIdx.z;
+    const int k0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = i0 + r, k = k0 + threadIdx.x;
+        if (i < nx && k < nz) tile[r][threadIdx.x] = in[((size_t)i * ny + j) * nz + k];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = k0 + r, i = i0 + threadIdx.x;
+        if (i < nx && k < nz) out[((size_t)k * ny + j) * nx + i] = tile[threadIdx.x][r];
+    }
+}
+
 // the receivers of a whole batch of sources in one launch: receiver r reads the field of slot slot_of[r]
 // (fields of a group interleaved: element stride ts, group stride ts * n_nodes)
 template <typename T>

@@ -447,16 +447,30 @@ class _Grid3d(_GridBase):
             return a.reshape((nx, ny, nz)).flatten('F')
         raise ValueError('%s must be 1D or 3D ndarray' % what)
 
+    def _c_order(self, a, what):
+        """the checks of _to_flat_F without its strided copy: the array in C order, flat"""
+        nx, ny, nz = self.shape
+        a = np.asarray(a)
+        if a.size != nx * ny * nz:
+            raise ValueError('%s vector has wrong size' % what)
+        if a.ndim == 3:
+            if a.shape != (nx, ny, nz):
+                raise ValueError('%s has wrong shape' % what)
+        elif a.ndim != 1:
+            raise ValueError('%s must be 1D or 3D ndarray' % what)
+        return np.ascontiguousarray(a).reshape(-1)
+
     def set_slowness(self, slowness):
-        """Assign slowness, shape (nx, ny, nz) or flattened in C order (rgrid.pyx:532-569)"""
-        s = np.ascontiguousarray(self._to_flat_F(slowness, 'Slowness'), dtype=self._dtype)
-        _lib.check(self._lib.ttcr_fsm_set_slowness(self._h, _ptr(s), s.size))
+        """Assign slowness, shape (nx, ny, nz) or flattened in C order (rgrid.pyx:532-569); the permutation to
+        the solver's x-fastest order is done on the device (ttcr_fsm_set_slowness_c_order)"""
+        s = np.ascontiguousarray(self._c_order(slowness, 'Slowness'), dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_set_slowness_c_order(self._h, _ptr(s), s.size))
 
     def set_velocity(self, velocity):
         """Assign velocity (rgrid.pyx:571-608): slowness = 1/velocity"""
-        v = self._to_flat_F(velocity, 'velocity')
+        v = self._c_order(velocity, 'velocity')
         s = np.ascontiguousarray(1. / v, dtype=self._dtype)
-        _lib.check(self._lib.ttcr_fsm_set_slowness(self._h, _ptr(s), s.size))
+        _lib.check(self._lib.ttcr_fsm_set_slowness_c_order(self._h, _ptr(s), s.size))
 
     def raytrace(self, source, rcv, slowness=None, thread_no=None, aggregate_src=False, compute_L=False,
                  compute_M=False, return_rays=False):
