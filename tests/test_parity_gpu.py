@@ -403,3 +403,39 @@ def test_hip_c_order_model_upload(dt, shape):
         fields.append((gc.get_slowness(), gc.get_grid_traveltimes()))
     np.testing.assert_array_equal(fields[0][0], fields[1][0])
     np.testing.assert_array_equal(fields[0][1], fields[1][1])
+
+
+@pytest.mark.parametrize("n_threads", [1, 2, 3])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hip_raypath_traveltimes_of_a_batch(oracle, dt, n_threads):
+    """tt_from_rp=1 (the ttcrpy default) with several sources per call: the receivers of all sources of a batch are
+    walked in one launch (raypath_batch); every value must equal the per-source walk of the oracle.  Smooth medium
+    (the reference's walk needs one); the second source sits on a receiver (t0 shortcut), sources carry origin times."""
+    import ttcr_amd
+
+    nn = (29, 25, 33)
+    dx = 0.5
+    x, y, z = (np.arange(n) * dx for n in nn)
+    X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
+    s = (1.0 / (1.0 + 0.08 * Z)) * (1.0 + 0.2 * np.exp(-((X - 6) ** 2 + (Y - 5) ** 2 + (Z - 8) ** 2) / 20.0))
+    srcs = np.array([[0.25, 3.3, 4.1, 5.7], [0.0, 7.0, 6.0, 8.0], [0.5, 10.0, 9.0, 12.0], [0.0, 11.2, 3.3, 6.1], [0.125, 7.7, 7.7, 7.7]])
+    rcv1 = np.array([[1.0, 2.0, 3.0], [14.0, 12.0, 16.0], [5.5, 0.0, 7.25], [7.0, 6.0, 8.0]])
+    g = ttcr_amd.Grid3d(x, y, z, n_threads=n_threads, cell_slowness=0, method="FSM", tt_from_rp=1, weno=1, dtype=dt)
+    tt = g.raytrace(np.repeat(srcs, len(rcv1), axis=0), np.tile(rcv1, (len(srcs), 1)), slowness=s)
+    for n, p in enumerate(srcs):
+        o = oracle.solve3d(dt, tuple(m - 1 for m in nn), dx, (0, 0, 0), s.flatten("F"), [p[1:]], [p[0]], rcv=rcv1, weno=True,
+                           tt_from_rp=True)
+        np.testing.assert_array_equal(tt[len(rcv1) * n:len(rcv1) * (n + 1)], o["tt_rcv"], err_msg=str(n))
+    # 2-D twin (cell grid: the walk integrates the cell slowness)
+    nc = (60, 44)
+    x2, z2 = np.arange(nc[0] + 1) * 0.25, np.arange(nc[1] + 1) * 0.25
+    zc = 0.5 * (z2[1:] + z2[:-1])
+    s2 = np.broadcast_to(1.0 / (1.0 + 0.1 * zc), nc).copy()
+    srcs2 = np.array([[0.5, 3.3, 4.1], [0.0, 10.0, 9.0], [0.25, 13.0, 2.1]])
+    rcv2 = np.array([[1.0, 2.0], [14.8, 10.8], [10.0, 9.0]])
+    g2 = ttcr_amd.Grid2d(x2, z2, n_threads=n_threads, cell_slowness=1, method="FSM", tt_from_rp=1, weno=1, dtype=dt)
+    tt2 = g2.raytrace(np.repeat(srcs2, len(rcv2), axis=0), np.tile(rcv2, (len(srcs2), 1)), slowness=s2)
+    for n, p in enumerate(srcs2):
+        o = oracle.solve2d(dt, nc, 0.25, 0.25, (0, 0), s2.ravel(), [p[1:]], [p[0]], cell_slowness=True, rcv=rcv2, weno=True,
+                           tt_from_rp=True)
+        np.testing.assert_array_equal(tt2[len(rcv2) * n:len(rcv2) * (n + 1)], o["tt_rcv"], err_msg="2d %d" % n)

@@ -135,6 +135,7 @@ class GridT : public GridBase {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
     DevBuf<int> d_rslot;
+    DevBuf<RaySrc> d_rdesc;
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
     DevBuf<int> d_rstat;
@@ -941,6 +942,88 @@ class GridT : public GridBase {
         }
     }
 
+    // getTraveltimeFromRaypath for the receivers of every source of a batch in ONE launch (one thread per receiver:
+    // a single source's few hundred receivers leave the device empty); errors as in raypath_grid_coords
+    void raypath_batch(const std::vector<int>& sl, const std::vector<int>& sr, const int* tx_off, const T* tx, const T* t0,
+                       const int* rx_off, const T* rx, T* tt_out) {
+        const int nc = ncoord();
+        size_t n = 0;
+        for (int s2 : sr) n += (size_t)(rx_off[s2 + 1] - rx_off[s2]);
+        if (n == 0) return;
+        std::vector<T> p(nc * n), o(n), txb;
+        std::vector<T> t0b;
+        std::vector<int> so(n), st(n);
+        std::vector<RaySrc> desc(sl.size());
+        size_t k = 0;
+        for (size_t b = 0; b < sl.size(); ++b) {
+            const int src = sr[b], m = rx_off[src + 1] - rx_off[src];
+            desc[b].tt_off = (long long)(tt_ptr(sl[b]) - d_tt.p);
+            desc[b].tx_off = (int)t0b.size();
+            desc[b].n_tx = tx_off[src + 1] - tx_off[src];
+            txb.insert(txb.end(), tx + (size_t)nc * tx_off[src], tx + (size_t)nc * tx_off[src + 1]);
+            t0b.insert(t0b.end(), t0 + tx_off[src], t0 + tx_off[src + 1]);
+            std::memcpy(p.data() + nc * k, rx + (size_t)nc * rx_off[src], sizeof(T) * nc * m);
+            std::fill(so.begin() + k, so.begin() + k + m, (int)b);
+            k += m;
+        }
+        d_rsrc.reserve(txb.size());
+        d_rt0.reserve(t0b.size());
+        d_rx.reserve(nc * n);
+        d_out.reserve(n);
+        d_rstat.reserve(n);
+        d_rslot.reserve(n);
+        d_rdesc.reserve(desc.size());
+        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txb.data(), sizeof(T) * txb.size(), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0b.data(), sizeof(T) * t0b.size(), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rx.p, p.data(), sizeof(T) * nc * n, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rslot.p, so.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rdesc.p, desc.data(), sizeof(RaySrc) * desc.size(), hipMemcpyHostToDevice, stream));
+        const long max_steps = 8L * ((long)ncx + ncy + ncz + 3);
+        const dim3 rgrid((unsigned)((n + 63) / 64)), rblock(64);
+        if (dim == 3) {
+            RayGeom<T> rg;
+            rg.nnx = ncx + 1; rg.nny = ncy + 1; rg.nnz = ncz + 1;
+            rg.dx = dx; rg.xmin = xmin; rg.ymin = ymin; rg.zmin = zmin; rg.xmax = xmax; rg.ymax = ymax; rg.zmax = zmax;
+            rg.interp_vel = interp_vel;
+            fsm_raypath3d<T, false><<<rgrid, rblock, 0, stream>>>(d_tt.p, NS, d_s.p, rg, 0, d_rsrc.p, d_rt0.p, d_rx.p, (int)n, d_out.p,
+                                                                  d_rstat.p, max_steps, nullptr, 0, nullptr, d_rdesc.p, d_rslot.p);
+        } else {
+            RayGeom2<T> rg2;
+            rg2.nnx = ncx + 1; rg2.nnz = ncz + 1;
+            rg2.dx = dx; rg2.dz = dz; rg2.xmin = xmin; rg2.zmin = zmin; rg2.xmax = xmax; rg2.zmax = zmax;
+            const T* cell_s = cell ? d_cells.p : nullptr;
+            fsm_raypath2d<T, false><<<rgrid, rblock, 0, stream>>>(d_tt.p, NS, d_s.p, cell_s, rg2, 0, d_rsrc.p, d_rt0.p, d_rx.p, (int)n,
+                                                                  d_out.p, d_rstat.p, max_steps, nullptr, 0, nullptr, d_rdesc.p, d_rslot.p);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(o.data(), d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (size_t q = 0; q < n; ++q) {
+            if (st[q] == 0) continue;
+            std::ostringstream msg;
+            auto pt = [&](const T* v) { for (int c = 0; c < nc; ++c) msg << (c ? " " : "") << v[c]; };
+            if (st[q] == 1) {
+                msg << "Error while computing raypaths: going outside grid \n                Rx: ";
+                pt(p.data() + (size_t)nc * q);
+                msg << "\n                Tx: ";
+                pt(txb.data() + (size_t)nc * desc[so[q]].tx_off);
+                msg << "\n";
+            } else {
+                msg << "Error while computing raypaths: ray from Rx ";
+                pt(p.data() + (size_t)nc * q);
+                msg << " did not reach the source within " << max_steps << " steps";
+            }
+            throw std::runtime_error(msg.str());
+        }
+        k = 0;
+        for (size_t b = 0; b < sl.size(); ++b) {
+            const int m = rx_off[sr[b] + 1] - rx_off[sr[b]];
+            std::memcpy(tt_out + rx_off[sr[b]], o.data() + k, sizeof(T) * m);
+            k += m;
+        }
+    }
+
     // Grid3Drn::getTraveltimeFromRaypath for every receiver of one source (ttcr/Grid3D.h:493-496); with
     // `record`, Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) instead (ttcr/Grid3D.h:546-586): the rays are
     // appended to rays_off / rays_pts (shifted back by the origin of a translated grid, :579-584)
@@ -1099,6 +1182,10 @@ class GridT : public GridBase {
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
                 if (!(ttrp || return_rays)) {
                     interp_batch(sl, sr, rx_off, rx.data(), tt_out);
+                    continue;
+                }
+                if (!return_rays) {
+                    raypath_batch(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out);
                     continue;
                 }
                 for (size_t b = 0; b < sl.size(); ++b) {

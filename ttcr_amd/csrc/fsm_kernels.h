@@ -1826,6 +1826,12 @@ __global__ void fsm_interp3d_batch(const T* __restrict__ tt0, int ts, size_t n_n
 // operator grad (:1033-1100) on the trilinearly interpolated field, one grid plane per step,
 // trapezoidal integration of the interpolated slowness computeSlowness (:2451-2676).  One thread
 // per receiver; every expression keeps the reference's T1/double mix.
+// receivers of several sources in one launch: receiver r belongs to batch entry rx_src[r]
+struct RaySrc {
+    long long tt_off;  // offset of the source's field from the first field (elements)
+    int tx_off, n_tx;  // its points in src / t0
+};
+
 template <typename T>
 struct RayGeom {
     int nnx, nny, nnz;
@@ -1990,9 +1996,14 @@ template <typename T, bool RAYS>
 __global__ void fsm_raypath3d(const T* __restrict__ Tn, int ts, const T* __restrict__ sn, RayGeom<T> g, int n_src,
                               const T* __restrict__ src, const T* __restrict__ t0, const T* __restrict__ rcv, int n_rcv,
                               T* __restrict__ out, int* __restrict__ status, long max_steps, T* __restrict__ pts, long cap,
-                              int* __restrict__ npts) {
+                              int* __restrict__ npts, const RaySrc* __restrict__ batch = nullptr,
+                              const int* __restrict__ rx_src = nullptr) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rcv) return;
+    if (batch) {
+        const RaySrc b = batch[rx_src[r]];
+        Tn += b.tt_off; src += 3 * (size_t)b.tx_off; t0 += b.tx_off; n_src = b.n_tx;
+    }
     const T rx[3] = {rcv[3 * r], rcv[3 * r + 1], rcv[3 * r + 2]};
     status[r] = 0;
     long np = 0;
@@ -2198,9 +2209,14 @@ template <typename T, bool RAYS>
 __global__ void fsm_raypath2d(const T* __restrict__ Tn, int ts, const T* __restrict__ sn, const T* __restrict__ sc,
                               RayGeom2<T> g, int n_src, const T* __restrict__ src, const T* __restrict__ t0,
                               const T* __restrict__ rcv, int n_rcv, T* __restrict__ out, int* __restrict__ status,
-                              long max_steps, T* __restrict__ pts, long cap, int* __restrict__ npts) {
+                              long max_steps, T* __restrict__ pts, long cap, int* __restrict__ npts,
+                              const RaySrc* __restrict__ batch = nullptr, const int* __restrict__ rx_src = nullptr) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rcv) return;
+    if (batch) {
+        const RaySrc b = batch[rx_src[r]];
+        Tn += b.tt_off; src += 2 * (size_t)b.tx_off; t0 += b.tx_off; n_src = b.n_tx;
+    }
     const T rx[2] = {rcv[2 * r], rcv[2 * r + 1]};
     status[r] = 0;
     long np = 0;
