@@ -136,6 +136,7 @@ class GridT : public GridBase {
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
+    int weno_ch4_min = 8;  // slot groups from which the 3-D WENO stage uses chunks of 4 levels
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
     DevBuf<int> d_rstat;
@@ -263,6 +264,7 @@ class GridT : public GridBase {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fsm_sweep45_rows<T>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         if (const char* e = std::getenv("TTCR_FSM_SWEEP45")) sweep45_strips = std::string(e) == "strips";
+        if (const char* e = std::getenv("TTCR_FSM_WENO_CH4_MIN")) weno_ch4_min = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
     }
@@ -286,7 +288,7 @@ class GridT : public GridBase {
     template <int DIM, int H>
     void launch_sweeps_persistent(int batch) {
         constexpr int C0 = ChunkCfg<T, DIM>::C;
-        if (H == 2 && DIM == 3 && batch >= 8 && C0 == 8) {
+        if (H == 2 && DIM == 3 && batch >= weno_ch4_min && C0 == 8) {
             if (NS == 2) launch_sweeps_persistent_ns<DIM, H, 2, (H == 2 && DIM == 3) ? 4 : C0>(batch);
             else launch_sweeps_persistent_ns<DIM, H, 1, (H == 2 && DIM == 3) ? 4 : C0>(batch);
         } else {
