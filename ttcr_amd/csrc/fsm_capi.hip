@@ -944,6 +944,26 @@ class GridT : public GridBase {
         }
     }
 
+    // a walk that failed on the device -> the reference's exception (ttcr/Grid3Drn.h:1170-1181); status 2 is our
+    // step limit, where the reference would not return
+    [[noreturn]] void throw_walk_error(int st, const T* rx, const T* tx, long max_steps) const {
+        const int nc = ncoord();
+        std::ostringstream msg;
+        auto pt = [&](const T* v) { for (int c = 0; c < nc; ++c) msg << (c ? " " : "") << v[c]; };
+        if (st == 1) {
+            msg << "Error while computing raypaths: going outside grid \n                Rx: ";
+            pt(rx);
+            msg << "\n                Tx: ";
+            pt(tx);
+            msg << "\n";
+        } else {
+            msg << "Error while computing raypaths: ray from Rx ";
+            pt(rx);
+            msg << " did not reach the source within " << max_steps << " steps";
+        }
+        throw std::runtime_error(msg.str());
+    }
+
     // getTraveltimeFromRaypath for the receivers of every source of a batch in ONE launch (one thread per receiver:
     // a single source's few hundred receivers leave the device empty); errors as in raypath_grid_coords
     void raypath_batch(const std::vector<int>& sl, const std::vector<int>& sr, const int* tx_off, const T* tx, const T* t0,
@@ -1001,23 +1021,8 @@ class GridT : public GridBase {
         HIP_CHECK(hipMemcpyAsync(o.data(), d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        for (size_t q = 0; q < n; ++q) {
-            if (st[q] == 0) continue;
-            std::ostringstream msg;
-            auto pt = [&](const T* v) { for (int c = 0; c < nc; ++c) msg << (c ? " " : "") << v[c]; };
-            if (st[q] == 1) {
-                msg << "Error while computing raypaths: going outside grid \n                Rx: ";
-                pt(p.data() + (size_t)nc * q);
-                msg << "\n                Tx: ";
-                pt(txb.data() + (size_t)nc * desc[so[q]].tx_off);
-                msg << "\n";
-            } else {
-                msg << "Error while computing raypaths: ray from Rx ";
-                pt(p.data() + (size_t)nc * q);
-                msg << " did not reach the source within " << max_steps << " steps";
-            }
-            throw std::runtime_error(msg.str());
-        }
+        for (size_t q = 0; q < n; ++q)
+            if (st[q] != 0) throw_walk_error(st[q], p.data() + (size_t)nc * q, txb.data() + (size_t)nc * desc[so[q]].tx_off, max_steps);
         k = 0;
         for (size_t b = 0; b < sl.size(); ++b) {
             const int m = rx_off[sr[b] + 1] - rx_off[sr[b]];
@@ -1080,23 +1085,8 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
             if (record) HIP_CHECK(hipMemcpyAsync(np.data(), d_raynp.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
-            for (int q = 0; q < m; ++q) {
-                if (st[q] == 0) continue;
-                std::ostringstream msg;
-                auto pt = [&](const T* v) { for (int c = 0; c < nc; ++c) msg << (c ? " " : "") << v[c]; };
-                if (st[q] == 1) {
-                    msg << "Error while computing raypaths: going outside grid \n                Rx: ";
-                    pt(pc + (size_t)nc * q);
-                    msg << "\n                Tx: ";
-                    pt(txp);
-                    msg << "\n";
-                } else {
-                    msg << "Error while computing raypaths: ray from Rx ";
-                    pt(pc + (size_t)nc * q);
-                    msg << " did not reach the source within " << max_steps << " steps";
-                }
-                throw std::runtime_error(msg.str());
-            }
+            for (int q = 0; q < m; ++q)
+                if (st[q] != 0) throw_walk_error(st[q], pc + (size_t)nc * q, txp, max_steps);
             if (record) {
                 off[0] = 0;
                 for (int q = 0; q < m; ++q) off[q + 1] = off[q] + np[q];
