@@ -522,7 +522,13 @@ static REAL SFX(slowness_at3d)(const SFX(fsm_grid3d) * g, const REAL* sn, REAL p
         if (FABS(py - (ymin + n * dy)) < FSM_SMALL2) { onY = (ptrdiff_t)n; break; }
     for (size_t n = 0; n < nnz; ++n)
         if (FABS(pz - (zmin + n * dz)) < FSM_SMALL2) { onZ = (ptrdiff_t)n; break; }
-#define SN(ii, jj, kk) (iv ? (REAL)(1.0 / sn[((size_t)(kk) * nny + (jj)) * nnx + (ii)]) : sn[((size_t)(kk) * nny + (jj)) * nnx + (ii)])
+/* The reference takes the cell index as (T2)(small + (p - min)/d) with small = 1e-4 but calls a point "on" a plane
+ * only within small^2: a point closer than 1e-4 cell to the LAST plane of an axis, yet not on it, gets the cell
+ * beyond the grid and the reference reads one node past its array there (heap garbage: its result is not
+ * reproducible).  Restated in range: such an index is clamped to the last node.  In-range indices are untouched. */
+#define SN_CL(v, n) ((size_t)(v) < (size_t)(n) ? (size_t)(v) : (size_t)(n) - 1)
+#define SN_AT(ii, jj, kk) sn[(SN_CL(kk, nnz) * nny + SN_CL(jj, nny)) * nnx + SN_CL(ii, nnx)]
+#define SN(ii, jj, kk) (iv ? (REAL)(1.0 / SN_AT(ii, jj, kk)) : SN_AT(ii, jj, kk))
 #define RET(v) return iv ? (REAL)(1.0 / (v)) : (v)
     REAL s[8], x[3], y[3], z[3];
     if (onX != -1 && onY != -1 && onZ != -1) {

@@ -439,3 +439,27 @@ def test_hip_raypath_traveltimes_of_a_batch(oracle, dt, n_threads):
         o = oracle.solve2d(dt, nc, 0.25, 0.25, (0, 0), s2.ravel(), [p[1:]], [p[0]], cell_slowness=True, rcv=rcv2, weno=True,
                            tt_from_rp=True)
         np.testing.assert_array_equal(tt2[len(rcv2) * n:len(rcv2) * (n + 1)], o["tt_rcv"], err_msg="2d %d" % n)
+
+
+def test_hip_receiver_near_the_last_plane_of_an_axis(oracle):
+    """tests/golden/edge_receiver_case.npz (found by a long fuzz run): a ray point 6.6e-5 cell below the z-max face gets
+    the cell index BEYOND the grid from the reference's (T2)(small + (p - min)/d) and the reference reads one node
+    past its slowness array there (its own result changes from run to run).  Oracle and kernel clamp that index to
+    the last node; everything in range is untouched.  Field, rays and traveltimes must agree bit for bit."""
+    import os
+
+    import ttcr_amd
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "edge_receiver_case.npz"))
+    s, src, t0, rcv = d["s"], d["src"], d["t0"], d["rcv"]
+    dx, org, nc = float(d["dx"]), tuple(d["org"]), tuple(int(v) for v in d["nc"])
+    axes = [o + np.arange(n + 1) * dx for o, n in zip(org, nc)]
+    o = oracle.solve3d(np.float64, nc, dx, org, s.flatten("F"), src, t0, return_rays=True, cell_slowness=False, rcv=rcv,
+                       weno=True)
+    g = ttcr_amd.Grid3d(*axes, cell_slowness=False, method="FSM", tt_from_rp=0, weno=1, dtype=np.float64)
+    tt, rays = g.raytrace(np.hstack([t0[:, None], src]), rcv, slowness=s, aggregate_src=True, return_rays=True)
+    np.testing.assert_array_equal(g.get_grid_traveltimes().flatten("F"), o["tt"])
+    np.testing.assert_array_equal(tt, o["tt_rcv"])
+    for a, b in zip(rays, o["rays"]):
+        np.testing.assert_array_equal(a, b)
+    assert abs(tt[0] - 9.245927) < 2e-6      # plain trilinear trapezoid along the same ray

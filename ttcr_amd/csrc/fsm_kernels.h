@@ -1860,7 +1860,12 @@ __device__ T slowness_at3d(const RayGeom<T>& g, const T* __restrict__ sn, T px, 
     const double small = 1.e-4;
     const int iv = g.interp_vel;
     const int onX = on_node(px, xmin, dx, g.nnx), onY = on_node(py, ymin, dy, g.nny), onZ = on_node(pz, zmin, dz, g.nnz);
+    // (an index one past the last node -- the reference's cell index of a point within 1e-4 cell below the last
+    // plane of an axis, where it reads past its array -- is clamped to the last node; see the oracle's SN)
     auto SN = [&](unsigned i, unsigned j, unsigned k) {
+        i = i < (unsigned)g.nnx ? i : (unsigned)g.nnx - 1;
+        j = j < (unsigned)g.nny ? j : (unsigned)g.nny - 1;
+        k = k < (unsigned)g.nnz ? k : (unsigned)g.nnz - 1;
         const T v = sn[((size_t)k * nny + j) * nnx + i];
         return iv ? (T)(1.0 / (double)v) : v;
     };
