@@ -17,6 +17,11 @@
  *     TTCR_F64 <-> <double,uint32_t>; all `const void*` arrays hold that type.
  *   - a "slot" is the reference's threadNo: a private traveltime field kept on the
  *     device until the next solve in the same slot (ttcr/Node3Dn.h:109-110).
+ *   - threads: every entry point that takes a grid locks that grid (one stream, one captured launch
+ *     sequence and the pinned / scratch buffers are shared by its slots), so calls on ONE handle from several
+ *     host threads -- ttcrpy's raytrace(..., thread_no=k) pattern -- are safe and run one after the other;
+ *     sources that should run side by side on the device go into one ttcr_fsm_raytrace_multi call.  Different
+ *     handles are independent.  ttcr_fsm_last_error() is per host thread.
  */
 #ifndef TTCR_AMD_H
 #define TTCR_AMD_H
@@ -103,8 +108,16 @@ int ttcr_fsm_raytrace_multi(ttcr_fsm_grid* g, int n_src, const int* tx_off, cons
 
 /* Replaces: Grid3Drn::getTT(tt, threadNo) (ttcr/Grid3Drn.h:102-108). n = node count. */
 int ttcr_fsm_get_tt(ttcr_fsm_grid* g, int slot, void* out, size_t n);
-/* Device pointer of a slot's traveltime field (stays owned by the grid). */
+/* The same field for a consumer on the device (no reference equivalent; the reference only has the host copy above).
+ * ttcr_fsm_get_tt_device: pointer to n_nodes CONTIGUOUS values of slot `slot` in the flat order above.  With one
+ *   slot this is the field itself; with n_slots >= 2 the fields of two slots are interleaved in HBM, so the call
+ *   de-interleaves into a scratch buffer of the grid: the pointer stays valid until the next ttcr_fsm_get_tt /
+ *   ttcr_fsm_get_tt_device call or the destruction of the grid.
+ * ttcr_fsm_get_tt_device_view: zero copy.  *d_ptr addresses node 0 of the slot's field where it lies and *stride is
+ *   the distance between consecutive nodes in ELEMENTS of the grid dtype (1 with one slot, 2 with n_slots >= 2:
+ *   layout T[slot/2][node][2]); valid until the next raytrace call on that slot.  Both stay owned by the grid. */
 int ttcr_fsm_get_tt_device(ttcr_fsm_grid* g, int slot, void** d_ptr);
+int ttcr_fsm_get_tt_device_view(ttcr_fsm_grid* g, int slot, void** d_ptr, size_t* stride);
 
 /* Replaces: Grid3Drn::getTraveltime(pt, nt) (ttcr/Grid3Drn.h:794-930) / 2-D (:359-414). */
 int ttcr_fsm_interp(ttcr_fsm_grid* g, int slot, int n_pts, const void* pts, void* tt_out);

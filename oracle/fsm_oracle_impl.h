@@ -423,7 +423,7 @@ int SFX(fsm_solve3d)(const SFX(fsm_grid3d) * g, const REAL* s, int n_src, const 
 /* Grid3Drn::getIJK (ttcr/Grid3Drn.h:233-237) + getTraveltime (:794-930):
  * node value / linear / bilinear / trilinear interpolation at a receiver. */
 REAL SFX(fsm_interp3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL px, REAL py, REAL pz) {
-    const size_t nnx = g->nnx, nny = g->nny;
+    const size_t nnx = g->nnx, nny = g->nny, nnz = g->nnz;
     const REAL xmin = g->xmin, ymin = g->ymin, zmin = g->zmin, dx = g->dx, dy = g->dx, dz = g->dx;
     const uint32_t i = (uint32_t)(FSM_SMALL2 + (px - xmin) / dx);
     const uint32_t j = (uint32_t)(FSM_SMALL2 + (py - ymin) / dy);
@@ -431,7 +431,13 @@ REAL SFX(fsm_interp3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL px, REAL p
     const int onx = FABS(px - (xmin + i * dx)) < FSM_SMALL2;
     const int ony = FABS(py - (ymin + j * dy)) < FSM_SMALL2;
     const int onz = FABS(pz - (zmin + k * dz)) < FSM_SMALL2;
-#define TT(ii, jj, kk) T[((size_t)(kk) * nny + (jj)) * nnx + (ii)]
+/* The index is a quotient rounded in REAL plus 1e-8, "on the plane" an ABSOLUTE distance below 1e-8: a point a
+ * rounding error below the last plane of an axis (or further away than 1e-8 when dx > 1) gets the last node as
+ * its lower index without counting as on the plane, and the reference then reads node index+1 -- past the row,
+ * or past the array in the last plane.  Such an index is clamped to the last node here (and in the kernel); its
+ * weight is the distance to the lower plane, ~0.  Indices in range are untouched. */
+#define TT_CL(v, n) ((size_t)(v) < (n) ? (size_t)(v) : (n) - 1)
+#define TT(ii, jj, kk) T[(TT_CL(kk, nnz) * nny + TT_CL(jj, nny)) * nnx + TT_CL(ii, nnx)]
     REAL tt;
     if (onx && ony && onz) {
         return TT(i, j, k);
@@ -489,6 +495,7 @@ REAL SFX(fsm_interp3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL px, REAL p
         tt = t1 * w1 + t2 * w2;
     }
 #undef TT
+#undef TT_CL
     return tt;
 }
 
@@ -1098,26 +1105,31 @@ int SFX(fsm_solve2d)(const SFX(fsm_grid2d) * g, const REAL* s, int n_src, const 
 
 /* Grid2Drn::getIJ (ttcr/Grid2Drn.h:186-189) + getTraveltime (:359-414) */
 REAL SFX(fsm_interp2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL pz) {
-    const size_t nnz = g->nnz;
+    const size_t nnx = g->nnx, nnz = g->nnz;
     const REAL xmin = g->xmin, zmin = g->zmin, dx = g->dx, dz = g->dz;
     const uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
     const uint32_t j = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
     const int onx = FABS(px - (xmin + i * dx)) < FSM_SMALL;
     const int onz = FABS(pz - (zmin + j * dz)) < FSM_SMALL;
+/* index = quotient + 1e-4 (in cells), "on the line" = ABSOLUTE distance below 1e-4: with dx > 1 a point between
+ * 1e-4 and 1e-4*dx below the last line of an axis gets the last node as lower index, is not "on" it, and the
+ * reference reads index+1 (the next column, or past the array).  Clamped to the last node as in 3-D. */
+#define T2_CL(v, n) ((size_t)(v) < (n) ? (size_t)(v) : (n) - 1)
+#define T2(ii, jj) T[T2_CL(ii, nnx) * nnz + T2_CL(jj, nnz)]
     REAL tt;
     if (onx && onz) {
-        return T[(size_t)i * nnz + j];
+        return T2(i, j);
     } else if (onx) {
-        REAL t1 = T[(size_t)i * nnz + j], t2 = T[(size_t)i * nnz + j + 1];
+        REAL t1 = T2(i, j), t2 = T2(i, j + 1);
         REAL w1 = (zmin + (j + 1) * dz - pz) / dz, w2 = (pz - (zmin + j * dz)) / dz;
         tt = t1 * w1 + t2 * w2;
     } else if (onz) {
-        REAL t1 = T[(size_t)i * nnz + j], t2 = T[(size_t)(i + 1) * nnz + j];
+        REAL t1 = T2(i, j), t2 = T2(i + 1, j);
         REAL w1 = (xmin + (i + 1) * dx - px) / dx, w2 = (px - (xmin + i * dx)) / dx;
         tt = t1 * w1 + t2 * w2;
     } else {
-        REAL t1 = T[(size_t)i * nnz + j], t2 = T[(size_t)(i + 1) * nnz + j];
-        REAL t3 = T[(size_t)i * nnz + j + 1], t4 = T[(size_t)(i + 1) * nnz + j + 1];
+        REAL t1 = T2(i, j), t2 = T2(i + 1, j);
+        REAL t3 = T2(i, j + 1), t4 = T2(i + 1, j + 1);
         REAL w1 = (xmin + (i + 1) * dx - px) / dx, w2 = (px - (xmin + i * dx)) / dx;
         t1 = t1 * w1 + t2 * w2;
         t2 = t3 * w1 + t4 * w2;
@@ -1125,6 +1137,8 @@ REAL SFX(fsm_interp2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL p
         w2 = (pz - (zmin + j * dz)) / dz;
         tt = t1 * w1 + t2 * w2;
     }
+#undef T2
+#undef T2_CL
     return tt;
 }
 
@@ -1155,8 +1169,12 @@ static void SFX(grad2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL 
 static uint32_t SFX(cellno2d)(const SFX(fsm_grid2d) * g, REAL px, REAL pz) {
     const REAL x = g->xmax - px < FSM_SMALL ? (REAL)(g->xmax - .5 * g->dx) : px;
     const REAL z = g->zmax - pz < FSM_SMALL ? (REAL)(g->zmax - .5 * g->dz) : pz;
-    const uint32_t nx = (uint32_t)(FSM_SMALL + (x - g->xmin) / g->dx);
-    const uint32_t nz = (uint32_t)(FSM_SMALL + (z - g->zmin) / g->dz);
+    uint32_t nx = (uint32_t)(FSM_SMALL + (x - g->xmin) / g->dx);
+    uint32_t nz = (uint32_t)(FSM_SMALL + (z - g->zmin) / g->dz);
+    /* (xmax - px < small is an absolute test, the index a relative one: with dx > 1 a point between 1e-4 and
+     * 1e-4*dx below xmax gets the cell past the last one and the reference reads past its cell array: clamped) */
+    if (nx > (uint32_t)(g->nnx - 2)) nx = (uint32_t)(g->nnx - 2);
+    if (nz > (uint32_t)(g->nnz - 2)) nz = (uint32_t)(g->nnz - 2);
     return nx * (uint32_t)(g->nnz - 1) + nz;
 }
 

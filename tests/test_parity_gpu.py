@@ -463,3 +463,163 @@ def test_hip_receiver_near_the_last_plane_of_an_axis(oracle):
     for a, b in zip(rays, o["rays"]):
         np.testing.assert_array_equal(a, b)
     assert abs(tt[0] - 9.245927) < 2e-6      # plain trilinear trapezoid along the same ray
+
+
+@pytest.mark.parametrize("n_threads", [1, 2, 3])
+def test_hip_raypaths_more_sources_than_slots(oracle, n_threads):
+    """return_rays with MORE sources than slots and unequal receiver counts: the solve order is round-major
+    (n_threads=2, 3 sources: 0, 2, 1), the rays must still come back one per receiver row, in row order."""
+    import ttcr_amd
+
+    n = 21
+    x = np.arange(n) * 0.5
+    s = np.ascontiguousarray(np.broadcast_to((1.0 / (1.0 + 0.1 * x))[None, None, :], (n, n, n)))
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=n_threads, cell_slowness=0, method="FSM", tt_from_rp=1, weno=1)
+    src = np.array([[1.0, 1.0, 1.0], [9.2, 3.3, 7.1], [5.0, 8.5, 2.2], [2.4, 7.9, 6.1], [7.7, 2.3, 4.4]])
+    rcv = np.array([[9.0, 9.0, 2.0], [3.0, 9.5, 8.0], [6.0, 6.0, 9.5], [0.5, 0.25, 7.75]])
+    # source n gets 1 + (n % 4) receivers, rows shuffled so that the rows of a source are not contiguous
+    rows = [(n_, k) for n_ in range(len(src)) for k in range(1 + n_ % 4)]
+    rng = np.random.default_rng(17)
+    rows = [rows[i] for i in rng.permutation(len(rows))]
+    srows = np.array([src[a] for a, _ in rows])
+    rrows = np.array([rcv[b] for _, b in rows])
+    tt, rays = g.raytrace(srows, rrows, slowness=s, return_rays=True)
+    assert len(rays) == len(rows)
+    for k in range(len(rows)):
+        r = oracle.solve3d(np.float64, (n - 1,) * 3, 0.5, (0, 0, 0), s.flatten("F"), [srows[k]], rcv=[rrows[k]], weno=True,
+                           return_rays=True)
+        np.testing.assert_array_equal(rays[k], r["rays"][0], err_msg=f"row {k} (source {rows[k][0]})")
+        assert tt[k] == r["tt_rcv"][0]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hip_receivers_next_to_the_last_planes(oracle, dt):
+    """getTraveltime at receivers a rounding error / a fraction of 1e-4 cell below the last plane of every axis, dx > 1
+    and dx not a power of two: the reference's index (rounded quotient + small) reaches the last node there while its
+    absolute on-plane test fails, and it reads node index+1.  Oracle and kernel clamp that read to the last node
+    (values in range untouched); both must agree bit for bit, in 3-D and in 2-D (cell grid: getCellNo as well)."""
+    import ttcr_amd
+
+    rng = np.random.default_rng(23)
+    nn, dx = (9, 8, 7), 2.3
+    axes = [np.arange(m) * dx for m in nn]
+    hi = np.array([a[-1] for a in axes], dtype=dt)
+    s = rng.uniform(0.3, 1.0, nn)
+    pts = [hi.copy()]
+    for ax in range(3):
+        for back in (1, 2, 40, 400):
+            p = hi.copy()
+            for _ in range(back):
+                p[ax] = np.nextafter(p[ax], dt(0))
+            pts.append(p.copy())
+            q = p.copy()
+            q[(ax + 1) % 3] = dt(0.37 * hi[(ax + 1) % 3])
+            pts.append(q)
+    p = hi.copy()
+    p -= dt(1.5e-4)
+    pts.append(p)
+    rcv = np.array(pts, dtype=np.float64)
+    src = np.array([[2.0, 3.0, 1.5]])
+    g = ttcr_amd.Grid3d(*axes, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    tt = g.raytrace(src, rcv, slowness=s)
+    o = oracle.solve3d(dt, tuple(m - 1 for m in nn), dx, (0, 0, 0), s.flatten("F"), src, rcv=rcv)
+    np.testing.assert_array_equal(g._flat_tt(0), o["tt"])
+    np.testing.assert_array_equal(tt, o["tt_rcv"])
+    assert np.all(np.isfinite(tt))
+    # 2-D, node grid with interpolation and cell grid with raypath traveltimes (getCellNo at segment mid-points)
+    nn2, dx2, dz2 = (12, 10), 2.3, 3.1
+    x2, z2 = np.arange(nn2[0]) * dx2, np.arange(nn2[1]) * dz2
+    hi2 = np.array([x2[-1], z2[-1]], dtype=dt)
+    pts2 = [hi2.copy()]
+    for ax in range(2):
+        for back in (1, 3, 60, 500):
+            p = hi2.copy()
+            for _ in range(back):
+                p[ax] = np.nextafter(p[ax], dt(0))
+            pts2.append(p.copy())
+            q = p.copy()
+            q[1 - ax] = dt(0.41 * hi2[1 - ax])
+            pts2.append(q)
+    pts2.append(hi2 - dt(1.7e-4))
+    rcv2 = np.array(pts2, dtype=np.float64)
+    src2 = np.array([[3.0, 4.0]])
+    s2 = rng.uniform(0.3, 1.0, nn2)
+    g2 = ttcr_amd.Grid2d(x2, z2, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    tt2 = g2.raytrace(src2, rcv2, slowness=s2)
+    o2 = oracle.solve2d(dt, (nn2[0] - 1, nn2[1] - 1), dx2, dz2, (0, 0), s2.ravel(), src2, rcv=rcv2)
+    np.testing.assert_array_equal(tt2, o2["tt_rcv"])
+    sc = 1.0 / (1.0 + 0.05 * np.arange(nn2[1] - 1))
+    sc2 = np.ascontiguousarray(np.broadcast_to(sc[None, :], (nn2[0] - 1, nn2[1] - 1)))
+    g3 = ttcr_amd.Grid2d(x2, z2, cell_slowness=1, method="FSM", tt_from_rp=1, weno=0, dtype=dt)
+    tt3 = g3.raytrace(src2, rcv2, slowness=sc2)
+    o3 = oracle.solve2d(dt, (nn2[0] - 1, nn2[1] - 1), dx2, dz2, (0, 0), sc2.ravel(), src2, rcv=rcv2, cell_slowness=True,
+                        tt_from_rp=True)
+    np.testing.assert_array_equal(tt3, o3["tt_rcv"])
+
+
+def test_hip_one_grid_from_several_host_threads(oracle):
+    """ttcrpy's raytrace(..., thread_no=k) pattern: several host threads, one grid, one slot each.  Calls on one handle
+    are serialised by the library (ttcr_amd.h); every thread must get its own source's field and receiver values."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import ttcr_amd
+
+    n = 40
+    x = np.arange(n) * 0.5
+    rng = np.random.default_rng(31)
+    s = rng.uniform(0.3, 1.0, (n, n, n))
+    nthr = 6
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32)
+    g.set_slowness(s)
+    srcs = rng.uniform(0.5, 19.0, (nthr, 3))
+    rcv = rng.uniform(0.0, 19.5, (7, 3))
+
+    def work(k):
+        out = []
+        for _ in range(3):
+            tt = g.raytrace(srcs[k:k + 1], rcv, thread_no=k)
+            out.append((tt, g._flat_tt(k), g.get_niter(k)))
+        return out
+
+    with ThreadPoolExecutor(max_workers=nthr) as ex:
+        res = list(ex.map(work, range(nthr)))
+    for k in range(nthr):
+        o = oracle.solve3d(np.float32, (n - 1,) * 3, 0.5, (0, 0, 0), s.astype(np.float32).flatten("F"), srcs[k:k + 1], rcv=rcv)
+        for tt, field, niter in res[k]:
+            np.testing.assert_array_equal(field, o["tt"])
+            np.testing.assert_array_equal(tt, o["tt_rcv"])
+            assert niter == o["niter"]
+
+
+def test_hip_device_views_of_a_field():
+    """ttcr_fsm_get_tt_device: n_nodes contiguous values; ttcr_fsm_get_tt_device_view: the field where it lies + stride
+    (2 with n_threads >= 2: interleaved pairs).  Both read back through torch from the raw device pointers."""
+    import ctypes as C
+
+    import torch
+
+    import ttcr_amd
+
+    n = 20
+    x = np.arange(n) * 0.5
+    rng = np.random.default_rng(37)
+    s = rng.uniform(0.3, 1.0, (n, n, n))
+    for nthr, want_stride in ((1, 1), (3, 2)):
+        g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32)
+        srcs = rng.uniform(0.5, 9.0, (nthr, 3))
+        g.raytrace(srcs, np.zeros((nthr, 3)), slowness=s)
+        nn = g.get_number_of_nodes()
+        for slot in range(nthr):
+            want = g._flat_tt(slot)
+            ptr, stride = g.tt_device_view(slot)
+            assert stride == want_stride
+            buf = torch.empty(nn * stride, dtype=torch.float32, device="cuda")
+            # device-to-device copy of the strided view through HIP (torch owns the destination)
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(buf.data_ptr(), ptr, (nn - 1) * stride * 4 + 4, 3) == 0
+            np.testing.assert_array_equal(buf.cpu().numpy()[::stride][:nn], want)
+            cptr = g.tt_device_ptr(slot)
+            buf2 = torch.empty(nn, dtype=torch.float32, device="cuda")
+            assert hip.hipMemcpy(buf2.data_ptr(), cptr, nn * 4, 3) == 0
+            np.testing.assert_array_equal(buf2.cpu().numpy(), want)

@@ -40,6 +40,7 @@ SYMBOLS = {
     "ttcr_fsm_raytrace_multi": (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
     "ttcr_fsm_get_tt": (_I, [_P, _I, _P, C.c_size_t]),
     "ttcr_fsm_get_tt_device": (_I, [_P, _I, C.POINTER(_P)]),
+    "ttcr_fsm_get_tt_device_view": (_I, [_P, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "ttcr_fsm_interp": (_I, [_P, _I, _I, _P, _P]),
     "ttcr_fsm_get_niter": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ttcr_fsm_n_slots": (_I, [_P]),

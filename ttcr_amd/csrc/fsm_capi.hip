@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -80,7 +81,9 @@ class GridBase {
     virtual void raytrace_multi(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
                                 const void* rx, void* tt_out, int forced_slot) = 0;
     virtual void get_tt(int slot, void* out, size_t n) = 0;
-    virtual void* tt_device(int slot) = 0;
+    virtual void* tt_device(int slot) = 0;                      // contiguous copy of the field (see ttcr_amd.h)
+    virtual void* tt_device_view(int slot, size_t* stride) = 0;  // the field where it lies + its element stride
+    std::mutex mu;  // one call at a time per handle: stream, graph capture, pinned and scratch buffers are shared
     virtual void interp(int slot, int n, const void* pts, void* out) = 0;
     virtual void rays_size(size_t* n_rays, size_t* n_points) const = 0;
     virtual void get_rays(long long* offsets, void* pts) const = 0;
@@ -149,6 +152,7 @@ class GridT : public GridBase {
     std::vector<int> tile_off, tile_cnt;  // offsets / counts into d_tiles
     DevBuf<double> d_change;
     DevBuf<unsigned long long> d_prof;  // TTCR_FSM_PROF=1 debug phase timers
+    size_t prof_words = 0;
     DevBuf<uint32_t> d_order;  // persistent kernel: patches in ticket order (anti-diagonal major)
     DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
     int n_patches = 0;
@@ -221,9 +225,10 @@ class GridT : public GridBase {
         d_lmask.reserve(n_slots);
         HIP_CHECK(hipHostMalloc((void**)&h_lmask, sizeof(int) * n_slots));
         d_change.reserve(n_slots);
-        if (std::getenv("TTCR_FSM_PROF")) {
-            d_prof.reserve(8);
-            HIP_CHECK(hipMemset(d_prof.p, 0, 8 * sizeof(unsigned long long)));
+        if (std::getenv("TTCR_FSM_PROF")) {   // FSM_ENABLE_PROF builds: 8 phase sums + a 4-word trace entry per work unit
+            prof_words = 8 + 4 * (size_t)(1 << 20);
+            d_prof.reserve(prof_words);
+            HIP_CHECK(hipMemset(d_prof.p, 0, prof_words * sizeof(unsigned long long)));
         }
         HIP_CHECK(hipHostMalloc((void**)&h_change, sizeof(double) * n_slots));
         HIP_CHECK(hipHostMalloc((void**)&h_slots, sizeof(int) * n_slots));
@@ -489,8 +494,22 @@ class GridT : public GridBase {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
+    // The fields of a slot group are interleaved (T[group][node][NS]): a consumer that wants n_nodes contiguous
+    // values gets a de-interleaved copy in a scratch buffer of the grid; the zero-copy view comes with its stride.
     void* tt_device(int slot) override {
+        HIP_CHECK(hipSetDevice(device));
         check_slot(slot);
+        if (NS == 1) return tt_ptr(slot);
+        d_gather.reserve(n_nodes);
+        const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
+        fsm_gather_field<T><<<blocks, 256, 0, stream>>>(tt_ptr(slot), d_gather.p, n_nodes, NS);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return d_gather.p;
+    }
+    void* tt_device_view(int slot, size_t* stride) override {
+        check_slot(slot);
+        if (stride) *stride = (size_t)NS;
         return tt_ptr(slot);
     }
 
@@ -727,6 +746,7 @@ class GridT : public GridBase {
                      const T* tx, const T* t0) {
         const int nb = (int)slot_ids.size();
         const int nc = ncoord();
+        const long long node_updates_before = timing.node_updates;
         // reinit + initFSM (ttcr/Grid3Drnfs.h:92-100)
         size_t tot_pts = 0;
         for (int b = 0; b < nb; ++b) tot_pts += tx_off[src_ids[b] + 1] - tx_off[src_ids[b]];
@@ -855,11 +875,17 @@ class GridT : public GridBase {
         if (d_prof.p) {
             unsigned long long h[8];
             HIP_CHECK(hipMemcpy(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost));
+            if (const char* tp = std::getenv("TTCR_FSM_PROF_TRACE")) {   // unit trace of the last iteration -> file
+                std::vector<unsigned long long> tr(prof_words);
+                HIP_CHECK(hipMemcpy(tr.data(), d_prof.p, prof_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (FILE* f = std::fopen(tp, "wb")) { std::fwrite(tr.data() + 8, sizeof(unsigned long long), prof_words - 8, f); std::fclose(f); }
+            }
             HIP_CHECK(hipMemset(d_prof.p, 0, sizeof(h)));
             if (mode >= 1) {
-                const double nb_ = (double)std::max<unsigned long long>(h[7], 1);
-                std::fprintf(stderr, "[ttcr_amd prof] chunks %llu  per chunk (us): issue %.2f  wait %.2f  stage %.2f  march %.2f  publish %.2f\n",
-                             h[7], h[0] * 0.01 / nb_, h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_, h[4] * 0.01 / nb_);
+                const double nb_ = (double)std::max<unsigned long long>(h[7], 1), nu_ = (double)std::max<unsigned long long>(h[6], 1);
+                std::fprintf(stderr, "[ttcr_amd prof] units %llu chunks %llu  per unit (us): start %.2f total %.2f | per chunk (us): top %.3f  wait %.3f  stage %.3f  march %.3f  writeback %.3f\n",
+                             h[6], h[7], h[5] * 0.01 / nu_, (h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) * 0.01 / nu_, h[0] * 0.01 / nb_,
+                             h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_, h[4] * 0.01 / nb_);
             } else {
                 const double nb_ = (double)std::max<unsigned long long>(h[4], 1);
                 std::fprintf(stderr, "[ttcr_amd prof] tiles %llu  per tile (us): setup %.2f  stage %.2f  march %.2f  writeback %.2f\n",
@@ -873,7 +899,7 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemcpy(h_evals, d_evals.p, sizeof(unsigned long long) * n_slots, hipMemcpyDeviceToHost));
             for (int s2 : slot_ids) timing.evaluated_updates += (long long)h_evals[s2];
         } else {
-            timing.evaluated_updates = timing.node_updates;
+            timing.evaluated_updates += timing.node_updates - node_updates_before;   // every update is evaluated
         }
     }
 
@@ -898,9 +924,9 @@ class GridT : public GridBase {
         const T* tt = tt_ptr(slot);
         const int blocks = (n + 127) / 128;
         if (dim == 3)
-            fsm_interp3d<T><<<blocks, 128, 0, stream>>>(tt, NS, d_rx.p, d_out.p, n, (int)ncx + 1, (int)ncy + 1, dx, xmin, ymin, zmin);
+            fsm_interp3d<T><<<blocks, 128, 0, stream>>>(tt, NS, d_rx.p, d_out.p, n, (int)ncx + 1, (int)ncy + 1, (int)ncz + 1, dx, xmin, ymin, zmin);
         else
-            fsm_interp2d<T><<<blocks, 128, 0, stream>>>(tt, NS, d_rx.p, d_out.p, n, (int)ncz + 1, dx, dz, xmin, zmin);
+            fsm_interp2d<T><<<blocks, 128, 0, stream>>>(tt, NS, d_rx.p, d_out.p, n, (int)ncx + 1, (int)ncz + 1, dx, dz, xmin, zmin);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -929,9 +955,9 @@ class GridT : public GridBase {
         const int blocks = (int)((n + 127) / 128);
         if (dim == 3)
             fsm_interp3d_batch<T><<<blocks, 128, 0, stream>>>(d_tt.p, NS, n_nodes, d_rslot.p, d_rx.p, d_out.p, (int)n, (int)ncx + 1,
-                                                              (int)ncy + 1, dx, xmin, ymin, zmin);
+                                                              (int)ncy + 1, (int)ncz + 1, dx, xmin, ymin, zmin);
         else
-            fsm_interp2d_batch<T><<<blocks, 128, 0, stream>>>(d_tt.p, NS, n_nodes, d_rslot.p, d_rx.p, d_out.p, (int)n, (int)ncz + 1, dx,
+            fsm_interp2d_batch<T><<<blocks, 128, 0, stream>>>(d_tt.p, NS, n_nodes, d_rslot.p, d_rx.p, d_out.p, (int)n, (int)ncx + 1, (int)ncz + 1, dx,
                                                               dz, xmin, zmin);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(o.data(), d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
@@ -1034,7 +1060,8 @@ class GridT : public GridBase {
     // Grid3Drn::getTraveltimeFromRaypath for every receiver of one source (ttcr/Grid3D.h:493-496); with
     // `record`, Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) instead (ttcr/Grid3D.h:546-586): the rays are
     // appended to rays_off / rays_pts (shifted back by the origin of a translated grid, :579-584)
-    void raypath_grid_coords(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out, bool record) {
+    void raypath_grid_coords(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out, bool record,
+                             std::vector<long long>* ray_len = nullptr, std::vector<T>* ray_pts = nullptr) {
         if (n <= 0) return;
         const int nc = ncoord();   // 3-D: Grid3Drn::getRaypath family; 2-D: Grid2Drn (ttcr/Grid2Drn.h:1478-1850)
         d_rsrc.reserve((size_t)nc * n_tx);
@@ -1100,12 +1127,13 @@ class GridT : public GridBase {
                 else
                     fsm_compact_rays2<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p);
                 HIP_CHECK(hipGetLastError());
-                const size_t base = rays_pts.size();
-                rays_pts.resize(base + (size_t)tot * nc);
-                HIP_CHECK(hipMemcpyAsync(rays_pts.data() + base, d_raydense.p, sizeof(T) * nc * tot, hipMemcpyDeviceToHost, stream));
+                // the rays of this source, kept apart: raytrace_multi strings the sources together in SOURCE order
+                // once every round is done (the solve order is round-major, i.e. interleaved when n_slots < n_src)
+                const size_t base = ray_pts->size();
+                ray_pts->resize(base + (size_t)tot * nc);
+                HIP_CHECK(hipMemcpyAsync(ray_pts->data() + base, d_raydense.p, sizeof(T) * nc * tot, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
-                const long long prev = rays_off.back();
-                for (int q = 0; q < m; ++q) rays_off.push_back(prev + off[q + 1]);
+                for (int q = 0; q < m; ++q) ray_len->push_back((long long)np[q]);
             }
         }
     }
@@ -1164,6 +1192,8 @@ class GridT : public GridBase {
         for (int b = 1; b < n_blk; ++b) start[b] = start[b - 1] + blk[b - 1];
         const int rounds = *std::max_element(blk.begin(), blk.end());
         const int mb = std::max(1, std::min(max_batch > 0 ? max_batch : n_slots, n_slots));
+        std::vector<std::vector<long long>> src_ray_len(return_rays ? n_src : 0);
+        std::vector<std::vector<T>> src_ray_pts(return_rays ? n_src : 0);
         for (int r = 0; r < rounds; ++r) {
             std::vector<int> slots, srcs;
             for (int b = 0; b < n_blk; ++b)
@@ -1184,8 +1214,18 @@ class GridT : public GridBase {
                     const int n = sr[b];
                     raypath_grid_coords(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)nc * tx_off[n], t0 + tx_off[n],
                                         rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n],
-                                        return_rays);
+                                        return_rays, &src_ray_len[n], &src_ray_pts[n]);
                 }
+            }
+        }
+        if (return_rays) {   // one ray per receiver row, in row order (rows of source 0, then source 1, ...)
+            size_t tot = 0;
+            for (int n = 0; n < n_src; ++n) tot += src_ray_pts[n].size();
+            rays_pts.reserve(tot);
+            for (int n = 0; n < n_src; ++n) {
+                for (long long len : src_ray_len[n]) rays_off.push_back(rays_off.back() + len);
+                rays_pts.insert(rays_pts.end(), src_ray_pts[n].begin(), src_ray_pts[n].end());
+                std::vector<T>().swap(src_ray_pts[n]);
             }
         }
         timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -1219,6 +1259,18 @@ static int guarded(F&& f) {
         g_last_error = e.what();
         return TTCR_ERR_RUNTIME;
     }
+}
+
+// entry points that touch a grid: serialised per handle (ttcrpy's raytrace(..., thread_no=k) lets several host
+// threads work on one grid; here the slots share one stream, one graph and the pinned / scratch buffers)
+template <typename G, typename F>
+static int guarded_on(G* g, F&& f) {
+    if (!g) {
+        g_last_error = "null grid handle";
+        return TTCR_ERR_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(g->impl->mu);
+    return guarded(std::forward<F>(f));
 }
 
 static int pick_device(int device) {
@@ -1292,21 +1344,21 @@ int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
 void ttcr_fsm_destroy(ttcr_fsm_grid* g) { delete g; }
 
 int ttcr_fsm_set_slowness(ttcr_fsm_grid* g, const void* s, size_t n) {
-    return guarded([&] { g->impl->set_slowness(s, n, false); });
+    return guarded_on(g, [&] { g->impl->set_slowness(s, n, false); });
 }
 int ttcr_fsm_set_slowness_c_order(ttcr_fsm_grid* g, const void* s, size_t n) {
-    return guarded([&] { g->impl->set_slowness(s, n, false, true); });
+    return guarded_on(g, [&] { g->impl->set_slowness(s, n, false, true); });
 }
 int ttcr_fsm_set_slowness_device(ttcr_fsm_grid* g, const void* d_s, size_t n) {
-    return guarded([&] { g->impl->set_slowness(d_s, n, true); });
+    return guarded_on(g, [&] { g->impl->set_slowness(d_s, n, true); });
 }
 int ttcr_fsm_get_slowness(ttcr_fsm_grid* g, void* out, size_t n) {
-    return guarded([&] { g->impl->get_slowness(out, n); });
+    return guarded_on(g, [&] { g->impl->get_slowness(out, n); });
 }
 
 int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
                       void* tt_out) {
-    return guarded([&] {
+    return guarded_on(g, [&] {
         if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
         const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
         g->impl->raytrace_multi(1, tx_off, tx, t0, rx_off, rx, tt_out, slot);
@@ -1315,20 +1367,29 @@ int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, cons
 
 int ttcr_fsm_raytrace_multi(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0,
                             const int* rx_off, const void* rx, void* tt_out) {
-    return guarded([&] { g->impl->raytrace_multi(n_src, tx_off, tx, t0, rx_off, rx, tt_out, -1); });
+    return guarded_on(g, [&] { g->impl->raytrace_multi(n_src, tx_off, tx, t0, rx_off, rx, tt_out, -1); });
 }
 
 int ttcr_fsm_get_tt(ttcr_fsm_grid* g, int slot, void* out, size_t n) {
-    return guarded([&] { g->impl->get_tt(slot, out, n); });
+    return guarded_on(g, [&] { g->impl->get_tt(slot, out, n); });
 }
 int ttcr_fsm_get_tt_device(ttcr_fsm_grid* g, int slot, void** d_ptr) {
-    return guarded([&] { *d_ptr = g->impl->tt_device(slot); });
+    return guarded_on(g, [&] {
+        if (!d_ptr) throw ValueError("null output pointer");
+        *d_ptr = g->impl->tt_device(slot);
+    });
+}
+int ttcr_fsm_get_tt_device_view(ttcr_fsm_grid* g, int slot, void** d_ptr, size_t* stride) {
+    return guarded_on(g, [&] {
+        if (!d_ptr || !stride) throw ValueError("null output pointer");
+        *d_ptr = g->impl->tt_device_view(slot, stride);
+    });
 }
 int ttcr_fsm_interp(ttcr_fsm_grid* g, int slot, int n_pts, const void* pts, void* tt_out) {
-    return guarded([&] { g->impl->interp(slot, n_pts, pts, tt_out); });
+    return guarded_on(g, [&] { g->impl->interp(slot, n_pts, pts, tt_out); });
 }
 int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw) {
-    return guarded([&] {
+    return guarded_on(g, [&] {
         if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
         if (niter) *niter = g->impl->niter[slot];
         if (niterw) *niterw = g->impl->niterw[slot];
@@ -1339,7 +1400,7 @@ size_t ttcr_fsm_n_nodes(const ttcr_fsm_grid* g) { return g->impl->n_nodes; }
 size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g) { return g->impl->n_cells; }
 
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
-    return guarded([&] {
+    return guarded_on(g, [&] {
         const std::string k(key ? key : "");
         if (k == "fixed_iters") g->impl->fixed_iters = (int)value;
         else if (k == "max_batch") g->impl->max_batch = (int)value;
@@ -1356,14 +1417,14 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
 }
 
 int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points) {
-    return guarded([&] { g->impl->rays_size(n_rays, n_points); });
+    return guarded_on(g, [&] { g->impl->rays_size(n_rays, n_points); });
 }
 int ttcr_fsm_get_rays(const ttcr_fsm_grid* g, long long* offsets, void* pts) {
-    return guarded([&] { g->impl->get_rays(offsets, pts); });
+    return guarded_on(g, [&] { g->impl->get_rays(offsets, pts); });
 }
 
 int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out) {
-    return guarded([&] {
+    return guarded_on(g, [&] {
         const Timing& t = g->impl->timing;
         out->sweep_ms = t.sweep_ms;
         out->total_ms = t.total_ms;

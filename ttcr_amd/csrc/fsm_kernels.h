@@ -721,7 +721,17 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     __shared__ int s_chg[64];  // bricks of the read set changed by this chunk
 
     const int tid = threadIdx.x;
+    // debug phase timers (FSM_ENABLE_PROF builds): thread 0 sums per phase in registers, one flush per unit
     unsigned long long prof_t = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
+    unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned pchunks = 0;
+    const unsigned long long trace_t0 = prof_t;
+#define FSM_PMARK(slot_)                                                          \
+    if (FSM_ENABLE_PROF && a.prof && tid == 0) {                                  \
+        const unsigned long long now_ = wall_clock64();                           \
+        pacc[slot_] += now_ - prof_t;                                             \
+        prof_t = now_;                                                            \
+    }
     if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
     __syncthreads();
     const int ticket = s_ticket;
@@ -1015,12 +1025,14 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         __syncthreads();
     }
     if (!SKIP) { issue_static(Lc); pref_for = Lc; }
+    FSM_PMARK(5)   // ticket, setup, wait for the previous sweep
+    const unsigned long long trace_t1 = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
     for (; Lc <= Le; Lc += C) {
         const int L0 = Lc;
         const int eoff = jp + kp - L0;
         const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;       // active levels e = ea..eb
         const int eb = eoff + NF - 1 < C - 1 ? eoff + NF - 1 : C - 1;
-        FSM_PROF_MARK(0)
+        FSM_PMARK(0)
 
         // (1) wait until both upwind patches have published every level <= L0+C-2
         //     The counters were sampled during the previous chunk's march (see below): when that old sample
@@ -1080,7 +1092,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         }
         __syncthreads();  // also: every read of the previous chunk's LDS tile is done
         if (tid == 0) s_anychg = 0;   // (read last before this barrier; written again only after the staging barrier)
-        FSM_PROF_MARK(1)
+        FSM_PMARK(1)
         if (SKIP && s_skip) {
             // nothing in the read set changed since this chunk was last evaluated: no-op
             have_prev = false;
@@ -1159,7 +1171,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         T sc[C];
 #pragma unroll
         for (int q = 0; q < C; ++q) sc[q] = sv[q];
-        FSM_PROF_MARK(2)
+        FSM_PMARK(2)
 
         // (4) prefetch the next chunk's static inputs; they land during the march
         if (Lc + C <= Le) { issue_static(Lc + C); pref_for = Lc + C; }
@@ -1236,8 +1248,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             if (chg_a && ba >= 0 && ba < rs_nf) s_chg[base + ba] = 1;
             if (chg_b && bb2 >= 0 && bb2 < rs_nf) s_chg[base + bb2] = 1;
         }
-        FSM_PROF_MARK(3)
-        if (FSM_ENABLE_PROF && a.prof && tid == 0) atomicAdd(a.prof + 7, 1ull);
+        FSM_PMARK(3)
+        if (FSM_ENABLE_PROF) ++pchunks;
 
         // (5) write back levels L0..L0+C-1 (tile q = H..H+C-1); the columns a downstream patch reads
         //     go out write-through (sc1)
@@ -1276,7 +1288,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         // (6) publish later: the counter moves once every wave has drained these stores -- at the
         //     staging barrier of the next chunk, or right after the loop
         pending = Lc + C > Le ? 0x3fffffff : Lc + C;
-        FSM_PROF_MARK(4)
+        FSM_PMARK(4)
     }
     if (pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1284,6 +1296,17 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         if (tid == 0) __hip_atomic_store(my_prog, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    if (FSM_ENABLE_PROF && a.prof && tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) atomicAdd(a.prof + q, pacc[q]);
+        atomicAdd(a.prof + 6, 1ull);
+        atomicAdd(a.prof + 7, (unsigned long long)pchunks);
+        // per-unit trace (last iteration wins): entry, first chunk, exit on the 100 MHz clock; patch and direction
+        unsigned long long* tr = a.prof + 8 + 4 * (size_t)ticket;
+        tr[0] = trace_t0; tr[1] = trace_t1; tr[2] = wall_clock64();
+        tr[3] = (unsigned long long)TJ | ((unsigned long long)TK << 16) | ((unsigned long long)dir << 32) | ((unsigned long long)z << 40);
+    }
+#undef FSM_PMARK
     // L1 decrease of every source of the unit: wavefront reduction, one atomic per wave and source
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nevals += __shfl_down(nevals, off, 64);
@@ -1710,7 +1733,7 @@ __global__ void fsm_init_source(const InitArgs<T> a) {
 
 // Receiver traveltimes: Grid3Drn::getTraveltime (ttcr/Grid3Drn.h:794-930)
 template <typename T>
-__device__ __forceinline__ T interp3d_pt(const T* __restrict__ Tn, int ts, T px, T py, T pz, int nnx, int nny, T dx,
+__device__ __forceinline__ T interp3d_pt(const T* __restrict__ Tn, int ts, T px, T py, T pz, int nnx, int nny, int nnz, T dx,
                                          T xmin, T ymin, T zmin) {
     const double small2 = 1.e-4 * 1.e-4;
     const T dy = dx, dz = dx;
@@ -1721,7 +1744,11 @@ __device__ __forceinline__ T interp3d_pt(const T* __restrict__ Tn, int ts, T px,
     const bool onx = (double)ab(px - (xmin + (T)i * dx)) < small2;
     const bool ony = (double)ab(py - (ymin + (T)j * dy)) < small2;
     const bool onz = (double)ab(pz - (zmin + (T)k * dz)) < small2;
-#define TT(ii, jj, kk) Tn[(((size_t)(kk) * nny + (jj)) * nnx + (ii)) * ts]
+    // The index is a rounded quotient plus 1e-8, "on the plane" an absolute distance below 1e-8: a point a rounding
+    // error below the last plane of an axis gets the last node as lower index without being on the plane, and the
+    // reference reads node index+1 (past the row / the array).  Clamped to the last node, like the oracle's TT.
+    auto cl = [](uint32_t v, int n) { return v < (uint32_t)n ? v : (uint32_t)n - 1u; };
+#define TT(ii, jj, kk) Tn[(((size_t)cl(kk, nnz) * nny + cl(jj, nny)) * nnx + cl(ii, nnx)) * ts]
     T tt;
     if (onx && ony && onz) {
         tt = TT(i, j, k);
@@ -1783,10 +1810,10 @@ __device__ __forceinline__ T interp3d_pt(const T* __restrict__ Tn, int ts, T px,
 
 template <typename T>
 __global__ void fsm_interp3d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
-                             int nnx, int nny, T dx, T xmin, T ymin, T zmin) {
+                             int nnx, int nny, int nnz, T dx, T xmin, T ymin, T zmin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, dx, xmin, ymin, zmin);
+    out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, nnz, dx, xmin, ymin, zmin);
 }
 
 // (nx, ny, nz) array in C order (z fastest, what numpy hands over) -> the solver's flat order (x fastest):
@@ -1811,13 +1838,13 @@ __global__ void fsm_c_to_x_fastest(const T* __restrict__ in, T* __restrict__ out
 // (fields of a group interleaved: element stride ts, group stride ts * n_nodes)
 template <typename T>
 __global__ void fsm_interp3d_batch(const T* __restrict__ tt0, int ts, size_t n_nodes, const int* __restrict__ slot_of,
-                                   const T* __restrict__ pts, T* __restrict__ out, int n, int nnx, int nny, T dx,
+                                   const T* __restrict__ pts, T* __restrict__ out, int n, int nnx, int nny, int nnz, T dx,
                                    T xmin, T ymin, T zmin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int slot = slot_of[r];
     const T* Tn = tt0 + (size_t)(slot / ts) * n_nodes * ts + slot % ts;
-    out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, dx, xmin, ymin, zmin);
+    out[r] = interp3d_pt(Tn, ts, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2], nnx, nny, nnz, dx, xmin, ymin, zmin);
 }
 
 // ---- traveltime from raypath (tt_from_rp, the 3-D default of ttcrpy) --------------------------
@@ -1933,7 +1960,7 @@ template <typename T>
 __device__ void grad3d(const RayGeom<T>& g, const T* __restrict__ Tn, int ts, T ptx, T pty, T ptz, T* gv) {
     const T k1 = (T)(1. / 24.), k2 = (T)(9. / 8.);
     const T dx = g.dx;
-    auto TT = [&](T a, T b, T c) { return interp3d_pt(Tn, ts, a, b, c, g.nnx, g.nny, dx, g.xmin, g.ymin, g.zmin); };
+    auto TT = [&](T a, T b, T c) { return interp3d_pt(Tn, ts, a, b, c, g.nnx, g.nny, g.nnz, dx, g.xmin, g.ymin, g.zmin); };
     auto pts4 = [&](T p1, T cmin, T cmax, T& o1, T& o2, T& o3, T& o4) {
         T p2 = (T)((double)p1 + 0.5 * (double)dx), p3 = (T)((double)p1 + 1.5 * (double)dx), p4 = (T)((double)p1 + 2.0 * (double)dx);
         if (p1 <= cmin) {
@@ -2090,27 +2117,32 @@ __global__ void fsm_compact_rays(const T* __restrict__ pts, long cap, const long
 // Grid2Drn::getTraveltime (ttcr/Grid2Drn.h:359-414); Grid2Drn::getSlowness (:1421-1476) has the same
 // shape on the node slowness (stride 1)
 template <typename T>
-__device__ __forceinline__ T interp2d_pt(const T* __restrict__ Tn, int ts, int nnz, T dx, T dz, T xmin, T zmin, T px, T pz) {
+__device__ __forceinline__ T interp2d_pt(const T* __restrict__ Tn, int ts, int nnx, int nnz, T dx, T dz, T xmin, T zmin, T px, T pz) {
     const double small = 1.e-4;
     const uint32_t i = (uint32_t)(small + (double)((px - xmin) / dx));
     const uint32_t j = (uint32_t)(small + (double)((pz - zmin) / dz));
     auto ab = [](T v) { return v < 0 ? -v : v; };
     const bool onx = (double)ab(px - (xmin + (T)i * dx)) < small;
     const bool onz = (double)ab(pz - (zmin + (T)j * dz)) < small;
+    // index = quotient + 1e-4 (cells), "on the line" = absolute distance below 1e-4: with dx > 1 a point between 1e-4
+    // and 1e-4*dx below the last line gets the last node as lower index without being on it, and the reference reads
+    // index+1.  Clamped to the last node, like the oracle's T2.
+    auto cl = [](uint32_t v, int n) { return v < (uint32_t)n ? v : (uint32_t)n - 1u; };
+#define T2(ii, jj) Tn[((size_t)cl(ii, nnx) * nnz + cl(jj, nnz)) * ts]
     T tt;
     if (onx && onz) {
-        tt = Tn[((size_t)i * nnz + j) * ts];
+        tt = T2(i, j);
     } else if (onx) {
-        T t1 = Tn[((size_t)i * nnz + j) * ts], t2 = Tn[((size_t)i * nnz + j + 1) * ts];
+        T t1 = T2(i, j), t2 = T2(i, j + 1);
         T w1 = (zmin + (T)(j + 1) * dz - pz) / dz, w2 = (pz - (zmin + (T)j * dz)) / dz;
         tt = t1 * w1 + t2 * w2;
     } else if (onz) {
-        T t1 = Tn[((size_t)i * nnz + j) * ts], t2 = Tn[((size_t)(i + 1) * nnz + j) * ts];
+        T t1 = T2(i, j), t2 = T2(i + 1, j);
         T w1 = (xmin + (T)(i + 1) * dx - px) / dx, w2 = (px - (xmin + (T)i * dx)) / dx;
         tt = t1 * w1 + t2 * w2;
     } else {
-        T t1 = Tn[((size_t)i * nnz + j) * ts], t2 = Tn[((size_t)(i + 1) * nnz + j) * ts];
-        T t3 = Tn[((size_t)i * nnz + j + 1) * ts], t4 = Tn[((size_t)(i + 1) * nnz + j + 1) * ts];
+        T t1 = T2(i, j), t2 = T2(i + 1, j);
+        T t3 = T2(i, j + 1), t4 = T2(i + 1, j + 1);
         T w1 = (xmin + (T)(i + 1) * dx - px) / dx, w2 = (px - (xmin + (T)i * dx)) / dx;
         t1 = t1 * w1 + t2 * w2;
         t2 = t3 * w1 + t4 * w2;
@@ -2118,26 +2150,27 @@ __device__ __forceinline__ T interp2d_pt(const T* __restrict__ Tn, int ts, int n
         w2 = (pz - (zmin + (T)j * dz)) / dz;
         tt = t1 * w1 + t2 * w2;
     }
+#undef T2
     return tt;
 }
 
 template <typename T>
 __global__ void fsm_interp2d(const T* __restrict__ Tn, int ts, const T* __restrict__ pts, T* __restrict__ out, int n,
-                             int nnz, T dx, T dz, T xmin, T zmin) {
+                             int nnx, int nnz, T dx, T dz, T xmin, T zmin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    out[r] = interp2d_pt(Tn, ts, nnz, dx, dz, xmin, zmin, pts[2 * r], pts[2 * r + 1]);
+    out[r] = interp2d_pt(Tn, ts, nnx, nnz, dx, dz, xmin, zmin, pts[2 * r], pts[2 * r + 1]);
 }
 
 template <typename T>
 __global__ void fsm_interp2d_batch(const T* __restrict__ tt0, int ts, size_t n_nodes, const int* __restrict__ slot_of,
-                                   const T* __restrict__ pts, T* __restrict__ out, int n, int nnz, T dx, T dz, T xmin,
+                                   const T* __restrict__ pts, T* __restrict__ out, int n, int nnx, int nnz, T dx, T dz, T xmin,
                                    T zmin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const int slot = slot_of[r];
     const T* Tn = tt0 + (size_t)(slot / ts) * n_nodes * ts + slot % ts;
-    out[r] = interp2d_pt(Tn, ts, nnz, dx, dz, xmin, zmin, pts[2 * r], pts[2 * r + 1]);
+    out[r] = interp2d_pt(Tn, ts, nnx, nnz, dx, dz, xmin, zmin, pts[2 * r], pts[2 * r + 1]);
 }
 
 // ---- 2-D raypath family: Grid2Drn::getTraveltimeFromRaypath (ttcr/Grid2Drn.h:1478-1661) and
@@ -2158,8 +2191,8 @@ __device__ void grad2d(const RayGeom2<T>& g, const T* __restrict__ Tn, int ts, T
         p2 = g.xmax;
         p1 = g.xmax - g.dx;
     }
-    gv[0] = (interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, p2, pz) -
-             interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, p1, pz)) / g.dx;
+    gv[0] = (interp2d_pt(Tn, ts, g.nnx, g.nnz, g.dx, g.dz, g.xmin, g.zmin, p2, pz) -
+             interp2d_pt(Tn, ts, g.nnx, g.nnz, g.dx, g.dz, g.xmin, g.zmin, p1, pz)) / g.dx;
     p1 = (T)((double)pz - (double)g.dz / 2.0);
     if (p1 < g.zmin) p1 = g.zmin;
     p2 = p1 + g.dz;
@@ -2167,8 +2200,8 @@ __device__ void grad2d(const RayGeom2<T>& g, const T* __restrict__ Tn, int ts, T
         p2 = g.zmax;
         p1 = g.zmax - g.dz;
     }
-    gv[1] = (interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, p2) -
-             interp2d_pt(Tn, ts, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, p1)) / g.dz;
+    gv[1] = (interp2d_pt(Tn, ts, g.nnx, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, p2) -
+             interp2d_pt(Tn, ts, g.nnx, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, p1)) / g.dz;
 }
 
 // Grid2Drn::getCellNo, ttcr/Grid2Drn.h:170-176
@@ -2177,8 +2210,11 @@ __device__ uint32_t cellno2d(const RayGeom2<T>& g, T px, T pz) {
     const double small = 1.e-4;
     const T x = (double)(g.xmax - px) < small ? (T)((double)g.xmax - .5 * (double)g.dx) : px;
     const T z = (double)(g.zmax - pz) < small ? (T)((double)g.zmax - .5 * (double)g.dz) : pz;
-    const uint32_t nx = (uint32_t)(small + (double)((x - g.xmin) / g.dx));
-    const uint32_t nz = (uint32_t)(small + (double)((z - g.zmin) / g.dz));
+    uint32_t nx = (uint32_t)(small + (double)((x - g.xmin) / g.dx));
+    uint32_t nz = (uint32_t)(small + (double)((z - g.zmin) / g.dz));
+    // (absolute test above, relative index here: a cell index past the last cell -- dx > 1 -- is clamped, see the oracle)
+    nx = nx > (uint32_t)(g.nnx - 2) ? (uint32_t)(g.nnx - 2) : nx;
+    nz = nz > (uint32_t)(g.nnz - 2) ? (uint32_t)(g.nnz - 2) : nz;
     return nx * (uint32_t)(g.nnz - 1) + nz;
 }
 
@@ -2239,7 +2275,7 @@ __global__ void fsm_raypath2d(const T* __restrict__ Tn, int ts, const T* __restr
         status[r] = st;
         out[r] = tt;
     };
-    auto slow = [&](T px, T pz) { return interp2d_pt(sn, 1, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, pz); };
+    auto slow = [&](T px, T pz) { return interp2d_pt(sn, 1, g.nnx, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, pz); };
     push(rx);
     for (int ns = 0; ns < n_src; ++ns)
         if (rx[0] == src[2 * ns] && rx[1] == src[2 * ns + 1]) { finish(0, t0[ns]); return; }
