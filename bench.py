@@ -62,8 +62,8 @@ def cpu_baseline(n=256, n_src=3):
     #      pool (ttcr/Grid3D.h:821-832); ctypes releases the GIL for the duration of a solve
     try:
         from concurrent.futures import ThreadPoolExecutor
-        nthr = max(1, min(os.cpu_count() or 1, 64))
-        many = cases.mt_sources(64)[:nthr]
+        nthr = max(1, os.cpu_count() or 1)   # ALL host cores, one source per thread
+        many = cases.mt_sources(max(64, nthr))[:nthr]
         t = time.perf_counter()
         with ThreadPoolExecutor(max_workers=nthr) as ex:
             its = list(ex.map(lambda p: O.solve3d(np.float32, (n - 1,) * 3, dx, (0, 0, 0), s, [p])["niter"], many))
@@ -96,22 +96,50 @@ KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,true,true> (o
 
 def profiled_traffic(n, n_src_rank0, world):
     """HBM bytes per launch (one sweep-iteration of the batch) from the committed rocprofv3 PMC passes of this very command
-    (profiles/r01/xs_512x64_{FETCH,WRITE}_SIZE_summary.csv, made by scripts/pmc_run.sh: separate
-    --pmc passes, KB units, gfx950 x2 correction of the read counter calibrated in the same run).
-    bench.py cannot profile itself, so the number is only reported for the profiled configuration."""
-    if not (n == 512 and n_src_rank0 == 64 and world == 1 and os.environ.get("TTCR_FSM_MODE", "2") == "2"):
-        return None, None
+    (profiles/r02/traffic.json, written by scripts/pmc_run.sh + scripts/pmc_to_json.py: separate --pmc passes, KB units,
+    gfx950 x2 correction of the read counter calibrated in the same run).  bench.py cannot profile itself; the record is
+    tagged with the hash of the kernel sources it was taken with and is only reported when that hash is the one of the
+    library being benchmarked now -- otherwise `traffic` is null rather than stale."""
     try:
-        vals = {}
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            path = os.path.join(ROOT, "profiles", "r01", f"xs_512x64_{c}_summary.csv")
-            with open(path) as f:
-                for line in f:
-                    if "fsm_sweep_persistent" in line:
-                        vals[c] = float(line.rsplit(",", 1)[1])  # KB per dispatch
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01/xs_512x64_*_SIZE_summary.csv"
+        from ttcr_amd.build import source_hash
+        with open(os.path.join(ROOT, "profiles", "r02", "traffic.json")) as f:
+            rec = json.load(f)
+        if rec.get("source_hash") != source_hash():
+            return None, "profiles/r02/traffic.json is from other kernel sources (%s): not reported" % rec.get("source_hash")
+        if not (n == rec["size"] and n_src_rank0 == rec["sources"] and world == 1 and os.environ.get("TTCR_FSM_MODE", "2") == "2"):
+            return None, None
+        return (2.0 * rec["fetch_kb_per_launch"] + rec["write_kb_per_launch"]) * 1024.0, "profiles/r02/traffic.json"
     except Exception:
         return None, None
+
+
+def single_source_leg(n, dx, x, s_dev, local_rank, reps=5):
+    """The case north_star's roofline target is written for: ONE source on the same grid, same run, HIP events around the
+    sweep launches of the solve (the first of the benchmark's sources, run to convergence)."""
+    import cases
+    import ttcr_amd
+
+    g1 = ttcr_amd.Grid3d(x, x, x, n_threads=1, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32, device=local_rank)
+    g1.set_slowness_device(s_dev.data_ptr(), s_dev.numel())
+    src = cases.mt_sources(1)
+    rcv = cases.rcv_lattice3d()
+    g1.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv)   # warm-up (graph capture)
+    ms, its, ev = 0.0, 0, 0
+    t = time.perf_counter()
+    for _ in range(reps):
+        g1.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv)
+        tm = g1.timing()
+        ms += tm["sweep_ms"]
+        its += g1.get_niter()
+        ev += tm["evaluated_updates"]
+    wall = time.perf_counter() - t
+    per_it = ms / its
+    achieved = BYTES_PER_NODE_ITER / 8.0 * ev / (ms * 1e-3) / 1e9
+    del g1
+    return {"ms_per_sweep_iteration": round(per_it, 4), "frac": round(achieved / HBM_PEAK_GBS, 4), "achieved_GBs": round(achieved, 1),
+            "Mnodes_per_s_per_sweep_iteration": round(n ** 3 / per_it / 1e3, 1), "sweep_iterations": its // reps,
+            "ms_per_solve_wall": round(wall / reps * 1e3, 3), "solves": reps,
+            "note": "1 source (first of the set) on the same grid, same process; HIP events on the library's stream"}
 
 
 def main():
@@ -123,6 +151,7 @@ def main():
     ap.add_argument("--sources", type=int, default=64, help="total sources of the job (sharded over the GPUs)")
     ap.add_argument("--sources-per-gpu", type=int, default=0, help="override: fixed sources per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-source", action="store_true", help="skip the 1-source leg of the N=1 run")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to "
                     "exercise the multi-rank path on a single-GPU box)")
@@ -231,13 +260,19 @@ def main():
     iters_per_src = [grid.get_niter(i) for i in range(S)]
 
     stats = torch.tensor([el, sweep_ms, float(node_iters), float(launches)], dtype=torch.float64, device=cdev)
+    per_rank = [(S, el)]
     if world > 1:
+        assert dist.get_world_size() == args.gpus
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         el_max, sweep_ms_max = float(mx[0]), float(mx[1])
         node_iters_all = float(sm[2])
+        mine = torch.tensor([float(S), el], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [(int(v[0]), float(v[1])) for v in allr]
     else:
         el_max, sweep_ms_max, node_iters_all = el, sweep_ms, float(node_iters)
 
@@ -270,6 +305,8 @@ def main():
                                    f"set block-distributed over {world} GPU(s) ({S} on rank 0), 441 receivers, fp32, "
                                    f"weno=False, tt_from_rp=False",
                        "grid_nodes": n_nodes, "sources_total": n_total, "sources_rank0": S,
+                       "sources_per_rank": [p[0] for p in per_rank],
+                       "sources_per_s_per_rank": [round(p[0] * args.steps / p[1], 3) for p in per_rank],
                        "sweep_iterations_per_source": sorted(set(iters_per_src)),
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, all_gather of receiver traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -280,8 +317,14 @@ def main():
                          "evaluated_fraction": round(evaluated / max(node_iters * 8, 1), 4),
                          "nominal_GBs_all_updates": round(nominal, 1),
                          "launches": int(launches), "avg_launch_us_hip_events": round(sweep_ms * 1e3 / max(launches, 1), 3),
-                         "algorithmic_bytes_per_launch": round(bytes_total / max(launches, 1), 1)},
+                         "algorithmic_bytes_per_launch": round(bytes_total / max(launches, 1), 1),
+                         "pricing_note": "contract figure: every evaluated node update at 104/8 B (T read, s read, T write + the "
+                                         "snapshot share), whether or not it changed the node -- the last sweep-iteration of a "
+                                         "converged solve evaluates everything and writes nothing (unchanged chunks skip their "
+                                         "write-back), and this design keeps no snapshot array"},
         }
+        if world == 1 and not args.no_single_source:
+            out["single_source"] = single_source_leg(n, dx, x, s_dev, local_rank)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

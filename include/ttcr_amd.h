@@ -122,6 +122,13 @@ int ttcr_fsm_get_tt_device_view(ttcr_fsm_grid* g, int slot, void** d_ptr, size_t
 /* Replaces: Grid3Drn::getTraveltime(pt, nt) (ttcr/Grid3Drn.h:794-930) / 2-D (:359-414). */
 int ttcr_fsm_interp(ttcr_fsm_grid* g, int slot, int n_pts, const void* pts, void* tt_out);
 
+/* Replaces: Grid3Drn::computeSlowness(pt, isTranslated) (ttcr/Grid3Drn.h:2451-2676) and Grid2Drn::computeSlowness(pt)
+ * (ttcr/Grid2Drn.h:262-330), what get_s0 of the Python classes calls per source point (src/ttcrpy/rgrid.pyx:824,
+ * :3799): the node slowness interpolated at n_pts points (velocity is interpolated instead when the grid was
+ * made with interp_vel, 3-D).  translated != 0: the points are already relative to the origin of a grid built with
+ * translate_origin.  A point outside the grid -> TTCR_ERR_RUNTIME (the reference reads its arrays unchecked). */
+int ttcr_fsm_compute_slowness(ttcr_fsm_grid* g, int n_pts, const void* pts, int translated, void* out);
+
 /* Replaces: get_niter()/get_niterw() (ttcr/Grid3Drnfs.h:56-57); per slot here
  * (the reference keeps one racy value per grid). */
 int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw);

@@ -20,6 +20,7 @@
 #define TTCR_GRID3DRNFS_AMD_H
 
 #include <atomic>
+#include <iostream>   // (Grid3D.h / Grid2D.h use std::cout without including it)
 #include <sstream>
 #include <stdexcept>
 #include <vector>

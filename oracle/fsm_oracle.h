@@ -27,6 +27,9 @@ extern "C" {
                         const REAL* t0, REAL eps, int maxit, int weno, REAL* T, REAL* change_hist,   \
                         int* niterw_out);                                                            \
     REAL fsm_interp3d_##S(const fsm_grid3d_##S* g, const REAL* T, REAL px, REAL py, REAL pz);        \
+    REAL fsm_compute_slowness3d_##S(const fsm_grid3d_##S* g, const REAL* sn, REAL px, REAL py,       \
+                                    REAL pz, int iv);                                                \
+    REAL fsm_compute_slowness2d_##S(const fsm_grid2d_##S* g, const REAL* sn, REAL px, REAL pz);      \
     int fsm_tt_from_raypath3d_##S(const fsm_grid3d_##S* g, const REAL* sn, const REAL* T, int n_src, \
                                   const REAL* src, const REAL* t0, const REAL rx[3], int iv,         \
                                   long max_steps, REAL* tt_out);                                     \

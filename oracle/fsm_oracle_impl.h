@@ -590,6 +590,12 @@ static REAL SFX(slowness_at3d)(const SFX(fsm_grid3d) * g, const REAL* sn, REAL p
 
 /* Grid3Drn::grad(g, pt, nt), ttcr/Grid3Drn.h:1033-1100: 4th-order centred operator on the
  * interpolated field.  (x uses pt.x - dx, y and z use pt - d/2.0 -- as in the reference.) */
+/* Grid3D::computeSlowness(pt) as the Cython layer calls it (src/ttcrpy/rgrid.pyx:824, get_s0): the function above
+ * on a point given in grid coordinates (the caller subtracts the origin of a translated grid, :2453-2455) */
+REAL SFX(fsm_compute_slowness3d)(const SFX(fsm_grid3d) * g, const REAL* sn, REAL px, REAL py, REAL pz, int iv) {
+    return SFX(slowness_at3d)(g, sn, px, py, pz, iv);
+}
+
 static void SFX(grad3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL ptx, REAL pty, REAL ptz, REAL* gx, REAL* gy, REAL* gz) {
     static const REAL k1 = 1. / 24.;
     static const REAL k2 = 9. / 8.;
@@ -1140,6 +1146,42 @@ REAL SFX(fsm_interp2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL p
 #undef T2
 #undef T2_CL
     return tt;
+}
+
+/* Grid2Drn::computeSlowness(pt), ttcr/Grid2Drn.h:262-330 (Grid2Drnfs and Grid2Drcfs both: interpolation of the NODE
+ * slowness): on-line test = first node within small^2 (absolute), cell index = quotient + small; an index past the
+ * last node is clamped like SN_CL in 3-D. */
+REAL SFX(fsm_compute_slowness2d)(const SFX(fsm_grid2d) * g, const REAL* sn, REAL px, REAL pz) {
+    const size_t nnx = g->nnx, nnz = g->nnz;
+    const REAL xmin = g->xmin, zmin = g->zmin, dx = g->dx, dz = g->dz;
+    ptrdiff_t onX = -1, onZ = -1;
+    for (size_t n = 0; n < nnx; ++n)
+        if (FABS(px - (xmin + n * dx)) < FSM_SMALL2) { onX = (ptrdiff_t)n; break; }
+    for (size_t n = 0; n < nnz; ++n)
+        if (FABS(pz - (zmin + n * dz)) < FSM_SMALL2) { onZ = (ptrdiff_t)n; break; }
+#define S2_CL(v, n) ((size_t)(v) < (size_t)(n) ? (size_t)(v) : (size_t)(n) - 1)
+#define S2(ii, kk) sn[S2_CL(ii, nnx) * nnz + S2_CL(kk, nnz)]
+    REAL s[4], x[3], z[3];
+    if (onX != -1 && onZ != -1) {
+        return sn[(size_t)onX * nnz + onZ];
+    } else if (onX != -1) {
+        const uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        s[0] = S2(onX, k); s[1] = S2(onX, k + 1);
+        x[0] = pz; x[1] = zmin + k * dz; x[2] = zmin + (k + 1) * dz;
+        return SFX(lin1)(x, s);
+    } else if (onZ != -1) {
+        const uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+        s[0] = S2(i, onZ); s[1] = S2(i + 1, onZ);
+        x[0] = px; x[1] = xmin + i * dx; x[2] = xmin + (i + 1) * dx;
+        return SFX(lin1)(x, s);
+    }
+    const uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+    const uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+    s[0] = S2(i, k); s[1] = S2(i, k + 1); s[2] = S2(i + 1, k); s[3] = S2(i + 1, k + 1);
+    x[0] = px; z[0] = pz; x[1] = xmin + i * dx; z[1] = zmin + k * dz; x[2] = xmin + (i + 1) * dx; z[2] = zmin + (k + 1) * dz;
+    return SFX(lin2)(x, z, s);
+#undef S2
+#undef S2_CL
 }
 
 /* ---- 2-D raypath family ----------------------------------------------------------------------

@@ -74,6 +74,8 @@ def lib():
         for sfx, ct, _, _ in _TYPES.values():
             getattr(_LIB, "fsm_interp3d_" + sfx).restype = ct
             getattr(_LIB, "fsm_interp2d_" + sfx).restype = ct
+            getattr(_LIB, "fsm_compute_slowness3d_" + sfx).restype = ct
+            getattr(_LIB, "fsm_compute_slowness2d_" + sfx).restype = ct
     return _LIB
 
 
@@ -246,6 +248,66 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
     out = dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
     if return_rays:
         out["rays"] = [rbuf[roff[n]:roff[n + 1]].astype(dt) for n in range(r.shape[0])]
+    return out
+
+
+def compute_slowness3d(dtype, ncells, dx, origin, slowness, pts, cell_slowness=False, translate=False, interp_vel=False,
+                       use_ref=False):
+    """Grid3D::computeSlowness(pt) at every row of pts (original coordinates), as get_s0 calls it
+    (src/ttcrpy/rgrid.pyx:824); use_ref: the compiled reference instead of the restatement."""
+    dt = np.dtype(dtype)
+    sfx, ct, G3, _ = _TYPES[dt]
+    ncx, ncy, ncz = (int(v) for v in ncells)
+    s = np.ascontiguousarray(np.asarray(slowness, dtype=dt).ravel())
+    p = _prep_pts(dt, pts, 3).copy()
+    out = np.empty(p.shape[0], dtype=dt)
+    if use_ref:
+        rc = getattr(ref(), "ref_compute_slowness3d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncy),
+                                                             C.c_uint32(ncz), ct(dx), ct(origin[0]), ct(origin[1]), ct(origin[2]),
+                                                             C.c_int(int(translate)), C.c_int(int(interp_vel)), _p(s),
+                                                             C.c_int(p.shape[0]), _p(p), _p(out))
+        if rc != 0:
+            raise RuntimeError(ref().ref_last_error().decode())
+        return out
+    L = lib()
+    g = G3()
+    getattr(L, "fsm_grid3d_init_" + sfx)(C.byref(g), C.c_uint32(ncx), C.c_uint32(ncy), C.c_uint32(ncz), ct(dx), ct(origin[0]),
+                                         ct(origin[1]), ct(origin[2]), C.c_int(int(translate)))
+    sn = cells_to_nodes3d(dt, ncells, s) if cell_slowness else s
+    if translate:
+        p -= np.array([g.ox, g.oy, g.oz], dtype=dt)
+    f = getattr(L, "fsm_compute_slowness3d_" + sfx)
+    for n, q in enumerate(p):
+        out[n] = f(C.byref(g), _p(sn), ct(q[0]), ct(q[1]), ct(q[2]), C.c_int(int(interp_vel)))
+    return out
+
+
+def compute_slowness2d(dtype, ncells, dx, dz, origin, slowness, pts, cell_slowness=False, use_ref=False):
+    """Grid2Drn::computeSlowness(pt), ttcr/Grid2Drn.h:262-330 (node and cell FSM grids alike)."""
+    dt = np.dtype(dtype)
+    sfx, ct, _, G2 = _TYPES[dt]
+    ncx, ncz = (int(v) for v in ncells)
+    s = np.ascontiguousarray(np.asarray(slowness, dtype=dt).ravel())
+    p = _prep_pts(dt, pts, 2)
+    out = np.empty(p.shape[0], dtype=dt)
+    if use_ref:
+        rc = getattr(ref(), "ref_compute_slowness2d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncz), ct(dx),
+                                                             ct(dz), ct(origin[0]), ct(origin[1]), _p(s), C.c_int(p.shape[0]),
+                                                             _p(p), _p(out))
+        if rc != 0:
+            raise RuntimeError(ref().ref_last_error().decode())
+        return out
+    L = lib()
+    g = G2()
+    getattr(L, "fsm_grid2d_init_" + sfx)(C.byref(g), C.c_uint32(ncx), C.c_uint32(ncz), ct(dx), ct(dz), ct(origin[0]), ct(origin[1]))
+    if cell_slowness:
+        sn = np.empty((ncx + 1) * (ncz + 1), dtype=dt)
+        getattr(L, "fsm_cells_to_nodes2d_" + sfx)(C.c_size_t(ncx), C.c_size_t(ncz), _p(s), _p(sn))
+    else:
+        sn = s
+    f = getattr(L, "fsm_compute_slowness2d_" + sfx)
+    for n, q in enumerate(p):
+        out[n] = f(C.byref(g), _p(sn), ct(q[0]), ct(q[1]))
     return out
 
 

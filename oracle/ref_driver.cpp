@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -187,6 +188,64 @@ REF3D(ref_fsm3d_f64, double)
 
 REF2D(ref_fsm2d_f32, float)
 REF2D(ref_fsm2d_f64, double)
+
+// Grid3D::computeSlowness(pt) / Grid2D::computeSlowness(pt) as the Cython layer calls them (get_s0,
+// src/ttcrpy/rgrid.pyx:824, :3799), through the base-class pointer
+#define REFCS3D(NAME, T)                                                                            \
+    extern "C" int NAME(int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz, T dx, T xmin,  \
+                        T ymin, T zmin, int translate, int intvel, const T* slowness, int n,        \
+                        const T* pts, T* out) {                                                     \
+        try {                                                                                       \
+            std::unique_ptr<ttcr::Grid3D<T, uint32_t>> g;                                           \
+            size_t ns;                                                                              \
+            if (cell_slowness) {                                                                    \
+                g.reset(new ttcr::Grid3Drcfs<T, uint32_t>(ncx, ncy, ncz, dx, xmin, ymin, zmin, 1e-5, 5, false, \
+                                                          false, intvel != 0, 1, translate != 0));  \
+                ns = (size_t)ncx * ncy * ncz;                                                       \
+            } else {                                                                                \
+                g.reset(new ttcr::Grid3Drnfs<T, uint32_t>(ncx, ncy, ncz, dx, xmin, ymin, zmin, 1e-5, 5, false, \
+                                                          false, intvel != 0, 1, translate != 0));  \
+                ns = (size_t)(ncx + 1) * (ncy + 1) * (ncz + 1);                                     \
+            }                                                                                       \
+            std::vector<T> s(slowness, slowness + ns);                                              \
+            g->setSlowness(s);                                                                      \
+            for (int i = 0; i < n; ++i)                                                             \
+                out[i] = g->computeSlowness(ttcr::sxyz<T>(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])); \
+            return 0;                                                                               \
+        } catch (std::exception & e) {                                                              \
+            g_err = e.what();                                                                       \
+            return 1;                                                                               \
+        }                                                                                           \
+    }
+REFCS3D(ref_compute_slowness3d_f32, float)
+REFCS3D(ref_compute_slowness3d_f64, double)
+
+#define REFCS2D(NAME, T)                                                                            \
+    extern "C" int NAME(int cell_slowness, uint32_t ncx, uint32_t ncz, T dx, T dz, T xmin, T zmin,  \
+                        const T* slowness, int n, const T* pts, T* out) {                           \
+        try {                                                                                       \
+            std::unique_ptr<ttcr::Grid2D<T, uint32_t, ttcr::sxz<T>>> g;                             \
+            size_t ns;                                                                              \
+            if (cell_slowness) {                                                                    \
+                g.reset(new ttcr::Grid2Drcfs<T, uint32_t, ttcr::sxz<T>>(ncx, ncz, dx, dz, xmin, zmin, 1e-5, 5, \
+                                                                        false, false, false, 1));   \
+                ns = (size_t)ncx * ncz;                                                             \
+            } else {                                                                                \
+                g.reset(new ttcr::Grid2Drnfs<T, uint32_t, ttcr::sxz<T>>(ncx, ncz, dx, dz, xmin, zmin, 1e-5, 5, \
+                                                                        false, false, false, 1));   \
+                ns = (size_t)(ncx + 1) * (ncz + 1);                                                 \
+            }                                                                                       \
+            std::vector<T> s(slowness, slowness + ns);                                              \
+            g->setSlowness(s);                                                                      \
+            for (int i = 0; i < n; ++i) out[i] = g->computeSlowness(ttcr::sxz<T>(pts[2 * i], pts[2 * i + 1])); \
+            return 0;                                                                               \
+        } catch (std::exception & e) {                                                              \
+            g_err = e.what();                                                                       \
+            return 1;                                                                               \
+        }                                                                                           \
+    }
+REFCS2D(ref_compute_slowness2d_f32, float)
+REFCS2D(ref_compute_slowness2d_f64, double)
 
 // Src / Rcv text files (double instantiation): coordinates (+ t0) into caller buffers, count returned
 extern "C" int ref_read_src(const char* fname, double* xyz, double* t0, int max_n) {

@@ -179,3 +179,39 @@ def test_fixture_data_files_are_the_reference_files():
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "files")
     for f in sorted(os.listdir(here)):
         assert open(os.path.join(here, f), "rb").read() == open("/root/reference/tests/files/" + f, "rb").read(), f
+
+
+def test_compute_slowness_matches_reference(O):
+    """Grid3D::computeSlowness(pt) / Grid2D::computeSlowness(pt) (get_s0 of the Python classes, src/ttcrpy/rgrid.pyx:758-826,
+    :3735-3802): restatement == compiled reference, node and cell grids, translated origin, interp_vel, both dtypes.
+    (The max corner of a translated fp32 grid is left out: after the origin subtraction it lies a rounding error off
+    the last planes, where the reference reads past its node array -- the restatement clamps, see SN_CL.)"""
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64):
+        for cell in (False, True):
+            for tr in (False, True):
+                for iv in (False, True):
+                    nc, dx, org = (7, 6, 5), 0.7, (100.0, -50.0, 3.0)
+                    ns = int(np.prod(nc) if cell else np.prod(np.array(nc) + 1))
+                    s = rng.uniform(0.3, 1.0, ns)
+                    lo = np.array(org)
+                    hi = lo + np.array(nc) * dx
+                    pts = [rng.uniform(lo, hi, (20, 3)), lo[None], (lo + np.array([2, 3, 1]) * dx)[None],
+                           np.array([[lo[0] + 2 * dx, lo[1] + 1.3, lo[2] + 0.9]]), np.array([[lo[0] + 1.1, lo[1] + 3 * dx, lo[2] + 2 * dx]])]
+                    if not (tr and dt == np.float32):
+                        pts.append(hi[None])
+                    pts = np.vstack(pts)
+                    a = O.compute_slowness3d(dt, nc, dx, org, s, pts, cell, tr, iv)
+                    b = O.compute_slowness3d(dt, nc, dx, org, s, pts, cell, tr, iv, use_ref=True)
+                    np.testing.assert_array_equal(a, b, err_msg=f"{dt} cell={cell} translate={tr} iv={iv}")
+        for cell in (False, True):
+            nc, dx, dz, org = (9, 7), 0.7, 0.4, (10.0, -5.0)
+            ns = int(np.prod(nc) if cell else np.prod(np.array(nc) + 1))
+            s = rng.uniform(0.3, 1.0, ns)
+            lo = np.array(org)
+            hi = lo + np.array(nc) * np.array([dx, dz])
+            pts = np.vstack([rng.uniform(lo, hi, (20, 2)), lo, hi, lo + np.array([2 * dx, 3 * dz]), [lo[0] + 2 * dx, lo[1] + 1.3],
+                             [lo[0] + 1.1, lo[1] + 3 * dz]])
+            a = O.compute_slowness2d(dt, nc, dx, dz, org, s, pts, cell)
+            b = O.compute_slowness2d(dt, nc, dx, dz, org, s, pts, cell, use_ref=True)
+            np.testing.assert_array_equal(a, b, err_msg=f"2-D {dt} cell={cell}")

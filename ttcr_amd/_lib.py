@@ -42,6 +42,7 @@ SYMBOLS = {
     "ttcr_fsm_get_tt_device": (_I, [_P, _I, C.POINTER(_P)]),
     "ttcr_fsm_get_tt_device_view": (_I, [_P, _I, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "ttcr_fsm_interp": (_I, [_P, _I, _I, _P, _P]),
+    "ttcr_fsm_compute_slowness": (_I, [_P, _I, _P, _I, _P]),
     "ttcr_fsm_get_niter": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ttcr_fsm_n_slots": (_I, [_P]),
     "ttcr_fsm_n_nodes": (C.c_size_t, [_P]),

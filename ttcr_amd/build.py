@@ -24,6 +24,18 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_hash():
+    """sha256 (16 hex digits) of everything the device code is compiled from: kernel sources + compiler flags.  Profiles
+    under profiles/ are tagged with it so that bench.py never reports counters taken with other kernels."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -85,6 +85,7 @@ class GridBase {
     virtual void* tt_device_view(int slot, size_t* stride) = 0;  // the field where it lies + its element stride
     std::mutex mu;  // one call at a time per handle: stream, graph capture, pinned and scratch buffers are shared
     virtual void interp(int slot, int n, const void* pts, void* out) = 0;
+    virtual void compute_slowness(int n, const void* pts, bool translated, void* out) = 0;
     virtual void rays_size(size_t* n_rays, size_t* n_points) const = 0;
     virtual void get_rays(long long* offsets, void* pts) const = 0;
     int dim = 3, dtype = 0, n_slots = 1, device = 0;
@@ -140,6 +141,8 @@ class GridT : public GridBase {
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // slot groups from which the 3-D WENO stage uses chunks of 4 levels
+    int time_order_below = 4;  // fewer slot groups than this in a batch: the whole-iteration launch hands its units out in the
+                               // order of their expected start times instead of sweep by sweep (build_persistent_lists)
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
     DevBuf<int> d_rstat;
@@ -154,6 +157,7 @@ class GridT : public GridBase {
     DevBuf<unsigned long long> d_prof;  // TTCR_FSM_PROF=1 debug phase timers
     size_t prof_words = 0;
     DevBuf<uint32_t> d_order;  // persistent kernel: patches in ticket order (anti-diagonal major)
+    DevBuf<uint32_t> d_order_xs[2][2];  // whole-iteration launch, [stage: first order / WENO][0: sweep by sweep, 1: by expected start time]
     DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
@@ -270,6 +274,7 @@ class GridT : public GridBase {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         if (const char* e = std::getenv("TTCR_FSM_SWEEP45")) sweep45_strips = std::string(e) == "strips";
         if (const char* e = std::getenv("TTCR_FSM_WENO_CH4_MIN")) weno_ch4_min = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_TIME_ORDER_BELOW")) time_order_below = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
     }
@@ -285,6 +290,80 @@ class GridT : public GridBase {
         d_order.reserve(order.size());
         HIP_CHECK(hipMemcpy(d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         d_sync.reserve(2 + (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4));
+        if (geom.npj >= (1 << 14) || geom.npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
+        for (int st = 0; st < 2; ++st)
+            for (int tm = 0; tm < 2; ++tm) {
+                const std::vector<uint32_t> xs = xs_order(order, tm != 0, st == 0 ? 1 : 2);
+                d_order_xs[st][tm].reserve(xs.size());
+                HIP_CHECK(hipMemcpy(d_order_xs[st][tm].p, xs.data(), xs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+    }
+
+    // Ticket order of the whole-iteration launch: every unit (direction d, patch) once, entries TJ | TK << 14 | d << 28.
+    // A unit waits for its two upwind patches of the same sweep and for the patches of sweep d-1 that own a column
+    // within 2H of its own (fsm_sweep_persistent), so any order that puts those first is deadlock free whatever the
+    // number of resident workgroups.  by_time = false: sweep by sweep, anti-diagonals inside a sweep.  by_time = true:
+    // by the start time every unit would have on an unbounded machine (upwind patch + one hand-off; previous sweep's
+    // patches finished), in chunk times.  A sweep has more patches than the chip has workgroup slots; handed out sweep
+    // by sweep, the slots fill up with patches that sit out their turn on the ramp of the patch wavefront while the
+    // next sweep, whose first corner is long free, cannot enter.  In start-time order the resident units are the ones
+    // that can run next, of whichever sweep.
+    std::vector<uint32_t> xs_order(const std::vector<uint32_t>& diag_order, bool by_time, int H) const {
+        const int ndir = dim == 3 ? 8 : 4, npj = geom.npj;
+        const int PJ = dim == 3 ? TileCfg<T, 3>::PJ : TileCfg<T, 2>::PJ, PK = dim == 3 ? TileCfg<T, 3>::PK : 1;
+        const int C = dim == 3 ? ChunkCfg<T, 3>::C : ChunkCfg<T, 2>::C;
+        std::vector<uint32_t> out;
+        out.reserve((size_t)n_patches * ndir);
+        if (!by_time) {
+            for (int d = 0; d < ndir; ++d)
+                for (uint32_t e : diag_order) out.push_back((e & 0xffffu) | ((e >> 16) << 14) | ((uint32_t)d << 28));
+            return out;
+        }
+        auto flags = [&](int d, int& rj, int& rk) {
+            if (dim == 3) { rj = (d >> 1) & 1; rk = (d >> 2) & 1; } else { rj = (d == 1) | (d == 2); rk = 0; }
+        };
+        std::vector<double> ts((size_t)n_patches * ndir, 0.0), tf((size_t)n_patches * ndir, 0.0);
+        const double hop_j = (PJ + C - 1.0) / C + 1.0, hop_k = (PK + C - 1.0) / C + 1.0;
+        for (int d = 0; d < ndir; ++d) {
+            int rj, rk, prj = 0, prk = 0;
+            flags(d, rj, rk);
+            if (d > 0) flags(d - 1, prj, prk);
+            for (uint32_t e : diag_order) {
+                const int TJ = e & 0xffffu, TK = e >> 16;
+                const size_t me = (size_t)d * n_patches + (size_t)TK * npj + TJ;
+                double t = 0.0;
+                if (TJ > 0) t = std::max(t, ts[me - 1] + hop_j);
+                if (TK > 0) t = std::max(t, ts[me - npj] + hop_k);
+                const int j0 = TJ * PJ, k0 = TK * PK;
+                const int jm = std::min(j0 + PJ, geom.NJ) - 1, km = std::min(k0 + PK, geom.NK) - 1;
+                if (d > 0) {
+                    const int ja = std::max(j0 - 2 * H, 0), jb = std::min(jm + 2 * H, geom.NJ - 1);
+                    const int ka = std::max(k0 - 2 * H, 0), kb = std::min(km + 2 * H, geom.NK - 1);
+                    const int ja2 = rj != prj ? geom.NJ - 1 - jb : ja, jb2 = rj != prj ? geom.NJ - 1 - ja : jb;
+                    const int ka2 = rk != prk ? geom.NK - 1 - kb : ka, kb2 = rk != prk ? geom.NK - 1 - ka : kb;
+                    for (int tk = ka2 / PK; tk <= kb2 / PK; ++tk)
+                        for (int tj = ja2 / PJ; tj <= jb2 / PJ; ++tj) t = std::max(t, tf[(size_t)(d - 1) * n_patches + (size_t)tk * npj + tj]);
+                }
+                ts[me] = t;
+                tf[me] = t + ((jm - j0) + (km - k0) + geom.NF + C - 1) / C + 1.0;
+            }
+        }
+        std::vector<uint32_t> idx((size_t)n_patches * ndir);
+        // stable sort by start time; ties keep (direction, anti-diagonal) order
+        size_t q = 0;
+        std::vector<uint32_t> ent((size_t)n_patches * ndir);
+        std::vector<double> key((size_t)n_patches * ndir);
+        for (int d = 0; d < ndir; ++d)
+            for (uint32_t e : diag_order) {
+                const int TJ = e & 0xffffu, TK = e >> 16;
+                ent[q] = (uint32_t)TJ | ((uint32_t)TK << 14) | ((uint32_t)d << 28);
+                key[q] = ts[(size_t)d * n_patches + (size_t)TK * npj + TJ];
+                idx[q] = (uint32_t)q;
+                ++q;
+            }
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a2, uint32_t b2) { return key[a2] < key[b2]; });
+        for (uint32_t i2 : idx) out.push_back(ent[i2]);
+        return out;
     }
 
     // The 3-D WENO stage exists with two chunk lengths: 8 levels (the kernel is latency bound with few
@@ -344,6 +423,7 @@ class GridT : public GridBase {
             a.s_sheared = nullptr;
             pa.timeout_ticks = 1000000000ull;  // 10 s: a unit may wait for most of the previous sweep
             const dim3 gridx((unsigned)n_patches * batch * ndir);
+            pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
             if (skip)
@@ -915,6 +995,37 @@ class GridT : public GridBase {
         interp_grid_coords(slot, n, p.data(), (T*)out);
     }
 
+    // Grid3Drn::computeSlowness(pt, isTranslated) (ttcr/Grid3Drn.h:2451-2676), Grid2Drn::computeSlowness (ttcr/Grid2Drn.h:262-330)
+    void compute_slowness(int n, const void* pts, bool translated, void* out) override {
+        HIP_CHECK(hipSetDevice(device));
+        if (!have_slowness) throw std::runtime_error("Error: slowness has not been assigned.");
+        if (n <= 0) return;
+        const int nc = ncoord();
+        std::vector<T> p((const T*)pts, (const T*)pts + (size_t)nc * n);
+        if (translate && !translated)
+            for (int m = 0; m < n; ++m) { p[3 * m] -= ox; p[3 * m + 1] -= oy; p[3 * m + 2] -= oz; }
+        check_pts(p.data(), n);   // (the reference indexes its node array unchecked; a point outside is refused here)
+        d_rx.reserve((size_t)nc * n);
+        d_out.reserve(n);
+        HIP_CHECK(hipMemcpyAsync(d_rx.p, p.data(), sizeof(T) * nc * n, hipMemcpyHostToDevice, stream));
+        const int blocks = (n + 63) / 64;
+        if (dim == 3) {
+            RayGeom<T> rg;
+            rg.nnx = ncx + 1; rg.nny = ncy + 1; rg.nnz = ncz + 1;
+            rg.dx = dx; rg.xmin = xmin; rg.ymin = ymin; rg.zmin = zmin; rg.xmax = xmax; rg.ymax = ymax; rg.zmax = zmax;
+            rg.interp_vel = interp_vel;
+            fsm_compute_slowness3d<T><<<blocks, 64, 0, stream>>>(rg, d_s.p, d_rx.p, n, d_out.p);
+        } else {
+            RayGeom2<T> rg2;
+            rg2.nnx = ncx + 1; rg2.nnz = ncz + 1;
+            rg2.dx = dx; rg2.dz = dz; rg2.xmin = xmin; rg2.zmin = zmin; rg2.xmax = xmax; rg2.zmax = zmax;
+            fsm_compute_slowness2d<T><<<blocks, 64, 0, stream>>>(rg2, d_s.p, d_rx.p, n, d_out.p);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, d_out.p, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
     void interp_grid_coords(int slot, int n, const T* p, T* out) {
         if (n <= 0) return;
         const int nc = ncoord();
@@ -1387,6 +1498,9 @@ int ttcr_fsm_get_tt_device_view(ttcr_fsm_grid* g, int slot, void** d_ptr, size_t
 }
 int ttcr_fsm_interp(ttcr_fsm_grid* g, int slot, int n_pts, const void* pts, void* tt_out) {
     return guarded_on(g, [&] { g->impl->interp(slot, n_pts, pts, tt_out); });
+}
+int ttcr_fsm_compute_slowness(ttcr_fsm_grid* g, int n_pts, const void* pts, int translated, void* out) {
+    return guarded_on(g, [&] { g->impl->compute_slowness(n_pts, pts, translated != 0, out); });
 }
 int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw) {
     return guarded_on(g, [&] {

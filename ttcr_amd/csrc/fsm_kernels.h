@@ -473,7 +473,8 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
 template <typename T>
 struct PersistArgs {
     SweepArgs<T> s;           // w, tiles unused
-    const uint32_t* order;    // patches in ticket order (TJ | TK<<16), sorted by m = TJ+TK
+    const uint32_t* order;    // ticket order.  One launch per sweep: patches (TJ | TK<<16) by anti-diagonal m = TJ+TK;
+                              // whole-iteration launch (XS): units (TJ | TK<<14 | dir<<28) of all directions
     int* sync;                // [0]: ticket counter, [1]: abort flag, [2 + z*n_patches + patch]: progress
     int n_patches, batch;
     unsigned long long timeout_ticks;  // 100 MHz wall-clock ticks
@@ -629,6 +630,9 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 #ifndef FSM_MINW
 #define FSM_MINW 1
 #endif
+#ifndef FSM_EARLY_PUB
+#define FSM_EARLY_PUB 0   // first chunks of a unit whose progress is published right after their write-back
+#endif
 // NS sources of a slot group marched together (field layout T[group][node][NS]): one element type
 // value held by the lane below / above (DPP wave shift, one VALU op; the end lanes get `edge`)
 __device__ __forceinline__ float lane_below(float x, float edge) {
@@ -732,18 +736,39 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         pacc[slot_] += now_ - prof_t;                                             \
         prof_t = now_;                                                            \
     }
+    const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
+    const int npj = a.g.npj;
+    // counter of the patch of sweep pd (its own oriented partition) that lane `lane` (< 16) has to see finished before
+    // unit (d, TJ_, TK_, z_) may touch its columns: the patches owning a column within 2H of the unit's (<= 3 x 3)
+    auto prev_sweep_counter = [&](int d, int TJ_, int TK_, int z_, int lane) -> const int* {
+        const int pd = d - 1;
+        int crj, crk, prj, prk;
+        if (IS3D) { crj = (d >> 1) & 1; crk = (d >> 2) & 1; prj = (pd >> 1) & 1; prk = (pd >> 2) & 1; }
+        else { crj = (d == 1) | (d == 2); crk = 0; prj = (pd == 1) | (pd == 2); prk = 0; }
+        const int j0_ = TJ_ * PJ, k0_ = TK_ * PK;
+        const int jm_ = (j0_ + PJ < NJ ? j0_ + PJ : NJ) - 1, km_ = (k0_ + PK < NK ? k0_ + PK : NK) - 1;
+        int ja = j0_ - 2 * H, jb = jm_ + 2 * H, ka = k0_ - 2 * H, kb = km_ + 2 * H;
+        ja = ja < 0 ? 0 : ja; jb = jb > NJ - 1 ? NJ - 1 : jb;
+        ka = ka < 0 ? 0 : ka; kb = kb > NK - 1 ? NK - 1 : kb;
+        // oriented (this sweep) -> natural -> oriented (previous sweep)
+        const int ja2 = (crj != prj) ? NJ - 1 - jb : ja, jb2 = (crj != prj) ? NJ - 1 - ja : jb;
+        const int ka2 = (crk != prk) ? NK - 1 - kb : ka, kb2 = (crk != prk) ? NK - 1 - ka : kb;
+        const int tja = ja2 / PJ, ntj = jb2 / PJ - tja + 1;
+        const int tka = IS3D ? ka2 / PK : 0, ntk = IS3D ? kb2 / PK - tka + 1 : 1;
+        const int ia = lane & 3, ib = lane >> 2;
+        if (ia >= ntj || ib >= ntk) return nullptr;
+        return pa.sync + 2 + ((size_t)pd * pa.batch + z_) * pa.n_patches + ((tka + ib) * npj + tja + ia);
+    };
     if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
     __syncthreads();
     const int ticket = s_ticket;
-    const int per_dir = pa.n_patches * pa.batch;
-    const int dir = XS ? ticket / per_dir : pa.dir;
-    const int trem = XS ? ticket - dir * per_dir : ticket;
-    const int pidx = trem / pa.batch, z = trem - pidx * pa.batch;
-    if (XS ? dir >= pa.ndir : pidx >= pa.n_patches) return;
-    const uint32_t tile = pa.order[pidx];
-    const int TJ = tile & 0xffffu, TK = tile >> 16;
-    const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
-    const int npj = a.g.npj;
+    // XS: `order` lists the units (direction, patch) of the whole iteration in ticket order -- any order in which a
+    // unit comes after its upwind patches and after the patches of the previous sweep it has to see finished
+    const int oidx = ticket / pa.batch, z = ticket - oidx * pa.batch;
+    if (oidx >= (XS ? pa.n_patches * pa.ndir : pa.n_patches)) return;
+    const uint32_t tile = pa.order[oidx];
+    const int dir = XS ? (int)(tile >> 28) : pa.dir;
+    const int TJ = XS ? (int)(tile & 0x3fffu) : (int)(tile & 0xffffu), TK = XS ? (int)((tile >> 14) & 0x3fffu) : (int)(tile >> 16);
     int* prog = pa.sync + 2 + ((size_t)(XS ? dir : 0) * pa.batch + z) * pa.n_patches;
     int* my_prog = prog + (TK * npj + TJ);
     // sweep direction: 3-D bits (F, J, K); 2-D order (+x+z, -x+z, -x-z, +x-z) with J = x, F = z
@@ -973,6 +998,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
     int pending = 0;            // progress value of the previous chunk, published once its stores have drained
+    int n_done = 0;             // chunks of this unit evaluated so far
     int pre_j = -1, pre_k = -1; // upwind progress counters as sampled during the previous chunk (lane 0 only)
     // Chunks that may hold frozen nodes of source l: the patch overlaps the bounding box of the frozen nodes in
     // J and K, and the chunk start L0 lies in [near_lo, near_hi] (the F extent of a chunk, clamped to the grid,
@@ -993,21 +1019,9 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     if (XS && dir > 0) {
         // previous sweep of this iteration: wait for the patches (of ITS oriented partition) that own
         // a column within 2H of ours -- at most 3 x 3 of them, one lane each
-        const int pd = dir - 1;
-        int prj, prk;
-        if (IS3D) { prj = (pd >> 1) & 1; prk = (pd >> 2) & 1; } else { prj = (pd == 1) | (pd == 2); prk = 0; }
-        int ja = j0 - 2 * H, jb = jmaxp + 2 * H, ka = k0 - 2 * H, kb = kmaxp + 2 * H;
-        ja = ja < 0 ? 0 : ja; jb = jb > NJ - 1 ? NJ - 1 : jb;
-        ka = ka < 0 ? 0 : ka; kb = kb > NK - 1 ? NK - 1 : kb;
-        // oriented (this sweep) -> natural -> oriented (previous sweep)
-        int ja2 = (rj != prj) ? NJ - 1 - jb : ja, jb2 = (rj != prj) ? NJ - 1 - ja : jb;
-        int ka2 = (rk != prk) ? NK - 1 - kb : ka, kb2 = (rk != prk) ? NK - 1 - ka : kb;
-        const int tja = ja2 / PJ, ntj = jb2 / PJ - tja + 1;
-        const int tka = IS3D ? ka2 / PK : 0, ntk = IS3D ? kb2 / PK - tka + 1 : 1;
         if (tid < 16) {
-            const int ia = tid & 3, ib = tid >> 2;
-            if (ia < ntj && ib < ntk) {
-                const int* pp = pa.sync + 2 + ((size_t)pd * pa.batch + z) * pa.n_patches + ((tka + ib) * npj + tja + ia);
+            const int* pp = prev_sweep_counter(dir, TJ, TK, z, tid);
+            if (pp) {
                 const unsigned long long t0 = wall_clock64();
                 int spins = 0;
                 while (__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0x3fffffff) {
@@ -1288,6 +1302,15 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         // (6) publish later: the counter moves once every wave has drained these stores -- at the
         //     staging barrier of the next chunk, or right after the loop
         pending = Lc + C > Le ? 0x3fffffff : Lc + C;
+        if (FSM_EARLY_PUB > 0 && n_done < FSM_EARLY_PUB) {
+            // the first chunks of a unit sit on the ramp of the patch wavefront (the downstream patches are waiting for
+            // exactly these levels): publish at once instead of at the next staging barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(my_prog, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending = 0;
+        }
+        ++n_done;
         FSM_PMARK(4)
     }
     if (pending) {
@@ -2180,6 +2203,51 @@ struct RayGeom2 {
     int nnx, nnz;
     T dx, dz, xmin, zmin, xmax, zmax;
 };
+
+// Grid2Drn::computeSlowness(pt), ttcr/Grid2Drn.h:262-330: node / linear / bilinear interpolation of the node slowness
+// (FSM node and cell grids alike); on-line = first node within small^2, cell index = quotient + small (clamped like SN)
+template <typename T>
+__device__ T slowness_at2d(const RayGeom2<T>& g, const T* __restrict__ sn, T px, T pz) {
+    const double small = 1.e-4;
+    const int onX = on_node(px, g.xmin, g.dx, g.nnx), onZ = on_node(pz, g.zmin, g.dz, g.nnz);
+    auto S2 = [&](unsigned i, unsigned k) {
+        i = i < (unsigned)g.nnx ? i : (unsigned)g.nnx - 1;
+        k = k < (unsigned)g.nnz ? k : (unsigned)g.nnz - 1;
+        return sn[(size_t)i * g.nnz + k];
+    };
+    if (onX != -1 && onZ != -1) return sn[(size_t)onX * g.nnz + onZ];
+    if (onX != -1) {
+        const unsigned k = (unsigned)(small + (double)((pz - g.zmin) / g.dz));
+        const T s0 = S2(onX, k), s1 = S2(onX, k + 1);
+        const T x0 = pz, x1 = g.zmin + (T)k * g.dz, x2 = g.zmin + (T)(k + 1) * g.dz;
+        return (s0 * (x2 - x0) + s1 * (x0 - x1)) / (x2 - x1);
+    }
+    if (onZ != -1) {
+        const unsigned i = (unsigned)(small + (double)((px - g.xmin) / g.dx));
+        const T s0 = S2(i, onZ), s1 = S2(i + 1, onZ);
+        const T x0 = px, x1 = g.xmin + (T)i * g.dx, x2 = g.xmin + (T)(i + 1) * g.dx;
+        return (s0 * (x2 - x0) + s1 * (x0 - x1)) / (x2 - x1);
+    }
+    const unsigned i = (unsigned)(small + (double)((px - g.xmin) / g.dx));
+    const unsigned k = (unsigned)(small + (double)((pz - g.zmin) / g.dz));
+    const T s0 = S2(i, k), s1 = S2(i, k + 1), s2 = S2(i + 1, k), s3 = S2(i + 1, k + 1);
+    const T x0 = px, z0 = pz, x1 = g.xmin + (T)i * g.dx, z1 = g.zmin + (T)k * g.dz;
+    const T x2 = g.xmin + (T)(i + 1) * g.dx, z2 = g.zmin + (T)(k + 1) * g.dz;
+    return (s0 * (x2 - x0) * (z2 - z0) + s1 * (x2 - x0) * (z0 - z1) + s2 * (x0 - x1) * (z2 - z0) + s3 * (x0 - x1) * (z0 - z1)) /
+           ((x2 - x1) * (z2 - z1));
+}
+
+// Grid3D::computeSlowness / Grid2D::computeSlowness at n points (get_s0 of the Python classes)
+template <typename T>
+__global__ void fsm_compute_slowness3d(RayGeom<T> g, const T* __restrict__ sn, const T* __restrict__ pts, int n, T* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = slowness_at3d(g, sn, pts[3 * r], pts[3 * r + 1], pts[3 * r + 2]);
+}
+template <typename T>
+__global__ void fsm_compute_slowness2d(RayGeom2<T> g, const T* __restrict__ sn, const T* __restrict__ pts, int n, T* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = slowness_at2d(g, sn, pts[2 * r], pts[2 * r + 1]);
+}
 
 // Grid2Drn::grad(g, pt, nt), ttcr/Grid2Drn.h:606-632
 template <typename T>

@@ -136,6 +136,28 @@ class _GridBase:
         _lib.check(self._lib.ttcr_fsm_get_tt(self._h, int(thread_no), _ptr(out), n))
         return out
 
+    def get_s0(self, hypo, slowness=None):
+        """get_s0(hypo, slowness=None): slowness at the source points (rgrid.pyx:758-826, 2-D :3735-3802).
+        hypo: event ID, origin time, source coordinates (5 columns in 3-D, 4 in 2-D); every row of an event gets the
+        value at the event's first row (Grid3D::computeSlowness there)."""
+        nd = self._ndim
+        hypo = np.asarray(hypo)
+        if hypo.ndim != 2 or hypo.shape[1] != nd + 2:
+            raise ValueError('hypo should be npts x %d' % (nd + 2))
+        src = hypo[:, 2:2 + nd]
+        evID = hypo[:, 0]
+        eid = np.sort(np.unique(evID))
+        if slowness is not None:
+            self.set_slowness(slowness)
+        first = np.array([int(np.nonzero(evID == e)[0][0]) for e in eid], dtype=np.int64)
+        pts = np.ascontiguousarray(src[first, :], dtype=self._dtype)
+        out = np.empty(max(len(eid), 1), dtype=self._dtype)
+        _lib.check(self._lib.ttcr_fsm_compute_slowness(self._h, len(eid), _ptr(pts), 0, _ptr(out)))
+        s0 = np.zeros((src.shape[0],))
+        for n, e in enumerate(eid):
+            s0[evID == e] = out[n]   # s / vTx[n].size() with one point per event
+        return s0
+
     def tt_device_ptr(self, thread_no=0):
         """Raw device address of n_nodes CONTIGUOUS traveltimes of a slot, in the solver's flat order.  With
         n_threads >= 2 the fields of two slots are interleaved in HBM and this is a de-interleaved copy in a
