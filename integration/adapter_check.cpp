@@ -104,6 +104,7 @@ template <typename F> static std::string what_of(F&& f) {
 }
 
 int main() {
+    std::setvbuf(stdout, nullptr, _IONBF, 0);
     if (ttcr_fsm_device_count() < 1) { std::printf("FAIL no HIP device\n"); return 100; }
     {   // ------------------------------------------------ 3-D node grid, fp32, 3 slots, through Grid3D<float,uint32_t>*
         const uint32_t ncx = 18, ncy = 14, ncz = 11;
@@ -149,6 +150,7 @@ int main() {
         std::vector<std::vector<sxyz<float>>> mTx = {{{3.3f, 1.1f, 2.7f}}, {{8.0f, 2.0f, 4.0f}}, {{1.0f, -2.0f, 0.0f}}, {{5.5f, 3.3f, 1.1f}}};
         std::vector<std::vector<float>> mt0 = {{0.25f}, {0.0f}, {1.0f}, {0.0f}}, mtt, btt;
         std::vector<std::vector<sxyz<float>>> mRx = {Rx, {{2.0f, 2.0f, 2.0f}}, {{9.5f, 4.5f, 5.0f}, {3.0f, 0.0f, 1.0f}}, Rx};
+        mtt.resize(mTx.size());   // (the reference indexes traveltimes[n] unchecked, like rgrid.pyx pre-sizes vtt)
         g->raytrace(mTx, mt0, mRx, mtt);
         dynamic_cast<Grid3Drnfs_amd<float, uint32_t>&>(*g).raytrace_batch(mTx, mt0, mRx, btt);
         CHECK(mtt == btt, "Grid3D multi-source overload (host threads) == raytrace_batch (one device call)");
@@ -171,7 +173,7 @@ int main() {
         std::vector<double> sc(6 * 5 * 4);
         for (size_t n = 0; n < sc.size(); ++n) sc[n] = slow(1000u + (unsigned)n);
         g->setSlowness(sc);
-        std::vector<sxyz<double>> Tx = {{500002.5, 4000002.5, -999.0}}, Rx = {{500000.0, 4000000.0, -1000.0}, {500006.0, 4000005.0, -996.0}};
+        std::vector<sxyz<double>> Tx = {{500002.5, 4000002.5, -999.0}}, Rx = {{500001.0, 4000001.5, -998.5}, {500005.0, 4000004.0, -997.0}};
         std::vector<double> t0 = {0.0}, tt;
         g->raytrace(Tx, t0, Rx, tt, 0);   // the ttcrpy default: cells, WENO, traveltimes from raypaths
         std::printf("a3c_tt %a %a\n", tt[0], tt[1]);
@@ -192,6 +194,7 @@ int main() {
         std::printf("a2_s0 %a\n", g->computeSlowness(Tx[0]));
         std::vector<std::vector<S>> mTx = {{{3.3f, 1.1f}}, {{7.0f, 2.0f}}, {{0.0f, 0.0f}}}, mRx = {Rx, {{5.0f, 1.0f}}, Rx};
         std::vector<std::vector<float>> mt0 = {{0.0f}, {0.5f}, {0.0f}}, mtt, btt;
+        mtt.resize(mTx.size());
         g->raytrace(mTx, mt0, mRx, mtt);
         dynamic_cast<Grid2Drnfs_amd<float, uint32_t, S>&>(*g).raytrace_batch(mTx, mt0, mRx, btt);
         CHECK(mtt == btt && mtt[0] == tt, "2-D: Grid2D multi-source overload == raytrace_batch");

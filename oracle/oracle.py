@@ -67,7 +67,7 @@ _TYPES = {
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("TTCR_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # (override: the ASan build)
         if not os.path.exists(path):
             build(with_ref=False)
         _LIB = C.CDLL(path)
@@ -147,6 +147,8 @@ def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=5
         r = _prep_pts(dt, rcv, 3).copy()
         if translate:
             r -= np.array([g.ox, g.oy, g.oz], dtype=dt)
+        if getattr(L, "fsm_outside3d_" + sfx)(C.byref(g), C.c_int(r.shape[0]), _p(r)):   # Grid3Drnfs::raytrace: checkPts(Rx)
+            raise RuntimeError("Error: Point outside grid.")
         if return_rays:
             # Grid3D::raytrace(Tx,t0,Rx,tt,r_data,threadNo) (ttcr/Grid3D.h:546-586): getRaypath with tt for
             # every receiver; rays are shifted back by the origin of a translated grid (:579-584)
@@ -347,6 +349,10 @@ def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, max
                                              C.byref(nw))
     out = dict(tt=T, niter=int(niter), niterw=int(nw.value), change=hist[:niter].copy(),
                changew=hist[maxit:maxit + nw.value].copy(), node_slowness=sn)
+    if rcv is not None:
+        r_chk = _prep_pts(dt, rcv, 2)
+        if getattr(L, "fsm_outside2d_" + sfx)(C.byref(g), C.c_int(r_chk.shape[0]), _p(r_chk)):   # Grid2Drnfs::raytrace: checkPts(Rx)
+            raise RuntimeError("Error: Point outside grid.")
     if rcv is not None and (tt_from_rp or return_rays):
         r = _prep_pts(dt, rcv, 2)
         frp = getattr(L, "fsm_raypath2d_" + sfx)

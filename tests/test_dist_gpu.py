@@ -128,7 +128,7 @@ def test_get_s0_matches_oracle(oracle):
 
     rng = np.random.default_rng(41)
     n = 16
-    x = 100.0 + np.arange(n) * 0.7
+    x = 100.0 + np.arange(n) * 0.75
     s = rng.uniform(0.3, 1.0, (n - 1, n - 1, n - 1))
     for tr in (0, 1):
         g = ttcr_amd.Grid3d(x, x, x, cell_slowness=1, method="FSM", translate_grid=tr)
@@ -138,7 +138,7 @@ def test_get_s0_matches_oracle(oracle):
         hypo[3, 2:] = [x[2], x[3], x[1]]   # an event on a node
         s0 = g.get_s0(hypo, slowness=s)
         first = {1: 1, 2: 3, 3: 0}
-        want = oracle.compute_slowness3d(np.float64, (n - 1,) * 3, 0.7, (100.0,) * 3, s.flatten("F"), hypo[[first[1], first[2], first[3]], 2:],
+        want = oracle.compute_slowness3d(np.float64, (n - 1,) * 3, 0.75, (100.0,) * 3, s.flatten("F"), hypo[[first[1], first[2], first[3]], 2:],
                                          cell_slowness=True, translate=bool(tr))
         for k, e in enumerate((1, 2, 3)):
             assert np.all(s0[hypo[:, 0] == e] == want[k])

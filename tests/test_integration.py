@@ -113,7 +113,7 @@ def test_adapter_drives_the_gpu_through_the_reference_base_classes(oracle):
     sc = _slow(1000 + np.arange(6 * 5 * 4)).astype(np.float64)
     orgc = (500000.0, 4000000.0, -1000.0)
     srcc = [[500002.5, 4000002.5, -999.0]]
-    rxc = [[500000.0, 4000000.0, -1000.0], [500006.0, 4000005.0, -996.0]]
+    rxc = [[500001.0, 4000001.5, -998.5], [500005.0, 4000004.0, -997.0]]
     oc = oracle.solve3d(np.float64, (6, 5, 4), 1.0, orgc, sc, srcc, rcv=rxc, cell_slowness=True, translate=True, weno=True, tt_from_rp=True)
     np.testing.assert_array_equal(np.array(vals["a3c_tt"]), oc["tt_rcv"])
     assert vals["a3c_niter"] == [oc["niter"], oc["niterw"]]

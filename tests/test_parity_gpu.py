@@ -503,7 +503,9 @@ def test_hip_receivers_next_to_the_last_planes(oracle, dt):
     rng = np.random.default_rng(23)
     nn, dx = (9, 8, 7), 2.3
     axes = [np.arange(m) * dx for m in nn]
-    hi = np.array([a[-1] for a in axes], dtype=dt)
+    # the far planes: xmax as the grid computes it (ttcr/Grid3Drn.h:73), not beyond the last axis value in the grid dtype
+    # (the ttcrpy-style pre-check compares with the axes)
+    hi = np.minimum(np.array([dt(0) + dt(m - 1) * dt(dx) for m in nn], dtype=dt), np.array([dt(a[-1]) for a in axes], dtype=dt))
     s = rng.uniform(0.3, 1.0, nn)
     pts = [hi.copy()]
     for ax in range(3):
@@ -529,7 +531,8 @@ def test_hip_receivers_next_to_the_last_planes(oracle, dt):
     # 2-D, node grid with interpolation and cell grid with raypath traveltimes (getCellNo at segment mid-points)
     nn2, dx2, dz2 = (12, 10), 2.3, 3.1
     x2, z2 = np.arange(nn2[0]) * dx2, np.arange(nn2[1]) * dz2
-    hi2 = np.array([x2[-1], z2[-1]], dtype=dt)
+    hi2 = np.minimum(np.array([dt(0) + dt(nn2[0] - 1) * dt(dx2), dt(0) + dt(nn2[1] - 1) * dt(dz2)], dtype=dt),
+                     np.array([dt(x2[-1]), dt(z2[-1])], dtype=dt))
     pts2 = [hi2.copy()]
     for ax in range(2):
         for back in (1, 3, 60, 500):
@@ -551,8 +554,17 @@ def test_hip_receivers_next_to_the_last_planes(oracle, dt):
     sc = 1.0 / (1.0 + 0.05 * np.arange(nn2[1] - 1))
     sc2 = np.ascontiguousarray(np.broadcast_to(sc[None, :], (nn2[0] - 1, nn2[1] - 1)))
     g3 = ttcr_amd.Grid2d(x2, z2, cell_slowness=1, method="FSM", tt_from_rp=1, weno=0, dtype=dt)
-    tt3 = g3.raytrace(src2, rcv2, slowness=sc2)
-    o3 = oracle.solve2d(dt, (nn2[0] - 1, nn2[1] - 1), dx2, dz2, (0, 0), sc2.ravel(), src2, rcv=rcv2, cell_slowness=True,
+    keep = []   # receivers whose walk ends at the source (the reference throws / does not return for the others)
+    for k, r in enumerate(rcv2):
+        try:
+            oracle.solve2d(dt, (nn2[0] - 1, nn2[1] - 1), dx2, dz2, (0, 0), sc2.ravel(), src2, rcv=[r], cell_slowness=True, tt_from_rp=True)
+            keep.append(k)
+        except RuntimeError:
+            pass
+    assert len(keep) >= 4
+    rcv3 = rcv2[keep]
+    tt3 = g3.raytrace(src2, rcv3, slowness=sc2)
+    o3 = oracle.solve2d(dt, (nn2[0] - 1, nn2[1] - 1), dx2, dz2, (0, 0), sc2.ravel(), src2, rcv=rcv3, cell_slowness=True,
                         tt_from_rp=True)
     np.testing.assert_array_equal(tt3, o3["tt_rcv"])
 
@@ -593,33 +605,36 @@ def test_hip_one_grid_from_several_host_threads(oracle):
 
 def test_hip_device_views_of_a_field():
     """ttcr_fsm_get_tt_device: n_nodes contiguous values; ttcr_fsm_get_tt_device_view: the field where it lies + stride
-    (2 with n_threads >= 2: interleaved pairs).  Both read back through torch from the raw device pointers."""
-    import ctypes as C
-
-    import torch
-
+    (2 with n_threads >= 2: interleaved pairs).  The raw device pointers are consumed the way a zero-copy consumer would:
+    handed to another grid as device-resident input (set_slowness_device) and read back from there."""
     import ttcr_amd
 
     n = 20
     x = np.arange(n) * 0.5
     rng = np.random.default_rng(37)
     s = rng.uniform(0.3, 1.0, (n, n, n))
+    nn = n ** 3
+    sink = ttcr_amd.Grid3d(x, x, x, cell_slowness=0, method="FSM", dtype=np.float32)                 # nn values
+    sink2 = ttcr_amd.Grid3d(np.arange(2 * n) * 0.5, x, x, cell_slowness=0, method="FSM", dtype=np.float32)   # 2 nn values
     for nthr, want_stride in ((1, 1), (3, 2)):
         g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32)
         srcs = rng.uniform(0.5, 9.0, (nthr, 3))
         g.raytrace(srcs, np.zeros((nthr, 3)), slowness=s)
-        nn = g.get_number_of_nodes()
+        fields = [g._flat_tt(k) for k in range(nthr)]
         for slot in range(nthr):
-            want = g._flat_tt(slot)
             ptr, stride = g.tt_device_view(slot)
             assert stride == want_stride
-            buf = torch.empty(nn * stride, dtype=torch.float32, device="cuda")
-            # device-to-device copy of the strided view through HIP (torch owns the destination)
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            assert hip.hipMemcpy(buf.data_ptr(), ptr, (nn - 1) * stride * 4 + 4, 3) == 0
-            np.testing.assert_array_equal(buf.cpu().numpy()[::stride][:nn], want)
-            cptr = g.tt_device_ptr(slot)
-            buf2 = torch.empty(nn, dtype=torch.float32, device="cuda")
-            assert hip.hipMemcpy(buf2.data_ptr(), cptr, nn * 4, 3) == 0
-            np.testing.assert_array_equal(buf2.cpu().numpy(), want)
+            sink.set_slowness_device(g.tt_device_ptr(slot), nn)            # contiguous copy of the slot's field
+            np.testing.assert_array_equal(sink.get_slowness().flatten("F"), fields[slot])
+            if stride == 1:
+                sink.set_slowness_device(ptr, nn)                           # the view IS the contiguous field
+                np.testing.assert_array_equal(sink.get_slowness().flatten("F"), fields[slot])
+        if want_stride == 2:
+            p0, _ = g.tt_device_view(0)
+            p1, _ = g.tt_device_view(1)
+            p2, _ = g.tt_device_view(2)
+            assert p1 - p0 == 4 and p2 - p0 == 2 * nn * 4                   # T[group][node][2]
+            sink2.set_slowness_device(p0, 2 * nn)                           # the whole first pair, as it lies
+            pair = sink2.get_slowness().flatten("F").reshape(nn, 2)
+            np.testing.assert_array_equal(pair[:, 0], fields[0])
+            np.testing.assert_array_equal(pair[:, 1], fields[1])

@@ -141,6 +141,7 @@ class GridT : public GridBase {
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // slot groups from which the 3-D WENO stage uses chunks of 4 levels
+    int pre_min = 4;           // 3-D: slot groups in a batch from which the upwind counters are sampled one chunk ahead (PRE)
     int time_order_below = 4;  // fewer slot groups than this in a batch: the whole-iteration launch hands its units out in the
                                // order of their expected start times instead of sweep by sweep (build_persistent_lists)
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
@@ -275,6 +276,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_SWEEP45")) sweep45_strips = std::string(e) == "strips";
         if (const char* e = std::getenv("TTCR_FSM_WENO_CH4_MIN")) weno_ch4_min = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_TIME_ORDER_BELOW")) time_order_below = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_PRE_MIN")) pre_min = std::atoi(e);                     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
     }
@@ -428,7 +430,7 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
             if (skip)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
-            else if (DIM == 2 || batch >= 4)   // counters sampled one chunk ahead (template PRE)
+            else if (DIM == 2 || batch >= pre_min)   // counters sampled one chunk ahead (template PRE)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, 0, stream>>>(pa);
             else
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
@@ -1137,7 +1139,7 @@ class GridT : public GridBase {
         HIP_CHECK(hipMemcpyAsync(d_rx.p, p.data(), sizeof(T) * nc * n, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(d_rslot.p, so.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(d_rdesc.p, desc.data(), sizeof(RaySrc) * desc.size(), hipMemcpyHostToDevice, stream));
-        const long max_steps = 8L * ((long)ncx + ncy + ncz + 3);
+        const long max_steps = walk_step_limit;
         const dim3 rgrid((unsigned)((n + 63) / 64)), rblock(64);
         if (dim == 3) {
             RayGeom<T> rg;
@@ -1187,8 +1189,12 @@ class GridT : public GridBase {
         rg2.nnx = ncx + 1; rg2.nnz = ncz + 1;
         rg2.dx = dx; rg2.dz = dz; rg2.xmin = xmin; rg2.zmin = zmin; rg2.xmax = xmax; rg2.zmax = zmax;
         const T* cell_s = (dim == 2 && cell) ? d_cells.p : nullptr;   // Grid2Drcfs integrates the CELL slowness
-        const long max_steps = 8L * ((long)ncx + ncy + ncz + 3);  // a ray crosses at most one plane per step
-        const long cap = max_steps + 3;                           // Rx, one point per step, at most two at the source
+        // The reference's walk has no step limit: next to a corner it can go back and forth between two planes for
+        // tens of thousands of steps before it drifts away (41 512 points for a receiver 1.7e-4 inside the far corner of
+        // a 2-D cell grid, tests/test_parity_gpu.py).  The limit only turns a walk that would never end into an error.
+        // Recording rows hold the length of an ordinary ray; a longer one is traced again with the room it asked for.
+        const long max_steps = walk_step_limit;
+        const long cap = std::min<long>(max_steps, 8L * ((long)ncx + ncy + ncz + 3)) + 3;   // Rx, one point per step, <= two at the source
         // receivers in chunks: the recording buffer stays below 256 MiB
         const int chunk = record ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (sizeof(T) * nc * cap))) : n;
         std::vector<int> st(chunk), np(chunk);
@@ -1224,7 +1230,7 @@ class GridT : public GridBase {
             if (record) HIP_CHECK(hipMemcpyAsync(np.data(), d_raynp.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             for (int q = 0; q < m; ++q)
-                if (st[q] != 0) throw_walk_error(st[q], pc + (size_t)nc * q, txp, max_steps);
+                if (st[q] != 0 && st[q] != 3) throw_walk_error(st[q], pc + (size_t)nc * q, txp, max_steps);
             if (record) {
                 off[0] = 0;
                 for (int q = 0; q < m; ++q) off[q + 1] = off[q] + np[q];
@@ -1238,6 +1244,30 @@ class GridT : public GridBase {
                 else
                     fsm_compact_rays2<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p);
                 HIP_CHECK(hipGetLastError());
+                for (int q = 0; q < m; ++q) {   // rays longer than a row (status 3): once more, alone, with room
+                    if (st[q] != 3) continue;
+                    const long need = (long)np[q] + 1;
+                    d_raylong.reserve((size_t)need * nc);
+                    const long long off2[2] = {off[q], off[q + 1]};
+                    d_rayoff2.reserve(2);
+                    HIP_CHECK(hipMemcpyAsync(d_rayoff2.p, off2, sizeof(off2), hipMemcpyHostToDevice, stream));
+                    if (dim == 3) {
+                        fsm_raypath3d<T, true><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * q, 1,
+                                                                     d_out.p + q, d_rstat.p + q, max_steps, d_raylong.p, need, d_raynp.p + q);
+                        fsm_compact_rays<T><<<1, 128, 0, stream>>>(d_raylong.p, need, d_rayoff2.p, d_raydense.p, translate ? ox : (T)0,
+                                                                   translate ? oy : (T)0, translate ? oz : (T)0);
+                    } else {
+                        fsm_raypath2d<T, true><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, cell_s, rg2, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * q,
+                                                                     1, d_out.p + q, d_rstat.p + q, max_steps, d_raylong.p, need, d_raynp.p + q);
+                        fsm_compact_rays2<T><<<1, 128, 0, stream>>>(d_raylong.p, need, d_rayoff2.p, d_raydense.p);
+                    }
+                    HIP_CHECK(hipGetLastError());
+                    int st2 = 0, np2 = 0;
+                    HIP_CHECK(hipMemcpyAsync(&st2, d_rstat.p + q, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipMemcpyAsync(&np2, d_raynp.p + q, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));   // (also: off2 goes out of scope)
+                    if (st2 != 0 || np2 != np[q]) throw DeviceError("raypath: a long ray did not retrace to the same length");
+                }
                 // the rays of this source, kept apart: raytrace_multi strings the sources together in SOURCE order
                 // once every round is done (the solve order is round-major, i.e. interleaved when n_slots < n_src)
                 const size_t base = ray_pts->size();
@@ -1252,7 +1282,9 @@ class GridT : public GridBase {
     // rays of the last raytrace call with return_rays on, in the order of the receiver rows of that call
     std::vector<long long> rays_off{0};
     std::vector<T> rays_pts;
-    DevBuf<T> d_raypts, d_raydense;
+    DevBuf<T> d_raypts, d_raydense, d_raylong;
+    DevBuf<long long> d_rayoff2;
+    long walk_step_limit = 1000000;   // steps after which a ray walk is declared endless (the oracle uses the same number)
     DevBuf<int> d_raynp;
     DevBuf<long long> d_rayoff;
 

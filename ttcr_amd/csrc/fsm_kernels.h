@@ -630,6 +630,9 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 #ifndef FSM_MINW
 #define FSM_MINW 1
 #endif
+#ifndef FSM_EXPERIMENT_NOSYNC
+#define FSM_EXPERIMENT_NOSYNC 0
+#endif
 #ifndef FSM_EARLY_PUB
 #define FSM_EARLY_PUB 0   // first chunks of a unit whose progress is published right after their write-back
 #endif
@@ -730,11 +733,14 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned pchunks = 0;
     const unsigned long long trace_t0 = prof_t;
+    unsigned long long* prec = nullptr;   // set once the ticket is known
 #define FSM_PMARK(slot_)                                                          \
     if (FSM_ENABLE_PROF && a.prof && tid == 0) {                                  \
         const unsigned long long now_ = wall_clock64();                           \
         pacc[slot_] += now_ - prof_t;                                             \
         prof_t = now_;                                                            \
+        /* per-chunk stamps of the first units (chunk record region of the trace buffer) */ \
+        if ((slot_) < 5 && prec && pchunks < 80u) prec[pchunks * 5u + (slot_)] = now_; \
     }
     const int NF = a.g.NF, NJ = a.g.NJ, NK = a.g.NK;
     const int npj = a.g.npj;
@@ -766,6 +772,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     // unit comes after its upwind patches and after the patches of the previous sweep it has to see finished
     const int oidx = ticket / pa.batch, z = ticket - oidx * pa.batch;
     if (oidx >= (XS ? pa.n_patches * pa.ndir : pa.n_patches)) return;
+    if (FSM_ENABLE_PROF && a.prof && ticket < 8192) prec = a.prof + 8 + 4 * 65536 + (size_t)ticket * 400;
     const uint32_t tile = pa.order[oidx];
     const int dir = XS ? (int)(tile >> 28) : pa.dir;
     const int TJ = XS ? (int)(tile & 0x3fffu) : (int)(tile & 0xffffu), TK = XS ? (int)((tile >> 14) & 0x3fffu) : (int)(tile >> 16);
@@ -2129,7 +2136,9 @@ template <typename T>
 __global__ void fsm_compact_rays(const T* __restrict__ pts, long cap, const long long* __restrict__ off,
                                  T* __restrict__ out, T ox, T oy, T oz) {
     const int r = blockIdx.x;
-    const long long a = off[r], n = off[r + 1] - a;
+    const long long a = off[r];
+    long long n = off[r + 1] - a;
+    n = n > cap ? cap : n;   // (a ray longer than its row is traced again with room and copied by a launch of its own)
     const T* src = pts + (size_t)r * cap * 3;
     for (long long i = threadIdx.x; i < 3 * n; i += blockDim.x) {
         const int c = (int)(i % 3);
@@ -2425,7 +2434,9 @@ __global__ void fsm_raypath2d(const T* __restrict__ Tn, int ts, const T* __restr
 template <typename T>
 __global__ void fsm_compact_rays2(const T* __restrict__ pts, long cap, const long long* __restrict__ off, T* __restrict__ out) {
     const int r = blockIdx.x;
-    const long long a = off[r], n = off[r + 1] - a;
+    const long long a = off[r];
+    long long n = off[r + 1] - a;
+    n = n > cap ? cap : n;
     const T* src = pts + (size_t)r * cap * 2;
     for (long long i = threadIdx.x; i < 2 * n; i += blockDim.x) out[2 * a + i] = src[i];
 }
