@@ -172,6 +172,16 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points);
 int ttcr_fsm_get_rays(const ttcr_fsm_grid* g, long long* offsets, void* pts);
 
+/* NOT provided (reference overloads without an entry point here):
+ *   - raytrace with l_data (ray projection matrix L): ttcrpy itself raises "compute_L not implemented for FSM"
+ *     (src/ttcrpy/rgrid.pyx:916-917);
+ *   - raytrace with m_data (velocity-derivative matrix M, `compute_M`): Grid3Drn::getRaypath(..., m_data, ...)
+ *     (ttcr/Grid3Drn.h:1503-1800) overwrites prev_pt with curr_pt BEFORE it forms the segment mid-point and length
+ *     (:1589-1597), so every interior segment contributes -s^2 * 0 * w and only the last hop carries weight, and its
+ *     weights index one node past the grid on the max faces: reproducing that bit for bit would pin a defect.
+ *   A binding must refuse both (the adapters in integration/ throw, ttcr_amd/rgrid.py raises NotImplementedError);
+ *   TTCR_ERR_UNSUPPORTED is reserved for an entry point that would take such a request. */
+
 typedef struct {
     double sweep_ms;        /* HIP-event time of all sweep launches of the last raytrace call   */
     double total_ms;        /* wall time of the last raytrace call (host clock, incl. copies)  */

@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU-box script: full -m gpu suite, bench line, rocprofv3 kernel stats + PMC traffic of the bench command (profiles/r02)
-O=gpurun_out/r2f; mkdir -p $O
+# GPU-box script run at the end of a round: full -m gpu suite, bench line, rocprofv3 kernel stats + PMC traffic of the bench command
+O=gpurun_out/round_end; mkdir -p $O
 (time python -m pytest tests -m gpu -x -q --durations=8) > $O/pytest.txt 2>&1
 tail -12 $O/pytest.txt
 python bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err; tail -c 2500 $O/bench.json

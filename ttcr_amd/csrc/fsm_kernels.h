@@ -630,9 +630,6 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 #ifndef FSM_MINW
 #define FSM_MINW 1
 #endif
-#ifndef FSM_EXPERIMENT_NOSYNC
-#define FSM_EXPERIMENT_NOSYNC 0
-#endif
 #ifndef FSM_EARLY_PUB
 #define FSM_EARLY_PUB 0   // first chunks of a unit whose progress is published right after their write-back
 #endif
