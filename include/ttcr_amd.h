@@ -19,9 +19,12 @@
  *     device until the next solve in the same slot (ttcr/Node3Dn.h:109-110).
  *   - threads: every entry point that takes a grid locks that grid (one stream, one captured launch
  *     sequence and the pinned / scratch buffers are shared by its slots), so calls on ONE handle from several
- *     host threads -- ttcrpy's raytrace(..., thread_no=k) pattern -- are safe and run one after the other;
- *     sources that should run side by side on the device go into one ttcr_fsm_raytrace_multi call.  Different
- *     handles are independent.  ttcr_fsm_last_error() is per host thread.
+ *     host threads are safe.  Single-source ttcr_fsm_raytrace calls that arrive together on a grid with several
+ *     slots -- the way Grid3D's multi-source overload reaches a backend: nt host threads, each with its own
+ *     threadNo (ttcr/Grid3D.h:810-853) -- are gathered for a short window (option "combine_window_us", default 200)
+ *     and solved as ONE device batch, side by side like a ttcr_fsm_raytrace_multi call; every caller gets its own
+ *     status and message.  Other calls on one handle run one after the other.  Different handles are independent.
+ *     ttcr_fsm_last_error() is per host thread.
  */
 #ifndef TTCR_AMD_H
 #define TTCR_AMD_H
@@ -142,6 +145,8 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "fixed_iters"  > 0: run exactly that many sweep-iterations, ignore eps
  *   "max_batch"    sources swept concurrently by one launch sequence (default: n_slots)
  *   "use_graph"    1: replay the per-iteration launch sequence from a hipGraph (default 1)
+ *   "combine_window_us"  single-source calls from several host threads wait this long for one another before they go
+ *                  to the device as one batch (default 200; 0: every call on its own)
  *   "mode"         2: persistent sweep kernel, ONE launch per sweep-iteration: patches ordered by
  *                     progress counters in HBM, the next directional sweep starts on the patches the
  *                     previous one has finished (default); 1: same kernel, one launch per directional

@@ -638,3 +638,59 @@ def test_hip_device_views_of_a_field():
             pair = sink2.get_slowness().flatten("F").reshape(nn, 2)
             np.testing.assert_array_equal(pair[:, 0], fields[0])
             np.testing.assert_array_equal(pair[:, 1], fields[1])
+
+
+def test_hip_concurrent_single_source_calls_are_combined_and_isolated(oracle):
+    """The way Grid3D's multi-source overload reaches a backend (ttcr/Grid3D.h:810-853): nt host threads, each calling the
+    single-source entry point with its own slot.  The library gathers calls that arrive together into one device batch;
+    every caller must get its own traveltimes / iteration count, and a call with a point outside the grid must fail
+    alone (TTCR_ERR_RUNTIME + the reference's text in ITS thread's last_error), the others unharmed."""
+    import ctypes as C
+    import threading
+
+    import ttcr_amd
+    from ttcr_amd import _lib
+
+    L = _lib.load()
+    n = 36
+    x = np.arange(n) * 0.5
+    rng = np.random.default_rng(43)
+    s = rng.uniform(0.3, 1.0, (n, n, n)).astype(np.float32)
+    nthr = 8
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32)
+    g.set_slowness(s)
+    srcs = rng.uniform(0.5, 17.0, (nthr, 3)).astype(np.float32)
+    rcv = rng.uniform(0.0, 17.5, (5, 3)).astype(np.float32)
+    bad = 3   # this caller's last receiver lies outside the grid
+    results = [None] * nthr
+    barrier = threading.Barrier(nthr)
+
+    def work(k):
+        tx = np.ascontiguousarray(srcs[k:k + 1])
+        t0 = np.zeros(1, dtype=np.float32)
+        rx = rcv.copy()
+        if k == bad:
+            rx[-1] = [5.0, 5.0, 17.6]
+        out = np.full(5, -1.0, dtype=np.float32)
+        barrier.wait()   # arrive together
+        st = L.ttcr_fsm_raytrace(g._h, k, 1, tx.ctypes.data_as(C.c_void_p), t0.ctypes.data_as(C.c_void_p), 5,
+                                 rx.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        results[k] = (st, L.ttcr_fsm_last_error().decode() if st else "", out)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(nthr)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(nthr):
+        st, msg, out = results[k]
+        if k == bad:
+            assert st == _lib.ERR_RUNTIME and msg == "Error: Point (5 5 17.6) outside grid.", (st, msg)
+            continue
+        assert st == 0, msg
+        o = oracle.solve3d(np.float32, (n - 1,) * 3, 0.5, (0, 0, 0), s.flatten("F"), srcs[k:k + 1], rcv=rcv)
+        np.testing.assert_array_equal(out, o["tt_rcv"])
+        np.testing.assert_array_equal(g._flat_tt(k), o["tt"])
+        assert g.get_niter(k) == o["niter"]
+    # the calls really went to the device together: the last batch held more than one source
+    assert g.timing()["n_sources"] > 1

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -78,8 +79,26 @@ class GridBase {
     virtual ~GridBase() {}
     virtual void set_slowness(const void* s, size_t n, bool on_device, bool c_order = false) = 0;
     virtual void get_slowness(void* out, size_t n) = 0;
+    // explicit_slots (optional): source n is solved in slot explicit_slots[n] (ascending, distinct) -- the combined
+    // single-source calls of several host threads; otherwise the sources are block-distributed like get_blk_size
     virtual void raytrace_multi(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
-                                const void* rx, void* tt_out, int forced_slot) = 0;
+                                const void* rx, void* tt_out, int forced_slot, const int* explicit_slots = nullptr) = 0;
+    virtual void validate_points(int n_tx, const void* tx, int n_rx, const void* rx) = 0;   // throws like raytrace would
+    // single-source calls that arrive together (ttcrpy's thread pool: nt host threads, one slot each) are solved together
+    struct Request {
+        int slot, n_tx, n_rx;
+        const void *tx, *t0, *rx;
+        void* tt;
+        int status = TTCR_OK;
+        std::string err;
+        bool done = false;
+    };
+    std::mutex q_mu;
+    std::condition_variable q_cv;
+    std::vector<Request*> queue;
+    bool leader_active = false;
+    int combine_window_us = 200;   // how long a call waits for company (option "combine_window_us"; 0: never)
+    size_t elem_size = 4;
     virtual void get_tt(int slot, void* out, size_t n) = 0;
     virtual void* tt_device(int slot) = 0;                      // contiguous copy of the field (see ttcr_amd.h)
     virtual void* tt_device_view(int slot, size_t* stride) = 0;  // the field where it lies + its element stride
@@ -184,6 +203,7 @@ class GridT : public GridBase {
           double miny, double minz, double eps, int maxit, int nslots, bool translate_, int dev) {
         dim = dim_;
         dtype = sizeof(T) == 4 ? TTCR_F32 : TTCR_F64;
+        elem_size = sizeof(T);
         cell = cell_;
         translate = translate_;
         ncx = nx; ncy = ny; ncz = nz;
@@ -1298,8 +1318,20 @@ class GridT : public GridBase {
     }
 
     // Grid3D::raytrace multi-source overload (ttcr/Grid3D.h:810-853)
+    void validate_points(int n_tx, const void* tx_v, int n_rx, const void* rx_v) override {
+        const int nc = ncoord();
+        if (n_tx <= 0) throw ValueError("every source needs at least one point");
+        std::vector<T> tx((const T*)tx_v, (const T*)tx_v + (size_t)nc * n_tx), rx((const T*)rx_v, (const T*)rx_v + (size_t)nc * std::max(n_rx, 0));
+        if (translate) {
+            for (int m = 0; m < n_tx; ++m) { tx[3 * m] -= ox; tx[3 * m + 1] -= oy; tx[3 * m + 2] -= oz; }
+            for (int m = 0; m < n_rx; ++m) { rx[3 * m] -= ox; rx[3 * m + 1] -= oy; rx[3 * m + 2] -= oz; }
+        }
+        check_pts(tx.data(), n_tx);
+        check_pts(rx.data(), n_rx);
+    }
+
     void raytrace_multi(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off,
-                        const void* rx_v, void* tt_out_v, int forced_slot) override {
+                        const void* rx_v, void* tt_out_v, int forced_slot, const int* explicit_slots = nullptr) override {
         HIP_CHECK(hipSetDevice(device));
         const auto wall0 = std::chrono::steady_clock::now();
         timing = Timing();
@@ -1327,8 +1359,13 @@ class GridT : public GridBase {
             check_pts(tx.data() + (size_t)nc * tx_off[n], tx_off[n + 1] - tx_off[n]);
             check_pts(rx.data() + (size_t)nc * rx_off[n], rx_off[n + 1] - rx_off[n]);
         }
+        if (explicit_slots)
+            for (int n = 0; n < n_src; ++n) {
+                check_slot(explicit_slots[n]);
+                if (n > 0 && explicit_slots[n] <= explicit_slots[n - 1]) throw ValueError("explicit slots must be ascending and distinct");
+            }
         // block distribution of the sources over the slots: get_blk_size (ttcr/Grid3D.h:451-465)
-        const int n_blk = std::min(n_slots, n_src);
+        const int n_blk = explicit_slots ? n_src : std::min(n_slots, n_src);
         std::vector<int> blk(n_blk, 0);
         for (int n = 0; n < n_src; ++n) blk[n % n_blk] += 1;
         std::vector<int> start(n_blk, 0);
@@ -1340,7 +1377,7 @@ class GridT : public GridBase {
         for (int r = 0; r < rounds; ++r) {
             std::vector<int> slots, srcs;
             for (int b = 0; b < n_blk; ++b)
-                if (r < blk[b]) { slots.push_back(forced_slot >= 0 ? forced_slot : b); srcs.push_back(start[b] + r); }
+                if (r < blk[b]) { slots.push_back(forced_slot >= 0 ? forced_slot : (explicit_slots ? explicit_slots[b] : b)); srcs.push_back(start[b] + r); }
             for (size_t c0 = 0; c0 < slots.size(); c0 += mb) {
                 const size_t c1 = std::min(slots.size(), c0 + mb);
                 std::vector<int> sl(slots.begin() + c0, slots.begin() + c1), sr(srcs.begin() + c0, srcs.begin() + c1);
@@ -1499,13 +1536,98 @@ int ttcr_fsm_get_slowness(ttcr_fsm_grid* g, void* out, size_t n) {
     return guarded_on(g, [&] { g->impl->get_slowness(out, n); });
 }
 
+// One batch of combined requests (distinct slots): every request is validated on its own (a point outside the grid fails
+// that call only), the valid ones go to the device as ONE multi-source solve with their slots, results are copied back.
+static void run_combined(GridBase* gb, std::vector<GridBase::Request*>& batch) {
+    std::vector<GridBase::Request*> ok;
+    for (auto* r : batch) {
+        try {
+            if (r->slot < 0 || r->slot >= gb->n_slots) throw ValueError("Thread number is larger than number of threads");
+            gb->validate_points(r->n_tx, r->tx, r->n_rx, r->rx);
+            ok.push_back(r);
+        } catch (const ValueError& e) { r->status = TTCR_ERR_VALUE; r->err = e.what();
+        } catch (const std::exception& e) { r->status = TTCR_ERR_RUNTIME; r->err = e.what(); }
+    }
+    if (ok.empty()) return;
+    std::sort(ok.begin(), ok.end(), [](const GridBase::Request* a, const GridBase::Request* b) { return a->slot < b->slot; });
+    const size_t es = gb->elem_size, nc = gb->dim == 3 ? 3 : 2;
+    std::vector<int> tx_off(ok.size() + 1, 0), rx_off(ok.size() + 1, 0), slots(ok.size());
+    for (size_t n = 0; n < ok.size(); ++n) {
+        tx_off[n + 1] = tx_off[n] + ok[n]->n_tx;
+        rx_off[n + 1] = rx_off[n] + std::max(ok[n]->n_rx, 0);
+        slots[n] = ok[n]->slot;
+    }
+    std::vector<char> tx(es * nc * tx_off.back()), t0(es * tx_off.back()), rx(es * nc * std::max(rx_off.back(), 1)), tt(es * std::max(rx_off.back(), 1));
+    for (size_t n = 0; n < ok.size(); ++n) {
+        std::memcpy(tx.data() + es * nc * tx_off[n], ok[n]->tx, es * nc * ok[n]->n_tx);
+        std::memcpy(t0.data() + es * tx_off[n], ok[n]->t0, es * ok[n]->n_tx);
+        if (ok[n]->n_rx > 0) std::memcpy(rx.data() + es * nc * rx_off[n], ok[n]->rx, es * nc * ok[n]->n_rx);
+    }
+    int st = TTCR_OK;
+    std::string msg;
+    try {
+        gb->raytrace_multi((int)ok.size(), tx_off.data(), tx.data(), t0.data(), rx_off.data(), rx.data(), tt.data(), -1, slots.data());
+    } catch (const ValueError& e) { st = TTCR_ERR_VALUE; msg = e.what();
+    } catch (const DeviceError& e) { st = TTCR_ERR_DEVICE; msg = e.what();
+    } catch (const std::exception& e) { st = TTCR_ERR_RUNTIME; msg = e.what(); }
+    for (size_t n = 0; n < ok.size(); ++n) {
+        ok[n]->status = st;
+        ok[n]->err = msg;
+        if (st == TTCR_OK && ok[n]->n_rx > 0) std::memcpy(ok[n]->tt, tt.data() + es * rx_off[n], es * ok[n]->n_rx);
+    }
+}
+
 int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
                       void* tt_out) {
-    return guarded_on(g, [&] {
-        if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
-        const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
-        g->impl->raytrace_multi(1, tx_off, tx, t0, rx_off, rx, tt_out, slot);
-    });
+    if (!g) { g_last_error = "null grid handle"; return TTCR_ERR_VALUE; }
+    GridBase* gb = g->impl.get();
+    if (gb->n_slots <= 1 || gb->combine_window_us <= 0 || gb->return_rays) {   // (rays belong to "the last call": no company)
+        return guarded_on(g, [&] {
+            if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
+            const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
+            g->impl->raytrace_multi(1, tx_off, tx, t0, rx_off, rx, tt_out, slot);
+        });
+    }
+    // Grid3D's multi-source overload (ttcr/Grid3D.h:810-853) reaches a backend as nt host threads, each calling the
+    // single-source raytrace with its own threadNo.  Calls that arrive within a short window are gathered by the first
+    // one (the leader) and go to the device as ONE batch -- the sources then run side by side like in
+    // ttcr_fsm_raytrace_multi instead of one after the other.
+    GridBase::Request req{slot, n_tx, n_rx, tx, t0, rx, tt_out};
+    std::unique_lock<std::mutex> lk(gb->q_mu);
+    gb->queue.push_back(&req);
+    gb->q_cv.notify_all();
+    while (!req.done) {
+        if (gb->leader_active) { gb->q_cv.wait(lk); continue; }
+        gb->leader_active = true;
+        const auto window = std::chrono::microseconds(gb->combine_window_us);
+        size_t seen = gb->queue.size();
+        while ((int)gb->queue.size() < gb->n_slots) {   // wait for company until nothing new arrives for one window
+            gb->q_cv.wait_for(lk, window);
+            if (gb->queue.size() == seen) break;
+            seen = gb->queue.size();
+        }
+        std::vector<GridBase::Request*> batch, rest;
+        std::vector<char> taken(gb->n_slots > 0 ? gb->n_slots : 1, 0);
+        for (auto* r : gb->queue) {   // one request per slot and batch; a second one for the same slot waits for the next round
+            const bool dup = r->slot >= 0 && r->slot < gb->n_slots && taken[r->slot];
+            if (dup) { rest.push_back(r); continue; }
+            if (r->slot >= 0 && r->slot < gb->n_slots) taken[r->slot] = 1;
+            batch.push_back(r);
+        }
+        gb->queue.swap(rest);
+        lk.unlock();
+        {
+            std::lock_guard<std::mutex> hl(gb->mu);
+            run_combined(gb, batch);
+        }
+        lk.lock();
+        for (auto* r : batch) r->done = true;
+        gb->leader_active = false;
+        gb->q_cv.notify_all();
+    }
+    lk.unlock();
+    if (req.status != TTCR_OK) g_last_error = req.err;
+    return req.status;
 }
 
 int ttcr_fsm_raytrace_multi(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0,
@@ -1551,6 +1673,7 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
         if (k == "fixed_iters") g->impl->fixed_iters = (int)value;
         else if (k == "max_batch") g->impl->max_batch = (int)value;
         else if (k == "use_graph") g->impl->use_graph = value != 0;
+        else if (k == "combine_window_us") g->impl->combine_window_us = (int)value;
         else if (k == "mode") g->impl->mode = (int)value;
         else if (k == "skip") g->impl->skip = (int)value;
         else if (k == "tt_from_rp") {
