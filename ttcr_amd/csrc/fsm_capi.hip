@@ -432,7 +432,7 @@ class GridT : public GridBase {
         pa.evals = d_evals.p;
         pa.nbf = nbf; pa.nbj = nbj; pa.nbk = nbk;
         pa.ndir = DIM == 3 ? 8 : 4;
-        pa.skip = skip;
+        pa.skip = skip_now();
 
         const dim3 block(C::PJ * C::PK), grid((unsigned)n_patches * batch);
         const int ndir = DIM == 3 ? 8 : 4;
@@ -448,7 +448,7 @@ class GridT : public GridBase {
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
-            if (skip)
+            if (skip_now())
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
             else if (DIM == 2 || batch >= pre_min)   // counters sampled one chunk ahead (template PRE)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, 0, stream>>>(pa);
@@ -476,7 +476,7 @@ class GridT : public GridBase {
             // ticket + progress counters back to zero (the abort word [1] is sticky within an iteration)
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
-            if (skip)
+            if (skip_now())
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, false><<<grid, block, 0, stream>>>(pa);
             else
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, false><<<grid, block, 0, stream>>>(pa);
@@ -766,6 +766,8 @@ class GridT : public GridBase {
 
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
     bool persistent_now() const { return mode >= 1 || stage == 1; }
+    // the rotated-template sweeps change nodes without stamping their bricks: no skipping next to them
+    bool skip_now() const { return skip != 0 && !(dim == 2 && rotated && !weno && dx == dz); }
 
     // Grid2Drn::sweep45 for every source of the batch (entries as handed to the sweep kernels)
     void launch_sweep45(int batch) {
@@ -818,7 +820,7 @@ class GridT : public GridBase {
         if (use_graph) {
             hipGraph_t& graph = graphs[stage];
             hipGraphExec_t& graph_exec = graph_execs[stage];
-            const int key = mode * 2 + skip;
+            const int key = mode * 2 + (skip_now() ? 1 : 0);
             if (!graph_exec || graph_batches[stage] != batch || graph_modes[stage] != key) {
                 if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
                 if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
@@ -964,10 +966,12 @@ class GridT : public GridBase {
                 active.swap(next);
             }
             timing.iterations = std::max(timing.iterations, it_total);
-            // the stamps of the first-order stage say nothing about the WENO stencil: start clean
-            if (stage == 0 && weno && skip) {
+            // the stamps of the first-order stage say nothing about the WENO stencil: every brick counts as changed in the
+            // last sweep, so that the first WENO sweep visits every node once with the new formula
+            if (stage == 0 && weno && skip_now()) {
                 for (int s2 : slot_ids)
-                    HIP_CHECK(hipMemsetAsync(d_stamp.p + (size_t)(s2 / NS) * n_bricks, 0x7f, n_bricks * sizeof(int), stream));
+                    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(d_stamp.p + (size_t)(s2 / NS) * n_bricks), it_total * (dim == 3 ? 8 : 4),
+                                                n_bricks, stream));
             }
         }
         const bool was_persistent = mode >= 1 || weno;

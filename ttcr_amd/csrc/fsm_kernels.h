@@ -969,11 +969,12 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         }
     };
 
-    // dirty-brick tracking: sigma = global sweep number (1-based); the same chunk was last evaluated
-    // at sigma - ndir.  If no brick of its read set changed at or after that sweep (or ever, in the
-    // first iteration) the chunk would reproduce the values that are already there: skip it.
+    // dirty-brick tracking: sigma = global sweep number (1-based).  The local update is a function of the six (2-D: four)
+    // neighbours only -- the sweep direction orders the visits, it does not enter the formula -- so a node that was visited
+    // in sweep sigma-1 and whose neighbours have not changed since satisfies T <= update(neighbours) already.  A chunk is a
+    // no-op when no brick of its read set (own nodes + halo) changed during sweep sigma-1 or so far in this sweep.
     const int sigma = SKIP ? pa.ndir * pa.iter_ptr[0] + dir + 1 : 0;
-    const int thr = sigma - pa.ndir > 0 ? sigma - pa.ndir : 0;
+    const int thr = sigma - 1 > 0 ? sigma - 1 : 0;
     int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;   // one stamp set per group
     // natural J / K extent of the read set (own + halo columns), fixed for the whole patch
     int rs_jlo, rs_jhi, rs_klo, rs_khi;
