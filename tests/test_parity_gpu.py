@@ -225,11 +225,15 @@ def test_hip_weno_wide_batch(oracle, dt):
 
 @pytest.mark.parametrize("weno", [0, 1], ids=["first-order", "weno3"])
 @pytest.mark.parametrize("n_threads", [2, 3])
-def test_hip_multi_source_batches(oracle, weno, n_threads):
+@pytest.mark.parametrize("pair", ["default", "0"], ids=["pairs", "unpaired"])
+def test_hip_multi_source_batches(oracle, monkeypatch, weno, n_threads, pair):
     """Several sources solved concurrently (slots = the reference's threads; two sources of a slot
-    group are marched together from an interleaved field): every slot's field, iteration counts and
-    receiver values must equal the single-source solves of the oracle."""
+    group are marched together from an interleaved field -- the 3-D default -- or every slot has its own field):
+    every slot's field, iteration counts and receiver values must equal the single-source solves of the oracle."""
     import ttcr_amd
+
+    if pair != "default":
+        monkeypatch.setenv("TTCR_FSM_PAIR", pair)
 
     rng = np.random.default_rng(17)
     nn = (41, 37, 29)
@@ -260,8 +264,14 @@ def test_hip_multi_source_batches(oracle, weno, n_threads):
         assert g.get_niter(slot) == outs[n]["niter"] and g.get_niterw(slot) == outs[n]["niterw"]
 
 
-def test_hip_multi_source_2d(oracle):
+@pytest.mark.parametrize("pair", ["default", "1"], ids=["unpaired", "pairs"])
+def test_hip_multi_source_2d(oracle, monkeypatch, pair):
+    """2-D slots have their own fields by default (the one-wave patches gain nothing from pairs); the pair layout
+    stays selectable (TTCR_FSM_PAIR=1) and exact"""
     import ttcr_amd
+
+    if pair != "default":
+        monkeypatch.setenv("TTCR_FSM_PAIR", pair)
 
     rng = np.random.default_rng(23)
     nn = (150, 70)

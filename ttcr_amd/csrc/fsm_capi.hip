@@ -240,8 +240,11 @@ class GridT : public GridBase {
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
         d_s.reserve(n_nodes);
-        NS = n_slots >= 2 ? 2 : 1;
-        if (const char* e = std::getenv("TTCR_FSM_PAIR")) if (std::atoi(e) == 0) NS = 1;
+        // source pairs (fields interleaved, marched together) in 3-D only: the one-wave 2-D patches issue in order, a
+        // second source doubles the instructions of a level and buys nothing (4096^2: 16 sources 28.0 -> 20.8 ms,
+        // 64 sources 35.8 -> 28.9 ms, 256 sources 112 -> 87 ms unpaired; profiles/r02/pairing_2d.txt)
+        NS = (n_slots >= 2 && dim == 3) ? 2 : 1;
+        if (const char* e = std::getenv("TTCR_FSM_PAIR")) NS = (std::atoi(e) != 0 && n_slots >= 2) ? 2 : 1;
         d_tt.reserve(n_nodes * (size_t)n_groups() * NS);
         mask_words = (n_nodes + 31) / 32;
         d_mask.reserve(mask_words * (size_t)n_slots);
