@@ -75,6 +75,9 @@ __device__ __forceinline__ double sqrt_disc(double x) {
     double h = 0.5 * y;
     double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
+#ifdef FSM_SQRT_SHORT_EXPERIMENT
+    return x == 0.0 ? x : g;
+#endif
     h = __builtin_fma(h, e, h);
     double d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
@@ -806,6 +809,56 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     const int jmaxp = (j0 + PJ < NJ ? j0 + PJ : NJ) - 1;
     const int kmaxp = (k0 + PK < NK ? k0 + PK : NK) - 1;
     const int Ls = j0 + k0, Le = jmaxp + kmaxp + NF - 1;  // levels at which the patch has nodes
+    // 2-D, sweeps 1 and 3 (-x+z after +x+z, +x-z after -x-z): only the J direction flips, the columns are walked the same
+    // way as in the sweep before.  Such a unit does not wait for the previous sweep to FINISH the patches around it (they
+    // are the last ones of that sweep): it follows them up the columns, chunk by chunk.  Lanes 1..3 of the (one-wave)
+    // workgroup each watch the counter of one patch of the previous sweep that owns a column within 2H of ours; a chunk
+    // that touches oriented F indices <= ilim may run once that patch has published every level <= ilim + (its last
+    // column index, halo included) + H + C: then every node the chunk reads is final there, and every read the previous
+    // sweep makes of the nodes the chunk writes is over (its chunks are C levels long).
+    constexpr bool CHASE_OK = XS && !IS3D && !SKIP && NT == 64;
+    const bool chase = CHASE_OK && (dir == 1 || dir == 3);
+    const int* chase_ptr = nullptr;
+    int chase_add = 0;
+    if (CHASE_OK && chase && tid >= 1 && tid <= 3) {
+        int ja = j0 - 2 * H, jb = jmaxp + 2 * H;
+        ja = ja < 0 ? 0 : ja;
+        jb = jb > NJ - 1 ? NJ - 1 : jb;
+        const int ja2 = NJ - 1 - jb, jb2 = NJ - 1 - ja;     // the same columns, oriented as in the previous sweep
+        const int tja = ja2 / PJ, ntj = jb2 / PJ - tja + 1;
+        if (tid - 1 < ntj) {
+            const int q = tja + tid - 1;
+            const int qmax = (q * PJ + PJ < NJ ? q * PJ + PJ : NJ) - 1;
+            chase_ptr = pa.sync + 2 + ((size_t)(dir - 1) * pa.batch + z) * pa.n_patches + q;
+            chase_add = qmax + 3 * H + C + 1;
+        }
+    }
+    // wait of a chasing unit before the chunk that starts at level L0 (and the prefetch of the one after it): lane 0 the
+    // upwind patch of this sweep (unless first_only), lanes 1..3 the previous sweep.  `sample`: value read ahead of time.
+    auto chase_wait = [&](int L0, int sample, bool with_upwind) {
+        int ilim = L0 + 2 * C + 2 * H - 1 - j0;
+        ilim = ilim > NF - 1 ? NF - 1 : ilim;
+        const int* wp = tid == 0 ? (with_upwind ? up_j : nullptr) : chase_ptr;
+        const int need = tid == 0 ? L0 + C - 1 : ilim + chase_add;
+        bool ok = !wp || sample >= need;
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+            unsigned long long t0 = 0;
+            int spins = 0;
+            for (;;) {
+                if (!ok) ok = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                if (spins == 0) t0 = wall_clock64();
+                if ((++spins & 63) == 0) {
+                    if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (wall_clock64() - t0 > pa.timeout_ticks) {
+                        if (tid == 0) __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    };
     P* __restrict__ Tg = reinterpret_cast<P*>(a.tt) + (size_t)grp * a.g.n_nodes;
     const T INF = real_traits<T>::inf();
     const P PINF = pack_fill<T, NS>(INF);
@@ -1021,7 +1074,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             near_hi[l] = jk ? b1 + jmaxp + kmaxp : 0;
         }
     }
-    if (XS && dir > 0) {
+    if (XS && dir > 0 && !chase) {
         // previous sweep of this iteration: wait for the patches (of ITS oriented partition) that own
         // a column within 2H of ours -- at most 3 x 3 of them, one lane each
         if (tid < 16) {
@@ -1043,6 +1096,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         }
         __syncthreads();
     }
+    if (CHASE_OK && chase) chase_wait(Lc - C, -1, false);   // (covers the prefetch of the first chunk)
     if (!SKIP) { issue_static(Lc); pref_for = Lc; }
     FSM_PMARK(5)   // ticket, setup, wait for the previous sweep
     const unsigned long long trace_t1 = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
@@ -1056,7 +1110,9 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         // (1) wait until both upwind patches have published every level <= L0+C-2
         //     The counters were sampled during the previous chunk's march (see below): when that old sample
         //     already suffices -- the upwind patches are normally ahead -- no load latency is paid here.
-        if (tid == 0 && (up_j || up_k) && !((up_j ? pre_j : 0x3fffffff) >= L0 + C - 1 && (up_k ? pre_k : 0x3fffffff) >= L0 + C - 1)) {
+        if (CHASE_OK && chase) {
+            chase_wait(L0, pre_j, true);
+        } else if (tid == 0 && (up_j || up_k) && !((up_j ? pre_j : 0x3fffffff) >= L0 + C - 1 && (up_k ? pre_k : 0x3fffffff) >= L0 + C - 1)) {
             const int need = L0 + C - 1;
             unsigned long long t0 = 0;   // the clock is only read once a poll has failed (the common case: none does)
             int spins = 0;
@@ -1177,6 +1233,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             if (up_j) pre_j = __hip_atomic_load(up_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (up_k) pre_k = __hip_atomic_load(up_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (PRE && CHASE_OK && chase_ptr && Lc + C <= Le)   // lanes 1..3 of a chasing unit: their patch of the previous sweep
+            pre_j = __hip_atomic_load(chase_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         bool near_src[NS];
 #pragma unroll
