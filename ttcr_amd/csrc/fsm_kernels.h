@@ -75,15 +75,25 @@ __device__ __forceinline__ double sqrt_disc(double x) {
     double h = 0.5 * y;
     double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
-#ifdef FSM_SQRT_SHORT_EXPERIMENT
-    return x == 0.0 ? x : g;
-#endif
     h = __builtin_fma(h, e, h);
     double d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
     d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
     return x == 0.0 ? x : g;
+}
+// the same for arguments that are positive wherever the result is used (NaN elsewhere is fine): no zero fix-up
+__device__ __forceinline__ double sqrt_disc_pos(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
 }
 
 // `live_lanes`: lane mask of the results that are used.  When no live lane of the wavefront leaves the 1-D branch
@@ -158,13 +168,17 @@ __device__ __forceinline__ double update3(double ax, double ay, double az, doubl
 // ---- 2-D local solvers ---------------------------------------------------------------------
 // Grid2Drn::update_node, ttcr/Grid2Drn.h:945-950 (square cells). a: x-axis minimum, b: z-axis.
 __device__ __forceinline__ float update2_fh(float a, float b, float fh) {
+    // both branches evaluated, one select: the one-wave 2-D march is a single dependent chain and a divergent branch
+    // costs it two exec-mask round trips per level.  Where the 1-D value is taken (|d| >= fh) the discriminant may be
+    // <= 0 and the quadratic value NaN -- it is dropped; where it is used, disc = 2 fh^2 - d^2 > fh^2 > 0.
     const float d = a - b;
-    if (__builtin_fabsf(d) >= fh) return (a < b ? a : b) + fh;
+    const float t1 = (a < b ? a : b) + fh;
     const float d2 = d * d;
     const double dfh = fh;
-    const double disc = __builtin_fma(2.0 * dfh, dfh, -(double)d2);   // finite: |d| < fh here (or NaN)
+    const double disc = __builtin_fma(2.0 * dfh, dfh, -(double)d2);
     const float sab = a + b;
-    return (float)(0.5 * ((double)sab + sqrt_disc(disc)));
+    const float t2 = (float)(0.5 * ((double)sab + sqrt_disc_pos(disc)));
+    return __builtin_fabsf(d) >= fh ? t1 : t2;
 }
 __device__ __forceinline__ double update2_fh(double a, double b, double fh) {
     if (__builtin_fabs(a - b) >= fh) return (a < b ? a : b) + fh;
