@@ -200,8 +200,9 @@ class GridT : public GridBase {
     int graph_batches[2] = {0, 0}, graph_modes[2] = {-1, -1};
 
     GridT(int dim_, bool cell_, uint32_t nx, uint32_t ny, uint32_t nz, double ddx, double ddz, double minx,
-          double miny, double minz, double eps, int maxit, int nslots, bool translate_, int dev) {
+          double miny, double minz, double eps, int maxit, int nslots, bool translate_, int dev, bool weno_) {
         dim = dim_;
+        weno = weno_;
         dtype = sizeof(T) == 4 ? TTCR_F32 : TTCR_F64;
         elem_size = sizeof(T);
         cell = cell_;
@@ -240,10 +241,12 @@ class GridT : public GridBase {
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
         d_s.reserve(n_nodes);
-        // source pairs (fields interleaved, marched together) in 3-D only: the one-wave 2-D patches issue in order, a
-        // second source doubles the instructions of a level and buys nothing (4096^2: 16 sources 28.0 -> 20.8 ms,
-        // 64 sources 35.8 -> 28.9 ms, 256 sources 112 -> 87 ms unpaired; profiles/r02/pairing_2d.txt)
-        NS = (n_slots >= 2 && dim == 3) ? 2 : 1;
+        // source pairs (fields interleaved, marched together) for the first-order 3-D solver only.  The one-wave 2-D
+        // patches issue in order, a second source doubles the instructions of a level and buys nothing (4096^2:
+        // 16 sources 28.0 -> 20.8 ms, 64 sources 35.8 -> 28.9 ms, 256 sources 112 -> 87 ms unpaired); the WENO stage
+        // is bound by its arithmetic, and pairs cost it a resident wave (256^3: 2 sources 761 -> 483 ms, 8 sources
+        // 1208 -> 973 ms, 16 sources 1740 -> 1672 ms, 64 sources 5986 -> 6221 ms).  profiles/r02/pairing.txt
+        NS = (n_slots >= 2 && dim == 3 && !weno) ? 2 : 1;
         if (const char* e = std::getenv("TTCR_FSM_PAIR")) NS = (std::atoi(e) != 0 && n_slots >= 2) ? 2 : 1;
         d_tt.reserve(n_nodes * (size_t)n_groups() * NS);
         mask_words = (n_nodes + 31) / 32;
@@ -1498,9 +1501,9 @@ int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
         const int dev = pick_device(device);
         auto g = std::make_unique<ttcr_fsm_grid>();
         if (dtype == TTCR_F32)
-            g->impl.reset(new GridT<float>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev));
+            g->impl.reset(new GridT<float>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev, weno != 0));
         else
-            g->impl.reset(new GridT<double>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev));
+            g->impl.reset(new GridT<double>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev, weno != 0));
         g->impl->weno = weno != 0;
         *out = g.release();
     });
@@ -1519,9 +1522,9 @@ int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
         const int dev = pick_device(device);
         auto g = std::make_unique<ttcr_fsm_grid>();
         if (dtype == TTCR_F32)
-            g->impl.reset(new GridT<float>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev));
+            g->impl.reset(new GridT<float>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev, weno != 0));
         else
-            g->impl.reset(new GridT<double>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev));
+            g->impl.reset(new GridT<double>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev, weno != 0));
         g->impl->weno = weno != 0;
         g->impl->rotated = rotated_template != 0;
         *out = g.release();

@@ -1071,7 +1071,9 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
     int pending = 0;            // progress value of the previous chunk, published once its stores have drained
     int n_done = 0;             // chunks of this unit evaluated so far
-    int pre_j = -1, pre_k = -1; // upwind progress counters as sampled during the previous chunk (lane 0 only)
+    int pre_j = -1, pre_k = -1; // upwind progress counters as sampled during the previous chunk (first lane of every wave)
+    P uvn[NUPI];                // upwind halo columns fetched one chunk ahead ...
+    int uvn_for = -(1 << 30);   // ... for the chunk that starts at this level
     // Chunks that may hold frozen nodes of source l: the patch overlaps the bounding box of the frozen nodes in
     // J and K, and the chunk start L0 lies in [near_lo, near_hi] (the F extent of a chunk, clamped to the grid,
     // is [L0 - jmaxp - kmaxp, L0 + C-1 - j0 - k0] in oriented i').  Worked out once per unit.
@@ -1197,12 +1199,19 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         nevals += (eb >= ea) ? (unsigned)(eb - ea + 1) : 0u;   // per active source, see the end
 
         // (2) upwind halo columns: fresh from HBM with sc1 loads (bypass L1)
+        //     -- unless this wave fetched them one chunk ahead (below), the normal case once a unit runs behind its
+        //     upwind neighbours: their latency is then off the path between two chunks
         P uv[NUPI];
+        if (PRE && uvn_for == L0) {
 #pragma unroll
-        for (int it = 0; it < NUPI; ++it) {
-            P v = PINF;
-            if ((unsigned)(L0 + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * L0));
-            uv[it] = v;
+            for (int it = 0; it < NUPI; ++it) uv[it] = uvn[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < NUPI; ++it) {
+                P v = PINF;
+                if ((unsigned)(L0 + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * L0));
+                uv[it] = v;
+            }
         }
         P xv = PINF;
         if (H == 2 && (unsigned)(L0 + xipb) < (unsigned)NF) {
@@ -1243,7 +1252,24 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         pending = 0;
         // sample the upwind counters for the NEXT chunk now: the loads complete during the march (counters only
         // grow, an old sample is a safe lower bound)
-        if (PRE && tid == 0 && Lc + C <= Le) {
+        if (PRE && Lc + C <= Le) {
+            // upwind halo of the NEXT chunk (levels L0+C-1 .. L0+2C-2), when the counters sampled for THIS chunk already
+            // cover it (every wave decides from the sample of its own first lane; a wave that cannot yet loads at the top
+            // of the next chunk as before)
+            const int need_n = L0 + 2 * C - 1;
+            const int sj = up_j ? __builtin_amdgcn_readfirstlane(pre_j) : 0x3fffffff;
+            const int sk = up_k ? __builtin_amdgcn_readfirstlane(pre_k) : 0x3fffffff;
+            if (sj >= need_n && sk >= need_n) {
+#pragma unroll
+                for (int it = 0; it < NUPI; ++it) {
+                    P v = PINF;
+                    if ((unsigned)(L0 + C + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * (L0 + C)));
+                    uvn[it] = v;
+                }
+                uvn_for = L0 + C;
+            }
+        }
+        if (PRE && (tid & 63) == 0 && Lc + C <= Le) {
             if (up_j) pre_j = __hip_atomic_load(up_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (up_k) pre_k = __hip_atomic_load(up_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
