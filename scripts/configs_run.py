@@ -50,3 +50,27 @@ tt, el, tm = run(g, np.repeat(srcs, len(rc), axis=0), np.tile(rc, (16, 1)), reps
 it = sum(g.get_niter(i) for i in range(16))
 print(f"C5 Grid2d 4096^2 nodes gradient fp32 16 sources: {el*1e3:.1f} ms wall, sweeps {tm['sweep_ms']:.1f} ms, iterations {it}, "
       f"{n*n*it/tm['sweep_ms']/1e3:.0f} Mnodes/s per sweep-iteration ({56*n*n*it/tm['sweep_ms']/1e6:.0f} GB/s algorithmic), {16/el:.1f} sources/s")
+del g
+# beyond the BASELINE configs: the 2-D solver with 1 / 64 sources, the default (WENO) 3-D path with 1 / 8 sources
+for ns in (1, 64):
+    g = ttcr_amd.Grid2d(x, x, n_threads=ns, cell_slowness=0, method='FSM', weno=0, dtype=np.float32)
+    g.set_slowness(s2)
+    srcs = cases.mt_sources(64, ndim=2)[:ns]
+    tt, el, tm = run(g, np.repeat(srcs, len(rc), axis=0), np.tile(rc, (ns, 1)), reps=2)
+    it = sum(g.get_niter(i) for i in range(ns))
+    print(f"2-D 4096^2 nodes gradient fp32 {ns} source(s): sweeps {tm['sweep_ms']:.1f} ms, iterations {it}, "
+          f"{n*n*it/tm['sweep_ms']/1e3:.0f} Mnodes/s per sweep-iteration ({56*n*n*it/tm['sweep_ms']/1e6:.0f} GB/s algorithmic = "
+          f"{56*n*n*it/tm['sweep_ms']/1e6/8000:.3f} of 8 TB/s)")
+    del g
+n = 256; dx = 20.0/(n-1); x = np.arange(n)*dx
+s = np.ascontiguousarray(np.broadcast_to((1/(1+0.1*x))[None, None, :], (n, n, n)), dtype=np.float32)
+rc = cases.rcv_lattice3d()
+for ns in (1, 8):
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=ns, cell_slowness=0, method='FSM', tt_from_rp=0, weno=1, dtype=np.float32)
+    g.set_slowness(s)
+    srcs = cases.mt_sources(64)[:ns]
+    tt, el, tm = run(g, np.repeat(srcs, len(rc), axis=0), np.tile(rc, (ns, 1)), reps=2)
+    it = sum(g.get_niter(i) + g.get_niterw(i) for i in range(ns))
+    print(f"WENO (ttcrpy default) 256^3 gradient fp32 {ns} source(s): sweeps {tm['sweep_ms']:.1f} ms, iterations (first-order + WENO, summed) {it}, "
+          f"{n**3*it/tm['sweep_ms']/1e3:.0f} Mnodes/s per sweep-iteration, {ns/el:.2f} sources/s")
+    del g

@@ -160,7 +160,7 @@ class GridT : public GridBase {
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // slot groups from which the 3-D WENO stage uses chunks of 4 levels
-    int pre_min = 4;           // 3-D: slot groups in a batch from which the upwind counters are sampled one chunk ahead (PRE)
+    int pre_min = 2;           // 3-D: slot groups in a batch from which the upwind counters are sampled one chunk ahead (PRE)
     int time_order_below = 4;  // fewer slot groups than this in a batch: the whole-iteration launch hands its units out in the
                                // order of their expected start times instead of sweep by sweep (build_persistent_lists)
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
