@@ -113,6 +113,25 @@ def profiled_traffic(n, n_src_rank0, world):
         return None, None
 
 
+def measured_copy_bandwidth(dev, reps=5):
+    """read + write bandwidth of a plain device-to-device copy of 1 GiB on this GPU (SURVEY 8d asks for the roofline
+    fraction against a measured figure as well as against the 8 TB/s peak)"""
+    import torch
+
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def single_source_leg(n, dx, x, s_dev, local_rank, reps=5):
     """The case north_star's roofline target is written for: ONE source on the same grid, same run, HIP events around the
     sweep launches of the solve (the first of the benchmark's sources, run to convergence)."""
@@ -323,6 +342,14 @@ def main():
                                          "converged solve evaluates everything and writes nothing (unchanged chunks skip their "
                                          "write-back), and this design keeps no snapshot array"},
         }
+        if world == 1:
+            try:
+                cp = measured_copy_bandwidth(dev)
+                out["roofline"]["measured_copy_GBs"] = round(cp, 1)
+                out["roofline"]["frac_of_measured_copy"] = round(achieved / cp, 4)
+            except Exception as e:   # (reported, never fatal: the contract fields above do not depend on it)
+                out["roofline"]["measured_copy_GBs"] = None
+                sys.stderr.write("copy bandwidth not measured: %s\n" % e)
         if world == 1 and not args.no_single_source:
             out["single_source"] = single_source_leg(n, dx, x, s_dev, local_rank)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only

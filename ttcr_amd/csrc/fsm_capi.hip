@@ -161,6 +161,15 @@ class GridT : public GridBase {
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // slot groups from which the 3-D WENO stage uses chunks of 4 levels
     int pre_min = 2;           // 3-D: slot groups in a batch from which the upwind counters are sampled one chunk ahead (PRE)
+    // extra (unused) dynamic LDS per workgroup of the whole-iteration launch: caps the resident workgroups per CU.  A lone
+    // source is bound by the dependent chain of a marching unit, and a unit that shares its CU's SIMDs with another
+    // marching unit runs that chain slower (TTCR_FSM_XS_LDS=bytes, TTCR_FSM_XS_LDS_BELOW=groups; 0: off)
+    // Measured, 512^3: one source 8.49 -> 7.37 ms per sweep-iteration with two workgroups per CU instead of four (7.14 with
+    // the counters sampled ahead as well), one source pair 10.5 -> 9.96; one per CU 9.95 (too few units in flight);
+    // from two slot groups on, and for the 2-D and WENO kernels, the cap does not pay (profiles/r02/occupancy_cap.txt).
+    size_t xs_lds_bytes = 40000;
+    int xs_lds_below = 2;
+    size_t xs_dyn_lds(int batch) const { return (dim == 3 && stage == 0 && batch < xs_lds_below) ? xs_lds_bytes : 0; }
     int time_order_below = 4;  // fewer slot groups than this in a batch: the whole-iteration launch hands its units out in the
                                // order of their expected start times instead of sweep by sweep (build_persistent_lists)
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
@@ -304,6 +313,8 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_TIME_ORDER_BELOW")) time_order_below = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_PRE_MIN")) pre_min = std::atoi(e);                     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
+        if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
     }
 
@@ -455,11 +466,11 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
             if (skip_now())
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
-            else if (DIM == 2 || batch >= pre_min)   // counters sampled one chunk ahead (template PRE)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
+            else if (DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0)   // counters sampled one chunk ahead (template PRE)
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
             else
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, 0, stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
             HIP_CHECK(hipGetLastError());
             return;
         }

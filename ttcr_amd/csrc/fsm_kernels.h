@@ -644,6 +644,9 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 }
 
 // ---- persistent sweep kernel, halo width H (1: first-order stage, 2: WENO3 stage) -----------
+#ifndef FSM_POLL_SLEEP
+#define FSM_POLL_SLEEP 2   // s_sleep argument (x64 clocks) between two polls of a progress counter
+#endif
 #ifndef FSM_MINW
 #define FSM_MINW 1
 #endif
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(FSM_POLL_SLEEP);
             }
         }
     };
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(FSM_POLL_SLEEP);
             }
         }
         // (1b) read set of this chunk in bricks: F range from the levels, J/K from the patch
