@@ -112,13 +112,15 @@ int ttcr_fsm_raytrace_multi(ttcr_fsm_grid* g, int n_src, const int* tx_off, cons
 /* Replaces: Grid3Drn::getTT(tt, threadNo) (ttcr/Grid3Drn.h:102-108). n = node count. */
 int ttcr_fsm_get_tt(ttcr_fsm_grid* g, int slot, void* out, size_t n);
 /* The same field for a consumer on the device (no reference equivalent; the reference only has the host copy above).
- * ttcr_fsm_get_tt_device: pointer to n_nodes CONTIGUOUS values of slot `slot` in the flat order above.  With one
- *   slot this is the field itself; with n_slots >= 2 the fields of two slots are interleaved in HBM, so the call
- *   de-interleaves into a scratch buffer of the grid: the pointer stays valid until the next ttcr_fsm_get_tt /
- *   ttcr_fsm_get_tt_device call or the destruction of the grid.
+ * ttcr_fsm_get_tt_device: pointer to n_nodes CONTIGUOUS values of slot `slot` in the flat order above.  Where every
+ *   slot has its own field (one slot; 2-D grids; weno = 1) this is the field itself; on a first-order 3-D grid with
+ *   n_slots >= 2 the fields of two slots are interleaved in HBM, so the call de-interleaves into a scratch buffer of
+ *   the grid: the pointer stays valid until the next ttcr_fsm_get_tt / ttcr_fsm_get_tt_device call or the
+ *   destruction of the grid.
  * ttcr_fsm_get_tt_device_view: zero copy.  *d_ptr addresses node 0 of the slot's field where it lies and *stride is
- *   the distance between consecutive nodes in ELEMENTS of the grid dtype (1 with one slot, 2 with n_slots >= 2:
- *   layout T[slot/2][node][2]); valid until the next raytrace call on that slot.  Both stay owned by the grid. */
+ *   the distance between consecutive nodes in ELEMENTS of the grid dtype -- 1, or 2 for the interleaved layout
+ *   T[slot/2][node][2]: always take it from the call; valid until the next raytrace call on that slot.  Both stay
+ *   owned by the grid. */
 int ttcr_fsm_get_tt_device(ttcr_fsm_grid* g, int slot, void** d_ptr);
 int ttcr_fsm_get_tt_device_view(ttcr_fsm_grid* g, int slot, void** d_ptr, size_t* stride);
 

@@ -614,7 +614,7 @@ def test_hip_one_grid_from_several_host_threads(oracle):
 
 def test_hip_device_views_of_a_field():
     """ttcr_fsm_get_tt_device: n_nodes contiguous values; ttcr_fsm_get_tt_device_view: the field where it lies + stride
-    (2 with n_threads >= 2: interleaved pairs).  The raw device pointers are consumed the way a zero-copy consumer would:
+    (2 where two slots share an interleaved field: first-order 3-D grids with n_threads >= 2).  The raw device pointers are consumed the way a zero-copy consumer would:
     handed to another grid as device-resident input (set_slowness_device) and read back from there."""
     import ttcr_amd
 
@@ -625,8 +625,9 @@ def test_hip_device_views_of_a_field():
     nn = n ** 3
     sink = ttcr_amd.Grid3d(x, x, x, cell_slowness=0, method="FSM", dtype=np.float32)                 # nn values
     sink2 = ttcr_amd.Grid3d(np.arange(2 * n) * 0.5, x, x, cell_slowness=0, method="FSM", dtype=np.float32)   # 2 nn values
-    for nthr, want_stride in ((1, 1), (3, 2)):
-        g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32)
+    # (one slot; three slots of a first-order grid: interleaved pairs; three slots with weno=1: one field per slot)
+    for nthr, weno, want_stride in ((1, 0, 1), (3, 0, 2), (3, 1, 1)):
+        g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=weno, dtype=np.float32)
         srcs = rng.uniform(0.5, 9.0, (nthr, 3))
         g.raytrace(srcs, np.zeros((nthr, 3)), slowness=s)
         fields = [g._flat_tt(k) for k in range(nthr)]

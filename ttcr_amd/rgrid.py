@@ -159,17 +159,18 @@ class _GridBase:
         return s0
 
     def tt_device_ptr(self, thread_no=0):
-        """Raw device address of n_nodes CONTIGUOUS traveltimes of a slot, in the solver's flat order.  With
-        n_threads >= 2 the fields of two slots are interleaved in HBM and this is a de-interleaved copy in a
-        scratch buffer of the grid (valid until the next tt_device_ptr / get_grid_traveltimes call); see
-        tt_device_view for the zero-copy form."""
+        """Raw device address of n_nodes CONTIGUOUS traveltimes of a slot, in the solver's flat order.  On a
+        first-order 3-D grid with n_threads >= 2 the fields of two slots are interleaved in HBM and this is a
+        de-interleaved copy in a scratch buffer of the grid (valid until the next tt_device_ptr /
+        get_grid_traveltimes call); see tt_device_view for the zero-copy form."""
         p = C.c_void_p()
         _lib.check(self._lib.ttcr_fsm_get_tt_device(self._h, int(thread_no), C.byref(p)))
         return p.value
 
     def tt_device_view(self, thread_no=0):
         """(device address, element stride) of a slot's traveltime field where it lies: node n of the flat order is
-        at address + n * stride * itemsize (stride 1 with one slot, 2 with n_threads >= 2)."""
+        at address + n * stride * itemsize (stride 1, or 2 where two slots share an interleaved field: first-order 3-D
+        grids with n_threads >= 2)."""
         p, st = C.c_void_p(), C.c_size_t()
         _lib.check(self._lib.ttcr_fsm_get_tt_device_view(self._h, int(thread_no), C.byref(p), C.byref(st)))
         return p.value, st.value
