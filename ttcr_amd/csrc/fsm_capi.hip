@@ -176,7 +176,7 @@ class GridT : public GridBase {
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
     DevBuf<int> d_rstat;
     DevBuf<T> d_ssh;         // sheared copies of the node slowness, one per direction family
-    size_t ssh_stride = 0;   // elements per copy: NK * M * NJ
+    size_t ssh_stride = 0;   // elements per copy: NK * (M/2) * SR (3-D), NK * M * NJ (2-D)
     DevBuf<uint32_t> d_mask;
     DevBuf<int> d_bbox, d_slots, d_lmask;
     int* h_lmask = nullptr;  // pinned
@@ -292,8 +292,9 @@ class GridT : public GridBase {
             n_launch = count_launches(C::BL);
         }
         geom.n_nodes = (uint32_t)n_nodes;
-        geom.M = std::max(geom.NF, geom.NJ);
-        ssh_stride = (size_t)geom.NK * geom.M * geom.NJ;
+        geom.M = (std::max(geom.NF, geom.NJ) + 1) & ~1;
+        geom.SR = dim == 3 ? ((geom.NJ + 15) / 16) * 32 : 0;   // 2-D: plain rows (fsm_kernels.h, shear_index)
+        ssh_stride = geom.SR ? (size_t)geom.NK * (geom.M / 2) * geom.SR : (size_t)geom.NK * geom.M * geom.NJ;
         d_ssh.reserve(ssh_stride * (dim == 3 ? 4 : 2));
         if (dim == 3) build_tile_lists(TileCfg<T, 3>::PJ, TileCfg<T, 3>::PK, TileCfg<T, 3>::BL);
         else build_tile_lists(TileCfg<T, 2>::PJ, TileCfg<T, 2>::PK, TileCfg<T, 2>::BL);

@@ -223,17 +223,28 @@ __device__ __forceinline__ double update2_xz(double a, double b, double sn, doub
 struct SweepGeom {
     int NF, NJ, NK;        // node counts
     int npj, npk;          // patches along J and K
-    int M;                 // shear modulus = max(NF, NJ)
+    int M;                 // shear modulus: max(NF, NJ) rounded up to an even number
+    int SR;                // sheared slowness copies: pitch of a PAIR of rows, ceil(NJ/16) blocks of 2 levels x 16 columns;
+                           // 0: plain rows of NJ elements
     uint32_t n_nodes;      // NF*NJ*NK
 };
 
 // Sheared slowness.  A thread marches along F but a wavefront is laid out along J, so at a given
 // level the 64 lanes of a wave read nodes that are NF-1 elements apart in the natural layout.
-// set_slowness therefore keeps, per direction family, a copy laid out as
-//     A[k'][(i'+j') mod M][j']        (oriented indices, M = max(NF,NJ))
-// in which the nodes of one level and one k' are contiguous in j': the per-level slowness load
-// of a wave is a coalesced row read straight into registers (no LDS staging, no transposition).
+// set_slowness therefore keeps, per direction family, a copy indexed by (k', x = (i'+j') mod M, j')
+// (oriented indices) in which the nodes of one level and one k' are contiguous in j': the per-level slowness
+// load of a wave is a coalesced row read straight into registers (no LDS staging, no transposition).
+// Element order: A[k'][x / 2][j' / 16][x % 2][j' % 16] -- one 128-byte line holds TWO consecutive levels of the 16
+// columns a patch row covers.  With plain rows A[k'][x][j'] the 64 bytes a patch row needs per level were half of a
+// line whose other half belongs to the neighbouring patch (another workgroup, another time): every line was fetched
+// twice.  Now the second half is the same lanes' next level, a fraction of a microsecond later.
 // A direction and its opposite traverse the same array backwards, so 4 (3-D) / 2 (2-D) copies.
+// (3-D grids.  The 64-column rows of the one-wave 2-D patches fill whole lines as plain rows A[x][j'] and are 3 % slower
+// with the paired form -- four half lines per load instead of two full ones --, so 2-D grids keep plain rows: SR == 0.)
+__host__ __device__ __forceinline__ size_t shear_index(const SweepGeom& g, int kx, int x, int jx) {
+    if (g.SR == 0) return ((size_t)kx * (size_t)g.M + (size_t)x) * (size_t)g.NJ + (size_t)jx;
+    return ((size_t)kx * (size_t)(g.M >> 1) + (size_t)(x >> 1)) * (size_t)g.SR + (size_t)((jx >> 4) * 32 + (x & 1) * 16 + (jx & 15));
+}
 template <typename T>
 __global__ void fsm_shear_slowness(const T* __restrict__ s, T* __restrict__ out, SweepGeom g, int rf, int rj) {
     const size_t N = g.n_nodes;
@@ -242,7 +253,7 @@ __global__ void fsm_shear_slowness(const T* __restrict__ s, T* __restrict__ out,
         const int ip = rf ? g.NF - 1 - i : i, jp = rj ? g.NJ - 1 - j : j;
         int x = ip + jp;
         x = x >= g.M ? x - g.M : x;
-        out[((size_t)k * g.M + x) * g.NJ + jp] = s[n];
+        out[shear_index(g, k, x, jp)] = s[n];
     }
 }
 
@@ -334,14 +345,13 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
         const int M = a.g.M;
         const int jx = a.rev ? NJ - 1 - jp : jp;
         const int kx = a.rev ? NK - 1 - kp : kp;
-        const size_t base = (size_t)kx * M * NJ + jx;
 #pragma unroll
         for (int q = 1; q <= BL; ++q) {
             int x = L0 - 1 + q - kp;  // i' + j' at this level
             x = a.rev ? NF + NJ - 2 - x : x;
             x = x >= M ? x - M : x;
             T v = 0;
-            if (q >= qa && q <= qb) v = Sg[base + (size_t)x * NJ];
+            if (q >= qa && q <= qb) v = Sg[shear_index(a.g, kx, x, jx)];
             sv[q - 1] = v;
         }
     }
@@ -897,7 +907,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     const uint32_t* __restrict__ Fz = a.frozen + (size_t)grp * NS * a.mask_words;   // + l * mask_words
     const int* bb = a.bbox + 6 * grp * NS;                                           // + 6 * l
     const int M = a.g.M;
-    const size_t sbase = (size_t)(rev ? NK - 1 - kp : kp) * M * NJ + (rev ? NJ - 1 - jp : jp);
+    const size_t sbase = shear_index(a.g, rev ? NK - 1 - kp : kp, 0, rev ? NJ - 1 - jp : jp);   // + the (x) part, see issue_static
 
     // LDS row (without the level) of the column at patch-relative (cj, ck), halo included
     auto lds_row = [&](int cj, int ck) { return (IS3D ? (ck + H) * RJ + cj + H : cj + H) * RS; };
@@ -1013,20 +1023,27 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
             x = x < 0 ? x + M : x;
         }
-        // walk x by +-1 modulo M without a branch or a 64-bit multiply per element: xo = x * NJ alongside
+        // walk x by +-1 modulo M without a branch or a multiply per element: xo = offset of (x) in the copy alongside
+        // (rows come in pairs: even x -> (x/2) SR, odd x -> (x/2) SR + 16)
         const T* __restrict__ Sp = Sg + sbase;
         const int step = rev ? -1 : 1, x_edge = rev ? -1 : M, x_reset = rev ? M - 1 : 0;
-        const uint32_t xo_step = (uint32_t)(step * NJ), xo_reset = (uint32_t)x_reset * (uint32_t)NJ;
-        uint32_t xo = (uint32_t)x * (uint32_t)NJ;
+        const uint32_t SR = (uint32_t)a.g.SR;
+        constexpr bool paired = IS3D;   // (the host sets SR accordingly: 3-D paired rows, 2-D plain rows)
+        const uint32_t xo_reset = !rev ? 0u : (paired ? (uint32_t)((M >> 1) - 1) * SR + 16u : (uint32_t)(M - 1) * (uint32_t)NJ);
+        // paired rows, step +1: even -> odd +16, odd -> even +(SR-16);  step -1: odd -> even -16, even -> odd -(SR-16)
+        const uint32_t d_even = paired ? (rev ? 0u - (SR - 16u) : 16u) : (uint32_t)(step * NJ);
+        const uint32_t d_odd = paired ? (rev ? 0u - 16u : SR - 16u) : (uint32_t)(step * NJ);
+        uint32_t xo = paired ? (uint32_t)(x >> 1) * SR + (uint32_t)(x & 1) * 16u : (uint32_t)x * (uint32_t)NJ;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             T v = 0;
             if (q >= ea && q <= eb) v = Sp[xo];
             sv[q] = v;
+            const uint32_t dx_ = (paired && (x & 1)) ? d_odd : d_even;
             x += step;
             const bool wrap = x == x_edge;
             x = wrap ? x_reset : x;
-            xo = wrap ? xo_reset : xo + xo_step;
+            xo = wrap ? xo_reset : xo + dx_;
         }
         xs_next = x;
         xs_level = L + C;
