@@ -168,7 +168,9 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                     getRaypath, ttcr/Grid2Drn.h:1663-1850, points are (x, z) pairs).
  *   "skip"         1: persistent kernel skips chunks whose read set (bricks of 16^3 nodes, tracked
  *                     by last-change sweep number) did not change since their last evaluation --
- *                     exact, results and iteration counts are unchanged; 0: evaluate every chunk (default) */
+ *                     exact, results and iteration counts are unchanged; 0: evaluate every chunk; -1 (default):
+ *                     on for a 3-D grid with ONE slot and weno = 1 (a lone source with the WENO stage is where it pays),
+ *                     off otherwise */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 /* Replaces: the r_data output of the raytrace overloads above (std::vector<std::vector<sxyz<T1>>>&,

@@ -116,7 +116,8 @@ class GridBase {
     int ttrp = 0, interp_vel = 0;  // traveltime from raypath (ttcr/Grid3D.h:493-496), processVel
     int return_rays = 0;           // raytrace overloads with r_data (ttcr/Grid3D.h:546-586): rays kept for get_rays
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
-    int skip = 0;  // persistent kernel: 1 = skip chunks whose read set did not change (exact); see DESIGN.md
+    int skip = -1; // persistent kernel: 1 = skip chunks whose read set did not change (exact); 0 = evaluate
+                   // every chunk; -1 (default) = on for a lone source with the WENO stage (256^3: 427 -> 368 ms), off otherwise
     int mode = 2;  // 2: persistent kernel, one launch per sweep-iteration, sweeps overlap (default);
                    // 1: persistent kernel, one launch per sweep; 0: one launch per tile wavefront
     Timing timing;
@@ -785,7 +786,10 @@ class GridT : public GridBase {
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
     bool persistent_now() const { return mode >= 1 || stage == 1; }
     // the rotated-template sweeps change nodes without stamping their bricks: no skipping next to them
-    bool skip_now() const { return skip != 0 && !(dim == 2 && rotated && !weno && dx == dz); }
+    bool skip_now() const {
+        const int on = skip < 0 ? (weno && dim == 3 && n_slots == 1 ? 1 : 0) : skip;
+        return on != 0 && !(dim == 2 && rotated && !weno && dx == dz);
+    }
 
     // Grid2Drn::sweep45 for every source of the batch (entries as handed to the sweep kernels)
     void launch_sweep45(int batch) {
