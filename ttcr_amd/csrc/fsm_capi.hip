@@ -171,7 +171,7 @@ class GridT : public GridBase {
     size_t xs_lds_bytes = 40000;
     int xs_lds_below = 2;
     size_t xs_dyn_lds(int batch) const { return (dim == 3 && stage == 0 && batch < xs_lds_below) ? xs_lds_bytes : 0; }
-    int time_order_below = 4;  // fewer slot groups than this in a batch: the whole-iteration launch hands its units out in the
+    int time_order_below = 17; // fewer batch entries (slot groups / slots) than this in a batch: the whole-iteration launch hands its units out in the
                                // order of their expected start times instead of sweep by sweep (build_persistent_lists)
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
