@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU-box script: the bench line and its rocprofv3 evidence on a box that has done nothing else before (the full
-# round_end_run.sh runs the 6-minute -m gpu suite first, and a heat-soaked GPU measures up to 4 % slower)
+# GPU-box script: the bench line and its rocprofv3 evidence (kernel stats, PMC traffic, 1-source profile) in one call,
+# without the 6-minute -m gpu suite that scripts/round_end_run.sh runs first
 O=gpurun_out/round_end; mkdir -p $O
 python bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 bash scripts/profile_run.sh r02_512x64 --steps 2 --warmup 1 --no-single-source > $O/profile.log 2>&1; tail -4 $O/profile.log
