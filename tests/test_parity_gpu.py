@@ -200,10 +200,14 @@ def test_hip_weno_matches_oracle_multi_patch(oracle, kind):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-def test_hip_weno_wide_batch(oracle, dt):
-    """16 sources in 16 slots = 8 slot groups swept together: the WENO stage then runs its short-chunk
-    kernel (4 levels per chunk); every field and both iteration counts must equal the oracle's"""
+@pytest.mark.parametrize("pair", ["0", "1"], ids=["unpaired", "pairs"])
+def test_hip_weno_wide_batch(oracle, monkeypatch, dt, pair):
+    """16 sources in 16 slots swept together, one field per slot (the default of weno grids: 8-level chunks) and as
+    8 slot groups of the pair layout (the WENO stage then runs its short-chunk kernel, 4 levels per chunk); every
+    field and both iteration counts must equal the oracle's"""
     import ttcr_amd
+
+    monkeypatch.setenv("TTCR_FSM_PAIR", pair)
 
     rng = np.random.default_rng(23)
     nn = (37, 41, 33)

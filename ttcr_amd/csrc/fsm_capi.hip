@@ -160,7 +160,7 @@ class GridT : public GridBase {
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
-    int weno_ch4_min = 8;  // slot groups from which the 3-D WENO stage uses chunks of 4 levels
+    int weno_ch4_min = 8;  // pair layout: slot groups from which the 3-D WENO stage uses chunks of 4 levels
     int pre_min = 2;           // 3-D: slot groups in a batch from which the upwind counters are sampled one chunk ahead (PRE)
     // extra (unused) dynamic LDS per workgroup of the whole-iteration launch: caps the resident workgroups per CU.  A lone
     // source is bound by the dependent chain of a marching unit, and a unit that shares its CU's SIMDs with another
@@ -413,7 +413,9 @@ class GridT : public GridBase {
     template <int DIM, int H>
     void launch_sweeps_persistent(int batch) {
         constexpr int C0 = ChunkCfg<T, DIM>::C;
-        if (H == 2 && DIM == 3 && batch >= weno_ch4_min && C0 == 8) {
+        // (pair layout only: with one field per slot -- the default of weno grids since round 2 -- the 8-level chunks are
+        // 2-4 % faster at every batch size, profiles/r02/weno_chunk.txt)
+        if (H == 2 && DIM == 3 && NS == 2 && batch >= weno_ch4_min && C0 == 8) {
             if (NS == 2) launch_sweeps_persistent_ns<DIM, H, 2, (H == 2 && DIM == 3) ? 4 : C0>(batch);
             else launch_sweeps_persistent_ns<DIM, H, 1, (H == 2 && DIM == 3) ? 4 : C0>(batch);
         } else {
