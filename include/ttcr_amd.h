@@ -166,11 +166,12 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                     Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) (ttcr/Grid3Drn.h:1339-1500); the rays
  *                     stay in the grid until the next raytrace call, see ttcr_fsm_get_rays (2-D: Grid2Drn::
  *                     getRaypath, ttcr/Grid2Drn.h:1663-1850, points are (x, z) pairs).
- *   "skip"         1: persistent kernel skips chunks whose read set (bricks of 16^3 nodes, tracked
- *                     by last-change sweep number) did not change since their last evaluation --
- *                     exact, results and iteration counts are unchanged; 0: evaluate every chunk; -1 (default):
- *                     on for a 3-D grid with ONE slot and weno = 1 (a lone source with the WENO stage is where it pays),
- *                     off otherwise */
+ *   "skip"         1: the persistent kernels step over chunks, work units and whole sweeps that cannot change a node:
+ *                     a chunk whose read set (bricks of 16^3 nodes stamped with the sweep of their last change; the
+ *                     change flags its upwind patches publish with their progress) holds no change since its nodes
+ *                     were last visited is a no-op, and so is every sweep that follows a sweep without a change --
+ *                     exact, fields and iteration counts are unchanged; 0: evaluate every chunk; -1 (default): on
+ *                     where it was measured to pay (3-D grids; off for a lone first-order source), see DESIGN.md 4a */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 /* Replaces: the r_data output of the raytrace overloads above (std::vector<std::vector<sxyz<T1>>>&,
@@ -180,6 +181,17 @@ int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
  * buffers of n_rays+1 offsets and 3*n_points (2-D: 2*n_points) coordinates. */
 int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points);
 int ttcr_fsm_get_rays(const ttcr_fsm_grid* g, long long* offsets, void* pts);
+
+/* Replaces: Grid3D::raytrace(Tx, t0, Rx, traveltimes, r_data, threadNo) (ttcr/Grid3D.h:546-586; 2-D: ttcr/Grid2D.h) as
+ * Grid3D's multi-source r_data overload calls it -- from nt host threads at once, each with its own threadNo
+ * (ttcr/Grid3D.h:855-905).  One call solves the source in `slot` and keeps traveltimes AND rays, whatever the
+ * "return_rays" option says; the rays are stored PER SLOT, so a thread finds the rays of its own call with
+ * ttcr_fsm_slot_rays_size / ttcr_fsm_get_slot_rays (same layout as ttcr_fsm_get_rays) whatever other threads do on other
+ * slots meanwhile.  They stay until the next ttcr_fsm_raytrace_rays call on that slot. */
+int ttcr_fsm_raytrace_rays(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx,
+                           const void* rx, void* tt_out);
+int ttcr_fsm_slot_rays_size(const ttcr_fsm_grid* g, int slot, size_t* n_rays, size_t* n_points);
+int ttcr_fsm_get_slot_rays(const ttcr_fsm_grid* g, int slot, long long* offsets, void* pts);
 
 /* NOT provided (reference overloads without an entry point here):
  *   - raytrace with l_data (ray projection matrix L): ttcrpy itself raises "compute_L not implemented for FSM"

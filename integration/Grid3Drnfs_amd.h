@@ -20,6 +20,7 @@
 #define TTCR_GRID3DRNFS_AMD_H
 
 #include <atomic>
+#include <mutex>
 #include <iostream>   // (Grid3D.h / Grid2D.h use std::cout without including it)
 #include <sstream>
 #include <stdexcept>
@@ -129,9 +130,20 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
     // with raypaths (ttcr/Grid3D.h:546-586)
     void raytrace(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<sxyz<T1>>& Rx,
                   std::vector<T1>& traveltimes, std::vector<std::vector<sxyz<T1>>>& r_data, const size_t threadNo = 0) const override {
-        RaysOn on(h);
-        raytrace(Tx, t0, Rx, traveltimes, threadNo);
-        fetch_rays(r_data);
+        // one call solves and keeps the rays of THIS slot: Grid3D's multi-source r_data overload (ttcr/Grid3D.h:855-905)
+        // calls this from nt host threads at once, and every thread must find its own rays
+        if (t0.size() != Tx.size()) throw std::runtime_error("Error: Tx and t0 of different sizes.");
+        traveltimes.resize(Rx.size());
+        chk(ttcr_fsm_set_option(h, "tt_from_rp", this->tt_from_rp ? 1.0 : 0.0));
+        chk(ttcr_fsm_raytrace_rays(h, (int)threadNo, (int)Tx.size(), Tx.data(), t0.data(), (int)Rx.size(), Rx.data(), traveltimes.data()));
+        last_slot.store((int)threadNo);
+        size_t nr = 0, np = 0;
+        chk(ttcr_fsm_slot_rays_size(h, (int)threadNo, &nr, &np));
+        std::vector<long long> off(nr + 1);
+        std::vector<sxyz<T1>> pts(np ? np : 1);
+        chk(ttcr_fsm_get_slot_rays(h, (int)threadNo, off.data(), pts.data()));
+        r_data.resize(nr);
+        for (size_t n = 0; n < nr; ++n) r_data[n].assign(pts.begin() + off[n], pts.begin() + off[n + 1]);
     }
     void raytrace(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<std::vector<sxyz<T1>>>& Rx,
                   std::vector<std::vector<T1>*>& traveltimes, std::vector<std::vector<std::vector<sxyz<T1>>>*>& r_data,
@@ -180,6 +192,7 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
         std::vector<T1> tt(rx.size());
         chk(ttcr_fsm_set_option(h, "tt_from_rp", this->tt_from_rp ? 1.0 : 0.0));
         {
+            std::lock_guard<std::mutex> rays_lock(rays_mu);   // option, solve and fetch are one unit
             RaysOn on(h, r_data != nullptr);
             chk(ttcr_fsm_raytrace_multi(h, (int)ns, tx_off.data(), tx.data(), vt0.data(), rx_off.data(), rx.data(), tt.data()));
             if (r_data) {
@@ -197,6 +210,7 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
 
    private:
     ttcr_fsm_grid* h = nullptr;
+    mutable std::mutex rays_mu;
     T2 ncx, ncy, ncz;
     T1 dx, xmin, ymin, zmin, xmax, ymax, zmax;
     bool cells;

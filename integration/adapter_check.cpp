@@ -158,6 +158,27 @@ int main() {
         for (const auto& v : btt) for (float x : v) std::printf(" %a", x);
         std::printf("\n");
         CHECK(mtt[0] == tt, "source 0 of the batch == the single solve");
+        // the same with raypaths: Grid3D's multi-source r_data overload (ttcr/Grid3D.h:855-905) calls the adapter's
+        // single-source r_data virtual from its host threads at once -- every thread has to get the rays of its own call
+        {
+            std::vector<std::vector<float>> rtt(mTx.size()), qtt;
+            std::vector<std::vector<std::vector<sxyz<float>>>> rrays(mTx.size()), qrays;
+            bool same = true;
+            for (int rep = 0; rep < 5 && same; ++rep) {
+                g->raytrace(mTx, mt0, mRx, rtt, rrays);
+                dynamic_cast<Grid3Drnfs_amd<float, uint32_t>&>(*g).raytrace_batch(mTx, mt0, mRx, qtt, &qrays);
+                same = rtt == qtt && rrays.size() == qrays.size();
+                for (size_t n = 0; same && n < rrays.size(); ++n) {
+                    same = rrays[n].size() == qrays[n].size();
+                    for (size_t r = 0; same && r < rrays[n].size(); ++r) {
+                        same = rrays[n][r].size() == qrays[n][r].size();
+                        for (size_t q = 0; same && q < rrays[n][r].size(); ++q)
+                            same = rrays[n][r][q].x == qrays[n][r][q].x && rrays[n][r][q].y == qrays[n][r][q].y && rrays[n][r][q].z == qrays[n][r][q].z;
+                    }
+                }
+            }
+            CHECK(same, "Grid3D multi-source r_data overload (host threads): every thread gets its own rays == raytrace_batch");
+        }
         // error paths, as exceptions with the reference's texts
         std::vector<sxyz<float>> out = {{1.0f, -2.0f, 5.6f}};
         CHECK(what_of([&] { g->raytrace(Tx, t0, out, tt, 0); }) == "Error: Point (1 -2 5.6) outside grid.", "receiver outside grid throws the reference's message");

@@ -5,14 +5,14 @@ anti-diagonal); unit run times; and the number of units inside their chunk loop 
 import sys
 import numpy as np
 
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4)
+a = np.fromfile(sys.argv[1], dtype=np.uint64)[:4 * 65536].reshape(-1, 4)   # (the chunk records of the first units follow)
 a = a[a[:, 2] > 0]
 t0 = a[:, 0].min()
 ent = (a[:, 0] - t0) * 0.01   # us
 beg = (a[:, 1] - t0) * 0.01
 end = (a[:, 2] - t0) * 0.01
 TJ = (a[:, 3] & 0xffff).astype(int); TK = ((a[:, 3] >> 16) & 0xffff).astype(int)
-d = ((a[:, 3] >> 32) & 0xff).astype(int); z = (a[:, 3] >> 40).astype(int)
+d = ((a[:, 3] >> 32) & 0xff).astype(int); z = ((a[:, 3] >> 40) & 0xff).astype(int); nch = (a[:, 3] >> 48).astype(int)
 print(f"units {len(a)}  span {end.max():.1f} us")
 for dd in sorted(set(d)):
     m = d == dd
@@ -23,6 +23,7 @@ for dd in sorted(set(d)):
     ds = sorted(set(md))
     med = np.array([np.median(beg[m][md == q]) for q in ds])
     slope = np.polyfit(ds, med, 1)[0] if len(ds) > 2 else 0.0
+    print(f"dir {dd}: units {m.sum()} shortcut {(nch[m]==0xffff).sum()} no-chunk {(nch[m]==0).sum()} chunks/evaluating unit {np.mean(nch[m][(nch[m]>0)&(nch[m]<0xffff)]) if ((nch[m]>0)&(nch[m]<0xffff)).any() else 0:.1f} | resident: median {np.median(end[m]-ent[m]):.1f} us")
     print(f"dir {dd}: entry {ent[m].min():9.1f}  first chunk {beg[m].min():9.1f}  last exit {end[m].max():9.1f} | "
           f"ramp {slope:6.2f} us/diagonal | run: median {np.median(run):7.1f} min {run.min():7.1f} max {run.max():7.1f} | "
           f"wait before start: median {np.median(wait):8.1f} max {wait.max():8.1f}")

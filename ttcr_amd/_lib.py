@@ -51,6 +51,9 @@ SYMBOLS = {
     "ttcr_fsm_last_timing": (_I, [_P, C.POINTER(Timing)]),
     "ttcr_fsm_rays_size": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ttcr_fsm_get_rays": (_I, [_P, _P, _P]),
+    "ttcr_fsm_raytrace_rays": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "ttcr_fsm_slot_rays_size": (_I, [_P, _I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ttcr_fsm_get_slot_rays": (_I, [_P, _I, _P, _P]),
 }
 
 _lib = None

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cmath>
@@ -81,8 +82,15 @@ class GridBase {
     virtual void get_slowness(void* out, size_t n) = 0;
     // explicit_slots (optional): source n is solved in slot explicit_slots[n] (ascending, distinct) -- the combined
     // single-source calls of several host threads; otherwise the sources are block-distributed like get_blk_size
+    // force_rays: keep the rays of this call whatever the "return_rays" option says
     virtual void raytrace_multi(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
-                                const void* rx, void* tt_out, int forced_slot, const int* explicit_slots = nullptr) = 0;
+                                const void* rx, void* tt_out, int forced_slot, const int* explicit_slots = nullptr,
+                                bool force_rays = false) = 0;
+    // one source in `slot`, traveltimes AND rays, the rays kept per slot (raytrace overloads with r_data called by several
+    // host threads at once, ttcr/Grid3D.h:855-905: every thread finds its own rays whatever the others do meanwhile)
+    virtual void raytrace_rays(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) = 0;
+    virtual void slot_rays_size(int slot, size_t* n_rays, size_t* n_points) const = 0;
+    virtual void get_slot_rays(int slot, long long* offsets, void* pts) const = 0;
     virtual void validate_points(int n_tx, const void* tx, int n_rx, const void* rx) = 0;   // throws like raytrace would
     // single-source calls that arrive together (ttcrpy's thread pool: nt host threads, one slot each) are solved together
     struct Request {
@@ -97,7 +105,8 @@ class GridBase {
     std::condition_variable q_cv;
     std::vector<Request*> queue;
     bool leader_active = false;
-    int combine_window_us = 200;   // how long a call waits for company (option "combine_window_us"; 0: never)
+    bool had_company = false;      // two calls have been seen on this handle at the same time (guarded by q_mu)
+    std::atomic<int> combine_window_us{200};   // how long a call waits for company (option "combine_window_us"; 0: never)
     size_t elem_size = 4;
     virtual void get_tt(int slot, void* out, size_t n) = 0;
     virtual void* tt_device(int slot) = 0;                      // contiguous copy of the field (see ttcr_amd.h)
@@ -114,7 +123,7 @@ class GridBase {
     bool sweep45_strips = false;  // force the strip kernel of sweep45 (env TTCR_FSM_SWEEP45=strips; tests)
     bool rotated = false;  // 2-D rotated_template: sweep45 after every first-order sweep (ttcr/Grid2Drnfs.h:277-286)
     int ttrp = 0, interp_vel = 0;  // traveltime from raypath (ttcr/Grid3D.h:493-496), processVel
-    int return_rays = 0;           // raytrace overloads with r_data (ttcr/Grid3D.h:546-586): rays kept for get_rays
+    std::atomic<int> return_rays{0};   // raytrace overloads with r_data (ttcr/Grid3D.h:546-586): rays kept for get_rays
     int fixed_iters = 0, max_batch = 0, use_graph = 1;
     int skip = -1; // persistent kernel: 1 = skip chunks whose read set did not change (exact); 0 = evaluate
                    // every chunk; -1 (default) = on for a lone source with the WENO stage (256^3: 427 -> 368 ms), off otherwise
@@ -192,6 +201,10 @@ class GridT : public GridBase {
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
     DevBuf<int> d_stamp;       // dirty-brick stamps [n_slots][nbf*nbj*nbk]
+    DevBuf<unsigned> d_cmap;   // SKIP kernels: per-chunk edge-change flags of every unit of a launch [dir][entry][patch][2][cmap_words]
+    int cmap_words = 1;
+    DevBuf<unsigned long long> d_sw;   // SKIP kernels: per (global sweep, slot group) units finished | units that changed a node
+    int sw_sweeps = 0;
     DevBuf<int> d_iter;        // current iteration index (read by the captured kernels)
     DevBuf<unsigned long long> d_evals;  // [n_slots] node updates actually evaluated
     int* h_iter = nullptr;     // pinned
@@ -305,6 +318,18 @@ class GridT : public GridBase {
         nbk = (geom.NK + FSM_BRICK - 1) / FSM_BRICK;
         n_bricks = (size_t)nbf * nbj * nbk;
         d_stamp.reserve(n_bricks * n_slots);  // one set per slot group is used
+        {
+            // change maps of the SKIP kernels: one bit per chunk and edge; a unit has at most (NF + PJ + PK) / C + 2 chunks
+            // (the shortest chunks any instantiation uses are 4 levels long), and reads a little past the end of its
+            // upwind units' maps
+            const int PJ = dim == 3 ? TileCfg<T, 3>::PJ : TileCfg<T, 2>::PJ, PK = dim == 3 ? TileCfg<T, 3>::PK : 1;
+            const int max_chunks = (geom.NF + 2 * (PJ + PK)) / 4 + 4;
+            cmap_words = max_chunks / 32 + 1;
+            d_cmap.reserve((size_t)n_patches * n_slots * (dim == 3 ? 8 : 4) * 2 * cmap_words);
+            // whole-sweep tallies: one entry per sweep of a solve (both stages); solves with more sweeps simply stop using them
+            sw_sweeps = (dim == 3 ? 8 : 4) * (2 * std::min(nitermax, 256) + 2);
+            d_sw.reserve((size_t)sw_sweeps * n_groups());
+        }
         d_iter.reserve(1);
         d_evals.reserve(n_slots);
         if (dim == 2)   // the row-parallel sweep45 kernel keeps four rows in (dynamic) LDS
@@ -454,6 +479,11 @@ class GridT : public GridBase {
         pa.nbf = nbf; pa.nbj = nbj; pa.nbk = nbk;
         pa.ndir = DIM == 3 ? 8 : 4;
         pa.skip = skip_now();
+        pa.cmap = d_cmap.p;
+        pa.cw = cmap_words;
+        pa.sw = d_sw.p;
+        pa.n_sw_groups = n_groups();
+        pa.n_sw_sweeps = sw_sweeps;
 
         const dim3 block(C::PJ * C::PK), grid((unsigned)n_patches * batch);
         const int ndir = DIM == 3 ? 8 : 4;
@@ -469,9 +499,13 @@ class GridT : public GridBase {
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
-            if (skip_now())
+            if (skip_now()) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * ndir * 2 * cmap_words, stream));
+            const bool pre = DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0;   // counters sampled one chunk ahead (template PRE)
+            if (skip_now() && pre)
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
+            else if (skip_now())
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
-            else if (DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0)   // counters sampled one chunk ahead (template PRE)
+            else if (pre)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
             else
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
@@ -497,6 +531,7 @@ class GridT : public GridBase {
             // ticket + progress counters back to zero (the abort word [1] is sticky within an iteration)
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
+            if (skip_now()) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * 2 * cmap_words, stream));
             if (skip_now())
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, false><<<grid, block, 0, stream>>>(pa);
             else
@@ -786,11 +821,15 @@ class GridT : public GridBase {
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
 
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
+    // exact skipping of chunks / units / sweeps that cannot change a node: on wherever it was measured to pay (profiles/r03)
+    int skip_default() const { return dim == 3 ? 1 : 0; }
     bool persistent_now() const { return mode >= 1 || stage == 1; }
     // the rotated-template sweeps change nodes without stamping their bricks: no skipping next to them
     bool skip_now() const {
-        const int on = skip < 0 ? (weno && dim == 3 && n_slots == 1 ? 1 : 0) : skip;
-        return on != 0 && !(dim == 2 && rotated && !weno && dx == dz);
+        const int on = skip < 0 ? skip_default() : skip;
+        // (the SKIP kernels pack a level count and 8 flag bits into one progress word, and keep one mask bit per F brick)
+        const bool fits = (long long)geom.NF + geom.NJ + geom.NK < (1ll << 22) && nbf <= 32 * FSM_SLAB_WORDS;
+        return on != 0 && fits && !(dim == 2 && rotated && !weno && dx == dz);
     }
 
     // Grid2Drn::sweep45 for every source of the batch (entries as handed to the sweep kernels)
@@ -940,6 +979,7 @@ class GridT : public GridBase {
         const int ndir = dim == 3 ? 8 : 4;
         if (persistent_now() || weno) HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 2 * sizeof(int), stream));
         HIP_CHECK(hipMemsetAsync(d_evals.p, 0, sizeof(unsigned long long) * n_slots, stream));
+        HIP_CHECK(hipMemsetAsync(d_sw.p, 0, sizeof(unsigned long long) * (size_t)sw_sweeps * n_groups(), stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
         int it_total = 0;  // global iteration index: sweep numbers for the dirty-brick stamps
         for (stage = 0; stage < (weno ? 2 : 1); ++stage) {
@@ -993,10 +1033,18 @@ class GridT : public GridBase {
             // the stamps of the first-order stage say nothing about the WENO stencil: every brick counts as changed in the
             // last sweep, so that the first WENO sweep visits every node once with the new formula
             if (stage == 0 && weno && skip_now()) {
+                // (and no whole-sweep shortcut across the stage boundary: a tally of zero finished units never qualifies)
+                HIP_CHECK(hipMemsetAsync(d_sw.p, 0, sizeof(unsigned long long) * (size_t)sw_sweeps * n_groups(), stream));
                 for (int s2 : slot_ids)
                     HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(d_stamp.p + (size_t)(s2 / NS) * n_bricks), it_total * (dim == 3 ? 8 : 4),
                                                 n_bricks, stream));
             }
+        }
+        if (std::getenv("TTCR_FSM_DEBUG_SW")) {   // tuning: the whole-sweep tallies of the SKIP kernels
+            std::vector<unsigned long long> h((size_t)std::min(sw_sweeps, 40) * n_groups());
+            HIP_CHECK(hipMemcpy(h.data(), d_sw.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (size_t q = 0; q < h.size(); ++q) std::fprintf(stderr, "%s%u/%u", q % n_groups() == 0 ? "\n[sw] " : " ", (unsigned)h[q], (unsigned)(h[q] >> 32));
+            std::fprintf(stderr, "\n");
         }
         const bool was_persistent = mode >= 1 || weno;
         stage = 0;
@@ -1336,6 +1384,30 @@ class GridT : public GridBase {
     DevBuf<int> d_raynp;
     DevBuf<long long> d_rayoff;
 
+    // rays of the last raytrace_rays call of every slot
+    std::vector<std::vector<long long>> slot_rays_off;
+    std::vector<std::vector<T>> slot_rays_pts;
+    void raytrace_rays(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) override {
+        check_slot(slot);
+        const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
+        raytrace_multi(1, tx_off, tx, t0, rx_off, rx, tt_out, slot, nullptr, true);
+        if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
+        slot_rays_off[slot] = rays_off;
+        slot_rays_pts[slot].swap(rays_pts);
+        if (!return_rays) { rays_off.assign(1, 0); rays_pts.clear(); } else rays_pts = slot_rays_pts[slot];
+    }
+    void slot_rays_size(int slot, size_t* n_rays, size_t* n_points) const override {
+        check_slot(slot);
+        if (slot_rays_off.empty()) { *n_rays = 0; *n_points = 0; return; }
+        *n_rays = slot_rays_off[slot].size() - 1;
+        *n_points = (size_t)slot_rays_off[slot].back();
+    }
+    void get_slot_rays(int slot, long long* offsets, void* pts) const override {
+        check_slot(slot);
+        if (slot_rays_off.empty()) { offsets[0] = 0; return; }
+        std::memcpy(offsets, slot_rays_off[slot].data(), slot_rays_off[slot].size() * sizeof(long long));
+        if (!slot_rays_pts[slot].empty()) std::memcpy(pts, slot_rays_pts[slot].data(), slot_rays_pts[slot].size() * sizeof(T));
+    }
     void rays_size(size_t* n_rays, size_t* n_points) const override {
         *n_rays = rays_off.size() - 1;
         *n_points = (size_t)rays_off.back();
@@ -1359,8 +1431,10 @@ class GridT : public GridBase {
     }
 
     void raytrace_multi(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off,
-                        const void* rx_v, void* tt_out_v, int forced_slot, const int* explicit_slots = nullptr) override {
+                        const void* rx_v, void* tt_out_v, int forced_slot, const int* explicit_slots = nullptr,
+                        bool force_rays = false) override {
         HIP_CHECK(hipSetDevice(device));
+        const int return_rays = (this->return_rays.load() || force_rays) ? 1 : 0;   // (shadows the option for this call)
         const auto wall0 = std::chrono::steady_clock::now();
         timing = Timing();
         timing.n_sources = n_src;
@@ -1520,8 +1594,12 @@ int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
         auto g = std::make_unique<ttcr_fsm_grid>();
         if (dtype == TTCR_F32)
             g->impl.reset(new GridT<float>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev, weno != 0));
+#ifdef FSM_DEV_F32_ONLY   // tuning builds: half the instantiations
+        else throw ValueError("tuning build without double grids");
+#else
         else
             g->impl.reset(new GridT<double>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev, weno != 0));
+#endif
         g->impl->weno = weno != 0;
         *out = g.release();
     });
@@ -1541,8 +1619,12 @@ int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
         auto g = std::make_unique<ttcr_fsm_grid>();
         if (dtype == TTCR_F32)
             g->impl.reset(new GridT<float>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev, weno != 0));
+#ifdef FSM_DEV_F32_ONLY
+        else throw ValueError("tuning build without double grids");
+#else
         else
             g->impl.reset(new GridT<double>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev, weno != 0));
+#endif
         g->impl->weno = weno != 0;
         g->impl->rotated = rotated_template != 0;
         *out = g.release();
@@ -1598,6 +1680,20 @@ static void run_combined(GridBase* gb, std::vector<GridBase::Request*>& batch) {
     } catch (const ValueError& e) { st = TTCR_ERR_VALUE; msg = e.what();
     } catch (const DeviceError& e) { st = TTCR_ERR_DEVICE; msg = e.what();
     } catch (const std::exception& e) { st = TTCR_ERR_RUNTIME; msg = e.what(); }
+    if (st != TTCR_OK && st != TTCR_ERR_DEVICE && ok.size() > 1) {
+        // something only the solve itself finds out (a ray that leaves the grid, ...) failed the batch: the calls are
+        // independent in the reference, so each one is redone on its own and only the offending call reports the error
+        for (auto* r : ok) {
+            const int to[2] = {0, r->n_tx}, ro[2] = {0, std::max(r->n_rx, 0)};
+            try {
+                gb->raytrace_multi(1, to, r->tx, r->t0, ro, r->rx, r->tt, r->slot);
+                r->status = TTCR_OK;
+            } catch (const ValueError& e) { r->status = TTCR_ERR_VALUE; r->err = e.what();
+            } catch (const DeviceError& e) { r->status = TTCR_ERR_DEVICE; r->err = e.what();
+            } catch (const std::exception& e) { r->status = TTCR_ERR_RUNTIME; r->err = e.what(); }
+        }
+        return;
+    }
     for (size_t n = 0; n < ok.size(); ++n) {
         ok[n]->status = st;
         ok[n]->err = msg;
@@ -1609,53 +1705,84 @@ int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, cons
                       void* tt_out) {
     if (!g) { g_last_error = "null grid handle"; return TTCR_ERR_VALUE; }
     GridBase* gb = g->impl.get();
-    if (gb->n_slots <= 1 || gb->combine_window_us <= 0 || gb->return_rays) {   // (rays belong to "the last call": no company)
+    auto alone = [&] {
         return guarded_on(g, [&] {
             if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
             const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
             g->impl->raytrace_multi(1, tx_off, tx, t0, rx_off, rx, tt_out, slot);
         });
-    }
+    };
+    if (gb->n_slots <= 1 || gb->combine_window_us.load() <= 0 || gb->return_rays.load()) return alone();   // (rays belong to "the last call": no company)
     // Grid3D's multi-source overload (ttcr/Grid3D.h:810-853) reaches a backend as nt host threads, each calling the
     // single-source raytrace with its own threadNo.  Calls that arrive within a short window are gathered by the first
     // one (the leader) and go to the device as ONE batch -- the sources then run side by side like in
-    // ttcr_fsm_raytrace_multi instead of one after the other.
+    // ttcr_fsm_raytrace_multi instead of one after the other.  A handle that has only ever seen one call at a time (a
+    // plain loop over sources) never waits for company.
     GridBase::Request req{slot, n_tx, n_rx, tx, t0, rx, tt_out};
-    std::unique_lock<std::mutex> lk(gb->q_mu);
-    gb->queue.push_back(&req);
-    gb->q_cv.notify_all();
-    while (!req.done) {
-        if (gb->leader_active) { gb->q_cv.wait(lk); continue; }
-        gb->leader_active = true;
-        const auto window = std::chrono::microseconds(gb->combine_window_us);
-        size_t seen = gb->queue.size();
-        while ((int)gb->queue.size() < gb->n_slots) {   // wait for company until nothing new arrives for one window
-            gb->q_cv.wait_for(lk, window);
-            if (gb->queue.size() == seen) break;
-            seen = gb->queue.size();
-        }
-        std::vector<GridBase::Request*> batch, rest;
-        std::vector<char> taken(gb->n_slots > 0 ? gb->n_slots : 1, 0);
-        for (auto* r : gb->queue) {   // one request per slot and batch; a second one for the same slot waits for the next round
-            const bool dup = r->slot >= 0 && r->slot < gb->n_slots && taken[r->slot];
-            if (dup) { rest.push_back(r); continue; }
-            if (r->slot >= 0 && r->slot < gb->n_slots) taken[r->slot] = 1;
-            batch.push_back(r);
-        }
-        gb->queue.swap(rest);
-        lk.unlock();
-        {
-            std::lock_guard<std::mutex> hl(gb->mu);
-            run_combined(gb, batch);
-        }
-        lk.lock();
-        for (auto* r : batch) r->done = true;
-        gb->leader_active = false;
+    try {
+        std::unique_lock<std::mutex> lk(gb->q_mu);
+        if (!gb->queue.empty() || gb->leader_active) gb->had_company = true;
+        gb->queue.push_back(&req);
         gb->q_cv.notify_all();
+        while (!req.done) {
+            if (gb->leader_active) { gb->q_cv.wait(lk); continue; }
+            gb->leader_active = true;
+            std::vector<GridBase::Request*> batch;
+            try {
+                if (gb->had_company) {
+                    const auto window = std::chrono::microseconds(gb->combine_window_us.load());
+                    size_t seen = gb->queue.size();
+                    while ((int)gb->queue.size() < gb->n_slots) {   // wait for company until nothing new arrives for one window
+                        gb->q_cv.wait_for(lk, window);
+                        if (gb->queue.size() == seen) break;
+                        seen = gb->queue.size();
+                    }
+                }
+                std::vector<GridBase::Request*> rest;
+                std::vector<char> taken(gb->n_slots > 0 ? gb->n_slots : 1, 0);
+                for (auto* r : gb->queue) {   // one request per slot and batch; a second one for the same slot waits for the next round
+                    const bool dup = r->slot >= 0 && r->slot < gb->n_slots && taken[r->slot];
+                    if (dup) { rest.push_back(r); continue; }
+                    if (r->slot >= 0 && r->slot < gb->n_slots) taken[r->slot] = 1;
+                    batch.push_back(r);
+                }
+                gb->queue.swap(rest);
+                lk.unlock();
+                try {
+                    std::lock_guard<std::mutex> hl(gb->mu);
+                    run_combined(gb, batch);
+                } catch (...) { lk.lock(); throw; }
+                lk.lock();
+            } catch (...) {
+                // (an allocation failed somewhere above: nobody may be left waiting for a leader that is gone)
+                if (batch.empty()) { batch.swap(gb->queue); }
+                for (auto* r : batch)
+                    if (r->status == TTCR_OK) { r->status = TTCR_ERR_RUNTIME; r->err = "out of memory while combining raytrace calls"; }
+            }
+            for (auto* r : batch) r->done = true;
+            gb->leader_active = false;
+            gb->q_cv.notify_all();
+        }
+    } catch (...) {
+        g_last_error = "out of memory while queueing a raytrace call";
+        return TTCR_ERR_RUNTIME;
     }
-    lk.unlock();
     if (req.status != TTCR_OK) g_last_error = req.err;
     return req.status;
+}
+
+int ttcr_fsm_raytrace_rays(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                           void* tt_out) {
+    return guarded_on(g, [&] { g->impl->raytrace_rays(slot, n_tx, tx, t0, n_rx, rx, tt_out); });
+}
+int ttcr_fsm_slot_rays_size(const ttcr_fsm_grid* g, int slot, size_t* n_rays, size_t* n_points) {
+    return guarded_on(g, [&] {
+        if (!n_rays || !n_points) throw ValueError("null output pointer");
+        g->impl->slot_rays_size(slot, n_rays, n_points);
+    });
+}
+int ttcr_fsm_get_slot_rays(const ttcr_fsm_grid* g, int slot, long long* offsets, void* pts) {
+    return guarded_on(g, [&] { g->impl->get_slot_rays(slot, offsets, pts); });
 }
 
 int ttcr_fsm_raytrace_multi(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0,

@@ -512,6 +512,12 @@ struct PersistArgs {
     int nbf, nbj, nbk;        // bricks of FSM_BRICK^3 nodes (natural coordinates)
     int dir, ndir;            // direction index within the iteration, directions per iteration
     int skip;                 // 0: evaluate every chunk
+    // exact skipping (SKIP kernels), see "scheduler" in fsm_sweep_persistent
+    unsigned* cmap;           // [unit][2][cw] per-chunk change flags of a unit's J-edge / K-edge columns (zeroed per launch)
+    int cw;                   // words per edge and unit
+    unsigned long long* sw;   // [global sweep number][n_sw_groups]: units finished (low 32) | units that changed a node (high 32);
+                              // zeroed per solve; nullptr: no whole-sweep shortcut
+    int n_sw_groups, n_sw_sweeps;
     // whole-iteration launch (XS): all directions in one grid, sheared copies by family
     const T* ssh;             // [families][ssh_stride]
     size_t ssh_stride;
@@ -660,6 +666,13 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 #ifndef FSM_MINW
 #define FSM_MINW 1
 #endif
+// SKIP kernels: F bricks (of FSM_BRICK nodes) a grid may have along the fast axis, in 32-bit words of the slab mask
+#ifndef FSM_SLAB_WORDS
+#define FSM_SLAB_WORDS 32
+#endif
+// SKIP kernels publish progress as (levels << 8) | change flags of the last four chunks (two bits each: J-edge, K-edge columns);
+// a finished unit publishes FSM_FIN | (ever changed its J edge) | (ever changed its K edge) << 1
+#define FSM_FIN 0x7ffffff0
 #ifndef FSM_EARLY_PUB
 #define FSM_EARLY_PUB 0   // first chunks of a unit whose progress is published right after their write-back
 #endif
@@ -731,7 +744,7 @@ __device__ __forceinline__ void st_sc1(Pack<double, 2>* p, Pack<double, 2> x) {
 // chunk loop).  Pays off with several units in flight per patch position (64 sources: +3.8 %) and for the one-wave
 // 2-D patches (a single 4096^2 solve: +24 %); a lone 3-D source is 4 % better off without.
 template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE = false>
-__global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
+__global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeof(T) == 4) ? 3 : FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
     using P = Pack<T, NS>;
     constexpr int NT = PJ * PK;
     constexpr int RJ = PJ + 2 * H;
@@ -750,9 +763,21 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
 
     __shared__ P Tt[NROWS * RS];
     __shared__ int s_ticket;
-    __shared__ int s_skip;
     __shared__ int s_anychg;
     __shared__ int s_chg[64];  // bricks of the read set changed by this chunk
+    // scheduler state of the SKIP kernels (thread 0 only, apart from s_slab's set-up and s_next / s_act)
+    constexpr int SLABW = SKIP ? FSM_SLAB_WORDS : 1;
+    __shared__ unsigned s_stamped[SKIP ? 9 : 1][SLABW];   // bricks of the read set (J/K position, F index) this unit has already stamped
+    __shared__ unsigned s_slab[SLABW];   // bit bf: some brick of the unit's read set with F index bf changed in sweep sigma-1 or in this one
+    __shared__ int s_next, s_act;        // chunk the scheduler stopped at, and what to do there (1: evaluate, 2: drain first, 0: leave)
+    __shared__ int s_cwi[2], s_cwl[2];   // upwind change maps: cached word index, upwind level known when it was loaded
+    __shared__ unsigned s_cwv[2];        // ... and the word
+    __shared__ int s_mywi;               // own change map: word being filled
+    __shared__ unsigned s_mywv[2];
+    // per-unit constants and the little state of the scheduler live in LDS, not in registers: they are touched once per
+    // chunk by one lane, and the level march has no register to spare (a resident wave per SIMD is at stake)
+    enum { U_THR, U_RSJLO, U_RSKLO, U_RSNJ, U_RSNK, U_LCF, U_UPLCF0, U_UPLCF1, U_HIST, U_EVER, U_UCHG, U_PENDV, U_N };
+    __shared__ int s_u[U_N];
 
     const int tid = threadIdx.x;
     // debug phase timers (FSM_ENABLE_PROF builds): thread 0 sums per phase in registers, one flush per unit
@@ -794,7 +819,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     };
     if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
     __syncthreads();
-    const int ticket = s_ticket;
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
     // XS: `order` lists the units (direction, patch) of the whole iteration in ticket order -- any order in which a
     // unit comes after its upwind patches and after the patches of the previous sweep it has to see finished
     const int oidx = ticket / pa.batch, z = ticket - oidx * pa.batch;
@@ -826,8 +851,33 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     }
     const int grp = a.slots[z];   // slot (NS == 1) or slot group (NS == 2)
     if (grp < 0) {  // converged source(s): nothing to do, but never leave a waiter hanging
-        if (tid == 0) __hip_atomic_store(my_prog, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(my_prog, SKIP ? FSM_FIN : 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
+    }
+    // SKIP: when the previous sweep (of this source group) has finished every patch and changed no node, this sweep cannot
+    // change one either (by induction along its own order every node sees the neighbour values of its last visit): the unit
+    // is done before it starts, and so is every later sweep until the host looks at the iteration's change
+    if constexpr (SKIP) {
+        const int sigma0 = pa.ndir * pa.iter_ptr[0] + dir;   // global sweep number, 0-based
+        if (pa.sw && sigma0 >= 1 && sigma0 < pa.n_sw_sweeps) {
+            if (tid == 0) {
+                const unsigned long long v = __hip_atomic_load(pa.sw + (size_t)(sigma0 - 1) * pa.n_sw_groups + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_act = ((unsigned)v == (unsigned)pa.n_patches && (v >> 32) == 0ull) ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_act) {
+                if (tid == 0) {
+                    __hip_atomic_store(my_prog, FSM_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(pa.sw + (size_t)sigma0 * pa.n_sw_groups + grp, 1ull);
+                    if (FSM_ENABLE_PROF && a.prof && ticket < 65536) {
+                        unsigned long long* tr = a.prof + 8 + 4 * (size_t)ticket;
+                        tr[0] = trace_t0; tr[1] = trace_t0; tr[2] = wall_clock64();
+                        tr[3] = (unsigned long long)TJ | ((unsigned long long)TK << 16) | ((unsigned long long)dir << 32) | ((unsigned long long)z << 40) | (0xffffull << 48);
+                    }
+                }
+                return;
+            }
+        }
     }
     const int* up_j = TJ > 0 ? prog + (TK * npj + TJ - 1) : nullptr;
     const int* up_k = (IS3D && TK > 0) ? prog + ((TK - 1) * npj + TJ) : nullptr;
@@ -1060,22 +1110,8 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     // neighbours only -- the sweep direction orders the visits, it does not enter the formula -- so a node that was visited
     // in sweep sigma-1 and whose neighbours have not changed since satisfies T <= update(neighbours) already.  A chunk is a
     // no-op when no brick of its read set (own nodes + halo) changed during sweep sigma-1 or so far in this sweep.
-    const int sigma = SKIP ? pa.ndir * pa.iter_ptr[0] + dir + 1 : 0;
-    const int thr = sigma - 1 > 0 ? sigma - 1 : 0;
-    int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;   // one stamp set per group
-    // natural J / K extent of the read set (own + halo columns), fixed for the whole patch
-    int rs_jlo, rs_jhi, rs_klo, rs_khi;
-    {
-        const int ja = j0 - H < 0 ? 0 : j0 - H, jb = jmaxp + H > NJ - 1 ? NJ - 1 : jmaxp + H;
-        const int ka = k0 - H < 0 ? 0 : k0 - H, kb = kmaxp + H > NK - 1 ? NK - 1 : kmaxp + H;
-        rs_jlo = (rj ? NJ - 1 - jb : ja) / FSM_BRICK;
-        rs_jhi = (rj ? NJ - 1 - ja : jb) / FSM_BRICK;
-        rs_klo = (rk ? NK - 1 - kb : ka) / FSM_BRICK;
-        rs_khi = (rk ? NK - 1 - ka : kb) / FSM_BRICK;
-    }
-    const int rs_nj = rs_jhi - rs_jlo + 1, rs_nk = rs_khi - rs_klo + 1;
-    const int my_bj = jn / FSM_BRICK - rs_jlo;
-    const int my_bk = kn / FSM_BRICK - rs_klo;
+    // (SKIP kernels: sweep number sigma = global sweep index + 1; the read set of the unit in bricks, J / K extent -- see
+    //  the scheduler set-up below; all of it in LDS)
     unsigned long long nevals = 0;
 
     T dec[NS];
@@ -1087,7 +1123,6 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
 #pragma unroll
     for (int q = 0; q < 2 * H; ++q) carry[q] = PINF;
     bool have_prev = false;   // carry[] is valid (the previous chunk was evaluated)
-    bool quiet = true;        // the previous chunk was skipped or changed nothing
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
     int pending = 0;            // progress value of the previous chunk, published once its stores have drained
     int n_done = 0;             // chunks of this unit evaluated so far
@@ -1118,7 +1153,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             if (pp) {
                 const unsigned long long t0 = wall_clock64();
                 int spins = 0;
-                while (__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0x3fffffff) {
+                while (__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (SKIP ? FSM_FIN : 0x3fffffff)) {
                     if ((++spins & 63) == 0) {
                         if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                         if (wall_clock64() - t0 > pa.timeout_ticks) {
@@ -1134,18 +1169,195 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     }
     if (CHASE_OK && chase) chase_wait(Lc - C, -1, false);   // (covers the prefetch of the first chunk)
     if (!SKIP) { issue_static(Lc); pref_for = Lc; }
+    if constexpr (SKIP) {
+        // Slab mask of the unit: F bricks in which some brick of the read set (own + halo columns: <= 3 x 3 bricks in J, K)
+        // changed during sweep sigma-1 or already in this one.  The sweeps before this one are over for every column the
+        // unit reads (the wait above; one launch per sweep: the previous launch), so their stamps are final; what the
+        // upwind patches of THIS sweep change afterwards arrives with their progress values, what the unit changes
+        // itself it adds to the mask.  Changes of other nodes of a straddling brick may or may not be seen: they do
+        // not matter (not in the read set), seeing them only costs an evaluation.
+        const int nsw = (pa.nbf + 31) >> 5;
+        for (int w = tid; w < nsw; w += NT) s_slab[w] = 0u;
+        for (int w = tid; w < 9 * SLABW; w += NT) s_stamped[w / SLABW][w % SLABW] = 0u;
+        if (tid < 64) s_chg[tid] = 0;
+        if (tid == 0) {
+            s_cwi[0] = -1; s_cwi[1] = -1; s_mywi = -1;
+            // natural J / K extent of the read set (own + halo columns) in bricks, fixed for the whole unit
+            const int ja = j0 - H < 0 ? 0 : j0 - H, jb = jmaxp + H > NJ - 1 ? NJ - 1 : jmaxp + H;
+            const int ka = k0 - H < 0 ? 0 : k0 - H, kb = kmaxp + H > NK - 1 ? NK - 1 : kmaxp + H;
+            const int jlo = (rj ? NJ - 1 - jb : ja) / FSM_BRICK, jhi = (rj ? NJ - 1 - ja : jb) / FSM_BRICK;
+            const int klo = (rk ? NK - 1 - kb : ka) / FSM_BRICK, khi = (rk ? NK - 1 - ka : kb) / FSM_BRICK;
+            s_u[U_RSJLO] = jlo; s_u[U_RSNJ] = jhi - jlo + 1;
+            s_u[U_RSKLO] = klo; s_u[U_RSNK] = khi - klo + 1;
+            const int sg = pa.ndir * pa.iter_ptr[0] + dir + 1;   // this sweep's number, 1-based
+            s_u[U_THR] = sg - 1 > 0 ? sg - 1 : 0;
+            s_u[U_LCF] = Lc;
+            // first chunk start of the two upwind units (their chunk index = (level - start) / C)
+            const int lsj = Ls - PJ, lsk = Ls - PK, mu = TJ + TK - 1;
+            s_u[U_UPLCF0] = lsj - (((lsj - mu) % C + C) % C);
+            s_u[U_UPLCF1] = lsk - (((lsk - mu) % C + C) % C);
+            s_u[U_HIST] = 0; s_u[U_EVER] = 0; s_u[U_UCHG] = 0; s_u[U_PENDV] = 0;
+        }
+        __syncthreads();
+        {
+            const int jlo = s_u[U_RSJLO], nj = s_u[U_RSNJ], klo = s_u[U_RSKLO], nk = s_u[U_RSNK], thr = s_u[U_THR];
+            const int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;   // one stamp set per group
+            const int total = pa.nbf * nj * nk;
+            for (int b = tid; b < total; b += NT) {
+                const int bf = b % pa.nbf, jk = b / pa.nbf;
+                const int bj = jlo + jk % nj, bk = klo + jk / nj;
+                const int v = __hip_atomic_load(stamp + ((size_t)bk * pa.nbj + bj) * pa.nbf + bf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= thr) atomicOr(&s_slab[bf >> 5], 1u << (bf & 31));
+            }
+        }
+        __syncthreads();
+    }
     FSM_PMARK(5)   // ticket, setup, wait for the previous sweep
     const unsigned long long trace_t1 = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
+    // ---- SKIP kernels: the scheduler -------------------------------------------------------------------------------
+    // Thread 0 decides, chunk by chunk, whether a chunk can change anything, from three sources that cost it no extra
+    // memory round trip: the slab mask (above), the change flags that ride on the upwind progress values it has to read
+    // anyway (the last four chunks; older ones from the upwind unit's change map, one cached word per 32 chunks), and
+    // its own changes.  A chunk whose read set holds no change since the unit's columns were last visited is a no-op
+    // (DESIGN.md section 4a): the scheduler steps over it and publishes the progress, a run of such chunks costs one pass
+    // of a scalar loop, and the workgroup only synchronises where a chunk has to be evaluated.
+    // change map of unit (patch index pidx) of this launch, edge e
+    auto cmap_of = [&](int pidx, int e) -> unsigned* {
+        return pa.cmap + ((((size_t)(XS ? dir : 0) * pa.batch + z) * pa.n_patches + (size_t)pidx) * 2 + e) * pa.cw;
+    };
+    // any brick of the slab mask set within the natural F range [flo, fhi]
+    auto slab_any = [&](int flo, int fhi) -> bool {
+        const int b0 = flo / FSM_BRICK, b1 = fhi / FSM_BRICK;
+        for (int w = b0 >> 5; w <= (b1 >> 5); ++w) {
+            const int lo = w == (b0 >> 5) ? (b0 & 31) : 0, hi = w == (b1 >> 5) ? (b1 & 31) : 31;
+            const unsigned msk = (hi == 31 ? 0xffffffffu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+            if (s_slab[w] & msk) return true;
+        }
+        return false;
+    };
+    // natural F range of the nodes of chunk L, `ext` more levels / columns on either side (the read set: ext = H)
+    auto chunk_frange = [&](int L, int ext, int& flo, int& fhi) {
+        int ia = L - ext - jmaxp - kmaxp, ib = L + C - 1 + ext - j0 - k0;
+        ia = ia < 0 ? 0 : ia;
+        ib = ib > NF - 1 ? NF - 1 : ib;
+        flo = rf ? NF - 1 - ib : ia;
+        fhi = rf ? NF - 1 - ia : ib;
+    };
+    // did upwind unit e (0: J, 1: K) change its edge columns in the chunk(s) chunk `need - C + 1` reads?  v: its progress
+    // value, known to cover `need`.  (H = 2 reads one level further back: the chunk before as well.)
+    auto up_dirty = [&](int v, int need, int e) -> bool {
+        if (v >= FSM_FIN && !((v >> e) & 1)) return false;   // finished, never touched that edge
+        for (int p2 = 0; p2 < H; ++p2) {
+            const int nd = need - p2 * C;
+            const int ulcf = s_u[U_UPLCF0 + e];
+            const int ciu = (nd - C - ulcf) / C;
+            if (nd - C - ulcf < 0) continue;                 // before the upwind unit's first chunk
+            int bit;
+            const int d = v >= FSM_FIN ? 4 : ((v >> 8) - nd) / C;
+            if (d < 4) {
+                bit = (v >> (2 * d + e)) & 1;
+            } else {
+                const int w = ciu >> 5;
+                if (w >= pa.cw) continue;                    // beyond its last chunk
+                if (s_cwi[e] != w || s_cwl[e] < nd) {
+                    // (the word is read after the progress value that makes its bits final was seen)
+                    s_cwl[e] = v >= FSM_FIN ? 0x7fffffff : (v >> 8);
+                    const unsigned* um = cmap_of(e == 0 ? TK * npj + TJ - 1 : (TK - 1) * npj + TJ, e);
+                    s_cwv[e] = __hip_atomic_load(um + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_cwi[e] = w;
+                }
+                bit = (s_cwv[e] >> (ciu & 31)) & 1u;
+            }
+            if (bit) return true;
+        }
+        return false;
+    };
+    // wait until *ptr >= want (progress values only grow); returns the value seen, ok = false: abort / time-out
+    auto poll_until = [&](const int* ptr, int want, bool& ok) -> int {
+        unsigned long long t0 = 0;
+        int spins = 0;
+        for (;;) {
+            const int v = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v >= want) return v;
+            if (spins == 0) t0 = wall_clock64();
+            if ((++spins & 63) == 0) {
+                if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; return v; }
+                if (wall_clock64() - t0 > pa.timeout_ticks) {
+                    __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    return v;
+                }
+            }
+            __builtin_amdgcn_s_sleep(FSM_POLL_SLEEP);
+        }
+    };
     for (; Lc <= Le; Lc += C) {
+        if constexpr (SKIP) {
+            FSM_PMARK(0)
+            if (tid == 0) {
+                int L = Lc, act = 1, h = s_u[U_HIST];
+                const int lcf = s_u[U_LCF];
+                for (;;) {
+                    if (L > Le) { act = 0; break; }
+                    const int need = L + C - 1, need8 = need << 8;
+                    int vj = FSM_FIN, vk = FSM_FIN;
+                    bool ok = true;
+                    if (up_j) { vj = pre_j >= need8 ? pre_j : poll_until(up_j, need8, ok); pre_j = vj; }
+                    if (up_k && ok) { vk = pre_k >= need8 ? pre_k : poll_until(up_k, need8, ok); pre_k = vk; }
+                    if (!ok) { act = 0; break; }
+                    if (L == lcf && vj >= FSM_FIN && !(vj & 1) && vk >= FSM_FIN && !(vk & 2)) {
+                        // both upwind units are over and never touched the columns this unit reads: with a clean slab
+                        // mask the whole unit is a no-op
+                        bool any = false;
+                        for (int w = 0; w < ((pa.nbf + 31) >> 5); ++w) any |= s_slab[w] != 0u;
+                        if (!any) {
+                            __hip_atomic_store(my_prog, FSM_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            L = Le + 1;
+                            act = 0;
+                            break;
+                        }
+                    }
+                    int flo, fhi;
+                    chunk_frange(L, H, flo, fhi);
+                    bool dirty = slab_any(flo, fhi);
+                    if (!dirty && up_j) dirty = up_dirty(vj, need, 0);
+                    if (!dirty && up_k) dirty = up_dirty(vk, need, 1);
+                    if (dirty) break;
+                    if (pending) { act = 2; break; }   // the stores of the chunk before have to drain before progress moves on
+                    L += C;
+                    h = (h << 2) & 0xff;
+                    __hip_atomic_store(my_prog, L > Le ? (FSM_FIN | s_u[U_EVER]) : ((L << 8) | h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_u[U_HIST] = h;
+                s_next = L;
+                s_act = act;
+            }
+            __syncthreads();   // also: every read of the previous chunk's LDS tile is done
+            const int act = __builtin_amdgcn_readfirstlane(s_act), Ln = __builtin_amdgcn_readfirstlane(s_next);
+            if (Ln != Lc) {
+                have_prev = false;
+                Lc = Ln;
+            }
+            if (act == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(my_prog, s_u[U_PENDV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pending = 0;
+                Lc -= C;   // (the loop header adds it back: the scheduler runs again from the same chunk)
+                continue;
+            }
+            if (act == 0) break;
+        }
         const int L0 = Lc;
         const int eoff = jp + kp - L0;
         const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;       // active levels e = ea..eb
         const int eb = eoff + NF - 1 < C - 1 ? eoff + NF - 1 : C - 1;
-        FSM_PMARK(0)
+        if constexpr (!SKIP) { FSM_PMARK(0) }
 
         // (1) wait until both upwind patches have published every level <= L0+C-2
         //     The counters were sampled during the previous chunk's march (see below): when that old sample
         //     already suffices -- the upwind patches are normally ahead -- no load latency is paid here.
+        if constexpr (!SKIP) {
         if (CHASE_OK && chase) {
             chase_wait(L0, pre_j, true);
         } else if (tid == 0 && (up_j || up_k) && !((up_j ? pre_j : 0x3fffffff) >= L0 + C - 1 && (up_k ? pre_k : 0x3fffffff) >= L0 + C - 1)) {
@@ -1167,54 +1379,10 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                 __builtin_amdgcn_s_sleep(FSM_POLL_SLEEP);
             }
         }
-        // (1b) read set of this chunk in bricks: F range from the levels, J/K from the patch
-        int rs_flo, rs_nf;
-        {
-            int ia = L0 - H - jmaxp - kmaxp, ib = L0 + C - 1 + H - j0 - k0;
-            ia = ia < 0 ? 0 : ia;
-            ib = ib > NF - 1 ? NF - 1 : ib;
-            rs_flo = (rf ? NF - 1 - ib : ia) / FSM_BRICK;
-            rs_nf = (rf ? NF - 1 - ia : ib) / FSM_BRICK - rs_flo + 1;
-        }
-        // The stamps are only consulted when the neighbourhood looks quiet (first chunk, previous
-        // chunk skipped or evaluated without a change); next to an advancing front the chunk is
-        // simply evaluated -- always correct, and no check latency on the busy path.
-        if (SKIP && !quiet) {
-            if (tid < 64) s_chg[tid] = 0;
-            if (tid == 0) s_skip = 0;
-        } else if (SKIP) {
-            if (tid < 64) {
-                const int nb = rs_nf * rs_nj * rs_nk;  // <= 4*3*3
-                int mx = -1;
-                for (int b = tid; b < nb; b += 64) {
-                    const int bf = rs_flo + b % rs_nf, bj = rs_jlo + (b / rs_nf) % rs_nj, bk = rs_klo + b / (rs_nf * rs_nj);
-                    const int v = __hip_atomic_load(stamp + ((size_t)bk * pa.nbj + bj) * pa.nbf + bf, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    mx = v > mx ? v : mx;
-                }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const int o = __shfl_xor(mx, off, 64);
-                    mx = o > mx ? o : mx;
-                }
-                if (tid == 0) s_skip = mx < thr;
-                s_chg[tid] = 0;
-            }
-        }
         __syncthreads();  // also: every read of the previous chunk's LDS tile is done
+        }
         if (tid == 0) s_anychg = 0;   // (read last before this barrier; written again only after the staging barrier)
         FSM_PMARK(1)
-        if (SKIP && s_skip) {
-            // nothing in the read set changed since this chunk was last evaluated: no-op
-            have_prev = false;
-            quiet = true;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores of the chunk before, if any
-            __syncthreads();  // s_skip is rewritten by the next chunk
-            if (tid == 0)
-                __hip_atomic_store(my_prog, Lc + C > Le ? 0x3fffffff : Lc + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pending = 0;
-            continue;
-        }
         if (pref_for != L0) issue_static(L0);
         nevals += (eb >= ea) ? (unsigned)(eb - ea + 1) : 0u;   // per active source, see the end
 
@@ -1268,7 +1436,7 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             if (ulrow[it] >= 0) Tt[ulrow[it]] = uv[it];
         if (H == 2 && xlrow >= 0) Tt[xlrow] = xv;
         __syncthreads();
-        if (tid == 0 && pending) __hip_atomic_store(my_prog, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && pending) __hip_atomic_store(my_prog, SKIP ? s_u[U_PENDV] : pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pending = 0;
         // sample the upwind counters for the NEXT chunk now: the loads complete during the march (counters only
         // grow, an old sample is a safe lower bound)
@@ -1276,9 +1444,9 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
             // upwind halo of the NEXT chunk (levels L0+C-1 .. L0+2C-2), when the counters sampled for THIS chunk already
             // cover it (every wave decides from the sample of its own first lane; a wave that cannot yet loads at the top
             // of the next chunk as before)
-            const int need_n = L0 + 2 * C - 1;
-            const int sj = up_j ? __builtin_amdgcn_readfirstlane(pre_j) : 0x3fffffff;
-            const int sk = up_k ? __builtin_amdgcn_readfirstlane(pre_k) : 0x3fffffff;
+            const int need_n = SKIP ? (L0 + 2 * C - 1) << 8 : L0 + 2 * C - 1;   // (SKIP: progress values carry 8 flag bits)
+            const int sj = up_j ? __builtin_amdgcn_readfirstlane(pre_j) : 0x7fffffff;
+            const int sk = up_k ? __builtin_amdgcn_readfirstlane(pre_k) : 0x7fffffff;
             if (sj >= need_n && sk >= need_n) {
 #pragma unroll
                 for (int it = 0; it < NUPI; ++it) {
@@ -1313,17 +1481,6 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         // (4) prefetch the next chunk's static inputs; they land during the march
         if (Lc + C <= Le) { issue_static(Lc + C); pref_for = Lc + C; }
 
-        // brick (along F) of this thread's node at level e: it crosses at most one brick border
-        // inside the chunk, at e = e_split
-        int my_bf0, e_split;
-        {
-            const int ip0 = L0 - jp - kp;                 // i' at e = 0
-            const int i0n = rf ? NF - 1 - ip0 : ip0;      // natural i at e = 0; moves by sf per level
-            const int b0 = (i0n >= 0 ? i0n : 0) / FSM_BRICK;
-            my_bf0 = b0 - rs_flo;
-            const int rem = rf ? (i0n - b0 * FSM_BRICK) + 1 : (b0 + 1) * FSM_BRICK - i0n;
-            e_split = rem;
-        }
         // 2-D first-order patches are ONE wavefront: the J neighbours are the adjacent lanes, so the march
         // exchanges values with DPP wave shifts instead of an LDS write -> read round trip per level; the
         // two halo columns are static within the chunk and sit in registers (used by the end lanes only)
@@ -1336,7 +1493,6 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                 hdn[ee] = Tt[(PJ + H) * RS + ee + H + 1];       // column PJ at tile q+1
             }
         }
-        bool chg_a = false, chg_b = false;
         bool changed = false;
         // A lone wavefront issues in order, so where the march is latency bound (the one-wave 2-D patches) its
         // length IS the instruction count.  The 2-D kernels carry specialised copies of the level march
@@ -1378,13 +1534,6 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         }
 #pragma unroll
         for (int q = 0; q < 2 * H; ++q) carry[q] = own[C + q];
-        if (SKIP) {
-            // mark the bricks this thread changed (LDS flags, then one atomicMax per brick)
-            const int base = (my_bk * rs_nj + my_bj) * rs_nf;
-            const int ba = my_bf0, bb2 = my_bf0 + (rf ? -1 : 1);
-            if (chg_a && ba >= 0 && ba < rs_nf) s_chg[base + ba] = 1;
-            if (chg_b && bb2 >= 0 && bb2 < rs_nf) s_chg[base + bb2] = 1;
-        }
         FSM_PMARK(3)
         if (FSM_ENABLE_PROF) ++pchunks;
 
@@ -1393,10 +1542,33 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         // block-wide "did anything change": one LDS flag (cleared before the staging barrier), a ballot per wave.
         // (__syncthreads_or is a library routine with a dispatch-packet load, DPP and LDS reductions and two
         // barriers: measurable at once per chunk.)
-        if (wave_any(changed) && (tid & 63) == 0) s_anychg = 1;
+        // SKIP kernels: bit 1 / bit 2 = a column within H of the patch's downwind J / K edge changed; and the bricks a
+        // thread changed are flagged for the stamps (a thread's C nodes lie in at most two bricks along F)
+        if constexpr (SKIP) {
+            const bool ej = changed && jp + H > jmaxp, ek = IS3D && changed && kp + H > kmaxp;
+            const int f = (wave_any(changed) ? 1 : 0) | (wave_any(ej) ? 2 : 0) | (wave_any(ek) ? 4 : 0);
+            if (f && (tid & 63) == 0) atomicOr(&s_anychg, f);
+            if (changed) {
+                // flag the bricks this thread changed (its nodes of the chunk lie in at most two bricks along F); the
+                // flags are turned into stamps, and cleared, after the barrier
+                int flo, fhi;
+                chunk_frange(L0, H, flo, fhi);
+                const int rs_flo = flo / FSM_BRICK, rs_nf = fhi / FSM_BRICK - rs_flo + 1;
+                const int ip0 = L0 - jp - kp;                                  // i' of this thread's node at e = 0
+                const int ia = ip0 + ea, ib = ip0 + eb;                        // its nodes in the chunk (ea <= eb: it changed one)
+                const int na = rf ? NF - 1 - ib : ia, nb2 = rf ? NF - 1 - ia : ib;
+                const int my_bj = (rj ? NJ - 1 - jp : jp) / FSM_BRICK - s_u[U_RSJLO], my_bk = (rk ? NK - 1 - kp : kp) / FSM_BRICK - s_u[U_RSKLO];
+                const int base = (my_bk * s_u[U_RSNJ] + my_bj) * rs_nf;
+                const int ba = na / FSM_BRICK - rs_flo, bb2 = nb2 / FSM_BRICK - rs_flo;
+                if (ba >= 0 && ba < rs_nf) s_chg[base + ba] = 1;
+                if (bb2 != ba && bb2 >= 0 && bb2 < rs_nf) s_chg[base + bb2] = 1;
+            }
+        } else {
+            if (wave_any(changed) && (tid & 63) == 0) s_anychg = 1;
+        }
         __syncthreads();
-        const bool any_changed = s_anychg != 0;
-        quiet = !any_changed;
+        const int chg_flags = SKIP ? __builtin_amdgcn_readfirstlane(s_anychg) : s_anychg;
+        const bool any_changed = chg_flags != 0;
         if (any_changed) {
 #pragma unroll
             for (int it = 0; it < NOWN; ++it) {
@@ -1411,26 +1583,62 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
                 }
             }
         }
-        // (5b) stamp the changed bricks with this sweep's number (after the barrier above, the LDS
-        //      flags of all threads are visible); ordered before the counter by the drain below
-        if (SKIP && tid < 64) {
-            const int nb = rs_nf * rs_nj * rs_nk;
-            for (int b = tid; b < nb; b += 64) {
-                if (s_chg[b]) {
-                    const int bf = rs_flo + b % rs_nf, bj = rs_jlo + (b / rs_nf) % rs_nj, bk = rs_klo + b / (rs_nf * rs_nj);
-                    atomicMax(stamp + ((size_t)bk * pa.nbj + bj) * pa.nbf + bf, sigma);
+        // (5b) stamp the changed bricks with this sweep's number; ordered before the progress value by the drain below
+        if constexpr (SKIP) {
+            if (any_changed && tid < 64) {
+                int flo, fhi;
+                chunk_frange(L0, H, flo, fhi);
+                const int rs_flo = flo / FSM_BRICK, rs_nf = fhi / FSM_BRICK - rs_flo + 1;   // read set of the chunk along F, in bricks
+                const int rs_jlo = s_u[U_RSJLO], rs_nj = s_u[U_RSNJ], rs_klo = s_u[U_RSKLO], rs_nk = s_u[U_RSNK];
+                int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;
+                const int sigma = pa.ndir * pa.iter_ptr[0] + dir + 1;
+                const int nb = rs_nf * rs_nj * rs_nk;
+                for (int b = tid; b < nb; b += 64) {
+                    if (s_chg[b]) {
+                        s_chg[b] = 0;
+                        const int jk = b / rs_nf, bf = rs_flo + b % rs_nf;
+                        // one atomic per brick and unit: a brick is in the read set of several consecutive chunks
+                        if (!((s_stamped[jk][bf >> 5] >> (bf & 31)) & 1u)) {
+                            atomicOr(&s_stamped[jk][bf >> 5], 1u << (bf & 31));
+                            const int bj = rs_jlo + jk % rs_nj, bk = rs_klo + jk / rs_nj;
+                            atomicMax(stamp + ((size_t)bk * pa.nbj + bj) * pa.nbf + bf, sigma);
+                        }
+                    }
                 }
+            }
+            if (tid == 0) {
+                if (any_changed) {
+                    // own changes into the slab mask (the next chunks read these bricks) and into the unit's change map
+                    int flo, fhi;
+                    chunk_frange(L0, 0, flo, fhi);
+                    for (int b = flo / FSM_BRICK; b <= fhi / FSM_BRICK; ++b) s_slab[b >> 5] |= 1u << (b & 31);
+                    const int ci = (L0 - s_u[U_LCF]) / C, w = ci >> 5;
+                    if ((chg_flags & 6) && w < pa.cw) {
+                        if (s_mywi != w) { s_mywi = w; s_mywv[0] = 0u; s_mywv[1] = 0u; }
+                        for (int e2 = 0; e2 < 2; ++e2)
+                            if (chg_flags & (2 << e2)) {
+                                s_mywv[e2] |= 1u << (ci & 31);
+                                __hip_atomic_store(cmap_of(TK * npj + TJ, e2) + w, s_mywv[e2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                    }
+                    s_u[U_UCHG] = 1;
+                }
+                const int h2 = ((s_u[U_HIST] << 2) | (chg_flags >> 1)) & 0xff, ev2 = s_u[U_EVER] | (chg_flags >> 1);
+                s_u[U_HIST] = h2;
+                s_u[U_EVER] = ev2;
+                s_u[U_PENDV] = Lc + C > Le ? (FSM_FIN | ev2) : (((Lc + C) << 8) | h2);
             }
         }
         // (6) publish later: the counter moves once every wave has drained these stores -- at the
         //     staging barrier of the next chunk, or right after the loop
-        pending = Lc + C > Le ? 0x3fffffff : Lc + C;
+        if constexpr (SKIP) pending = 1;   // (the value is in s_u[U_PENDV])
+        else pending = Lc + C > Le ? 0x3fffffff : Lc + C;
         if (FSM_EARLY_PUB > 0 && n_done < FSM_EARLY_PUB) {
             // the first chunks of a unit sit on the ramp of the patch wavefront (the downstream patches are waiting for
             // exactly these levels): publish at once instead of at the next staging barrier
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(my_prog, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(my_prog, SKIP ? s_u[U_PENDV] : pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pending = 0;
         }
         ++n_done;
@@ -1439,7 +1647,12 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
     if (pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(my_prog, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(my_prog, SKIP ? s_u[U_PENDV] : pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (SKIP) {   // this sweep's tally for the whole-sweep shortcut of the next one
+        const int sigma0 = pa.ndir * pa.iter_ptr[0] + dir;
+        if (tid == 0 && pa.sw && sigma0 < pa.n_sw_sweeps)
+            atomicAdd(pa.sw + (size_t)sigma0 * pa.n_sw_groups + grp, 1ull | (s_u[U_UCHG] ? (1ull << 32) : 0ull));
     }
 
     if (FSM_ENABLE_PROF && a.prof && tid == 0) {
@@ -1448,9 +1661,13 @@ __global__ __launch_bounds__(PJ* PK, FSM_MINW) void fsm_sweep_persistent(const P
         atomicAdd(a.prof + 6, 1ull);
         atomicAdd(a.prof + 7, (unsigned long long)pchunks);
         // per-unit trace (last iteration wins): entry, first chunk, exit on the 100 MHz clock; patch and direction
-        unsigned long long* tr = a.prof + 8 + 4 * (size_t)ticket;
-        tr[0] = trace_t0; tr[1] = trace_t1; tr[2] = wall_clock64();
-        tr[3] = (unsigned long long)TJ | ((unsigned long long)TK << 16) | ((unsigned long long)dir << 32) | ((unsigned long long)z << 40);
+        // (trace buffer: 65536 unit entries of 4 words, then 80 chunk records of 5 stamps for each of the first 8192 units)
+        if (ticket < 65536) {
+            unsigned long long* tr = a.prof + 8 + 4 * (size_t)ticket;
+            tr[0] = trace_t0; tr[1] = trace_t1; tr[2] = wall_clock64();
+            tr[3] = (unsigned long long)TJ | ((unsigned long long)TK << 16) | ((unsigned long long)dir << 32) | ((unsigned long long)z << 40) |
+                    ((unsigned long long)pchunks << 48);
+        }
     }
 #undef FSM_PMARK
     // L1 decrease of every source of the unit: wavefront reduction, one atomic per wave and source
