@@ -73,6 +73,24 @@ int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_
                       double dx, double dz, double xmin, double zmin, double eps, int maxit, int weno,
                       int rotated_template, int n_slots, int device);
 
+/* The same grids on SEVERAL devices of one node -- what Grid3D's multi-source overload does with host threads
+ * (ttcr/Grid3D.h:810-853; the reference's OpenCL backend keeps one solver per thread slot in one process,
+ * ttcr/Grid3Drnfs_OpenCL.h:172-193): one replica of the grid per entry of `devices` (the same ordinal may appear more
+ * than once), the slowness replicated, the n_slots traveltime slots divided over the replicas (slot s lives on replica
+ * s / ceil(n_slots / n_devices)), the sources of ttcr_fsm_raytrace_multi block-distributed over ALL slots like
+ * get_blk_size (ttcr/Grid3D.h:451-465) and every replica driven by its own host thread: no exchange between devices
+ * during a solve, results identical to the one-device grid.  Every other entry point takes such a handle unchanged
+ * (a slot argument is routed to the replica that owns the slot).  ttcr_fsm3d_create / ttcr_fsm2d_create with
+ * device = -1 do the same when the environment variable TTCR_AMD_DEVICES holds a comma-separated device list, so an
+ * unmodified caller can be spread over the GPUs of a node.  ttcr_fsm_n_devices: replicas behind a handle (1: plain). */
+int ttcr_fsm3d_create_multi(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncy,
+                            uint32_t ncz, double dx, double xmin, double ymin, double zmin, double eps,
+                            int maxit, int weno, int n_slots, int translate_origin, const int* devices, int n_devices);
+int ttcr_fsm2d_create_multi(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncz,
+                            double dx, double dz, double xmin, double zmin, double eps, int maxit, int weno,
+                            int rotated_template, int n_slots, const int* devices, int n_devices);
+int ttcr_fsm_n_devices(const ttcr_fsm_grid* g);
+
 /* Replaces: `del self.grid` (src/ttcrpy/rgrid.pyx:284-285). */
 void ttcr_fsm_destroy(ttcr_fsm_grid* g);
 

@@ -161,6 +161,11 @@ int main() {
         // the same with raypaths: Grid3D's multi-source r_data overload (ttcr/Grid3D.h:855-905) calls the adapter's
         // single-source r_data virtual from its host threads at once -- every thread has to get the rays of its own call
         {
+            // (interior receivers: a walk that starts on the corner of the grid can leave it, which the reference and
+            //  this backend both answer with an exception -- thrown inside a host thread of Grid3D's pool)
+            const std::vector<sxyz<float>> Ri = {{2.0f, 2.0f, 2.0f}, {9.0f, 4.0f, 4.5f}, {4.4f, 0.3f, 1.9f}};
+            const std::vector<std::vector<sxyz<float>>> mRx = {Ri, {{2.0f, 2.0f, 2.0f}}, {{9.0f, 4.0f, 5.0f}, {3.0f, 0.0f, 1.0f}}, Ri};
+            const std::vector<std::vector<sxyz<float>>> mTx = {{{3.3f, 1.1f, 2.7f}}, {{8.0f, 2.0f, 4.0f}}, {{2.2f, -1.0f, 0.9f}}, {{5.5f, 3.3f, 1.1f}}};
             std::vector<std::vector<float>> rtt(mTx.size()), qtt;
             std::vector<std::vector<std::vector<sxyz<float>>>> rrays(mTx.size()), qrays;
             bool same = true;

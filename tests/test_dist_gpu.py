@@ -86,6 +86,11 @@ def test_sharded_raytrace_world2_hip(tmp_path, oracle):
     # 7 sources over 2 ranks: 4 + 3 (get_blk_size), 25 receivers each; every rank solved with the HIP library
     assert res[0]["rows"] == [100] and res[1]["rows"] == [75]
     assert all(x["lib"].endswith("libttcr_amd.so") for x in res)
+    # which collective backend ran: RCCL (nccl) whenever the box shows one GPU per rank, gloo only on a one-GPU box
+    import torch
+    want_backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    assert [x["backend"] for x in res] == [want_backend] * 2, (res[0]["backend"], res[0]["ndev"])
+    print("collective backend of the two ranks:", want_backend, "(devices visible: %d)" % res[0]["ndev"])
     assert res[1]["tt"] is None
     n = 48
     dx = 20.0 / (n - 1)

@@ -128,3 +128,39 @@ def test_adapter_drives_the_gpu_through_the_reference_base_classes(oracle):
     m2 = [([[3.3, 1.1]], 0.0, rx2), ([[7.0, 2.0]], 0.5, [[5.0, 1.0]]), ([[0.0, 0.0]], 0.0, rx2)]
     want2 = np.concatenate([oracle.solve2d(np.float32, (20, 12), 0.5, 0.25, (0, 0), s2, a, t0=[b], rcv=c)["tt_rcv"] for a, b, c in m2])
     np.testing.assert_array_equal(np.array(vals["a2_multi"], dtype=np.float32), want2)
+
+
+def test_reference_cython_wrapper_builds_against_the_backend(tmp_path):
+    """INTEGRATION.md section 1 carried out: integration/patch_ttcrpy.sh applies the three edits to a scratch copy of the
+    reference's own src/ttcrpy/rgrid.pyx / rgrid.pxd (sed commands only -- nothing of the reference lives in this
+    repository), cythonizes it and compiles it against the adapters and libttcr_amd.so.  The module cannot be imported here
+    (it imports vtk at module scope, which this image lacks -- SURVEY section 8c), so its symbol table is read instead: the
+    init function is there, the backend's ABI is what it links against, and no OpenCL entry point is left."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src", "ttcrpy")):
+        pytest.skip("the reference tree is not present (GPU box)")
+    from ttcr_amd import build as B
+
+    if not os.path.exists(B.LIB):
+        pytest.skip("libttcr_amd.so has not been built")
+    out = tmp_path / "ttcrpy_patched"
+    r = subprocess.run([os.path.join(ROOT, "integration", "patch_ttcrpy.sh"), ref, str(out), "-O0"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    so = r.stdout.strip().splitlines()[-1]
+    assert os.path.exists(so) and str(out) in so
+    # the edited sources name the adapter where the reference named its OpenCL classes
+    pyx = open(out / "ttcrpy" / "rgrid.pyx").read()
+    pxd = open(out / "ttcrpy" / "rgrid.pxd").read()
+    assert pyx.count("new Grid3Drnfs_amd[double,uint32_t](") == 2 and pyx.count("new Grid2Drnfs_amd[") == 4
+    assert "_OpenCL[" not in pyx and "_OpenCL[" not in pxd and 'cdef extern from "Grid3Drnfs_amd.h"' in pxd
+    nm = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln}
+    undefined = {ln.split()[-1] for ln in nm.splitlines() if " U " in ln}
+    assert "PyInit_rgrid" in defined
+    for sym in ("ttcr_fsm3d_create", "ttcr_fsm2d_create", "ttcr_fsm_destroy", "ttcr_fsm_set_slowness", "ttcr_fsm_raytrace",
+                "ttcr_fsm_raytrace_rays", "ttcr_fsm_get_slot_rays", "ttcr_fsm_get_tt",
+                "ttcr_fsm_compute_slowness", "ttcr_fsm_get_niter", "ttcr_fsm_set_option", "ttcr_fsm_last_error"):
+        assert sym in undefined, sym
+    assert not [s for s in undefined if s.startswith("cl") and s[2:3].isupper()], "an OpenCL entry point is still linked"
+    ldd = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "libttcr_amd.so" in ldd and "OpenCL" not in ldd

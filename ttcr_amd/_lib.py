@@ -31,6 +31,9 @@ SYMBOLS = {
     "ttcr_fsm_last_error": (C.c_char_p, []),
     "ttcr_fsm3d_create": (_I, [C.POINTER(_P), _I, _I, _U32, _U32, _U32, _D, _D, _D, _D, _D, _I, _I, _I, _I, _I]),
     "ttcr_fsm2d_create": (_I, [C.POINTER(_P), _I, _I, _U32, _U32, _D, _D, _D, _D, _D, _I, _I, _I, _I, _I]),
+    "ttcr_fsm3d_create_multi": (_I, [C.POINTER(_P), _I, _I, _U32, _U32, _U32, _D, _D, _D, _D, _D, _I, _I, _I, _I, C.POINTER(_I), _I]),
+    "ttcr_fsm2d_create_multi": (_I, [C.POINTER(_P), _I, _I, _U32, _U32, _D, _D, _D, _D, _D, _I, _I, _I, _I, C.POINTER(_I), _I]),
+    "ttcr_fsm_n_devices": (_I, [_P]),
     "ttcr_fsm_destroy": (None, [_P]),
     "ttcr_fsm_set_slowness": (_I, [_P, _P, C.c_size_t]),
     "ttcr_fsm_set_slowness_device": (_I, [_P, _P, C.c_size_t]),

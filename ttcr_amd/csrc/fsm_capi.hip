@@ -18,6 +18,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ttcr_amd.h"
@@ -130,6 +131,24 @@ class GridBase {
     int mode = 2;  // 2: persistent kernel, one launch per sweep-iteration, sweeps overlap (default);
                    // 1: persistent kernel, one launch per sweep; 0: one launch per tile wavefront
     Timing timing;
+    // ttcr_fsm_set_option (a multi-device grid forwards it to its replicas)
+    virtual void apply_option(const std::string& k, double value) {
+        if (k == "fixed_iters") fixed_iters = (int)value;
+        else if (k == "max_batch") max_batch = (int)value;
+        else if (k == "use_graph") use_graph = value != 0;
+        else if (k == "combine_window_us") combine_window_us = (int)value;
+        else if (k == "mode") mode = (int)value;
+        else if (k == "skip") skip = (int)value;
+        else if (k == "tt_from_rp") ttrp = value != 0;
+        else if (k == "interp_vel") interp_vel = value != 0;
+        else if (k == "return_rays") return_rays = value != 0;
+        else throw ValueError("unknown option '" + k + "'");
+    }
+    virtual void get_niter(int slot, int* it, int* itw) const {
+        if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
+        if (it) *it = niter[slot];
+        if (itw) *itw = niterw[slot];
+    }
 };
 
 // tile shapes (threads = PJ*PK); see DESIGN.md section 4 for the LDS budget
@@ -340,6 +359,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_TIME_ORDER_BELOW")) time_order_below = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_PRE_MIN")) pre_min = std::atoi(e);                     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_SKIP_UNITS")) skip_units_min = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
@@ -478,7 +498,7 @@ class GridT : public GridBase {
         pa.evals = d_evals.p;
         pa.nbf = nbf; pa.nbj = nbj; pa.nbk = nbk;
         pa.ndir = DIM == 3 ? 8 : 4;
-        pa.skip = skip_now();
+        pa.skip = skip_now(batch) ? (std::getenv("TTCR_FSM_SKIP_ALL_DIRTY") ? 2 : 1) : 0;
         pa.cmap = d_cmap.p;
         pa.cw = cmap_words;
         pa.sw = d_sw.p;
@@ -499,11 +519,11 @@ class GridT : public GridBase {
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
-            if (skip_now()) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * ndir * 2 * cmap_words, stream));
+            if (skip_now(batch)) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * ndir * 2 * cmap_words, stream));
             const bool pre = DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0;   // counters sampled one chunk ahead (template PRE)
-            if (skip_now() && pre)
+            if (skip_now(batch) && pre)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
-            else if (skip_now())
+            else if (skip_now(batch))
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
             else if (pre)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
@@ -531,8 +551,8 @@ class GridT : public GridBase {
             // ticket + progress counters back to zero (the abort word [1] is sticky within an iteration)
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
-            if (skip_now()) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * 2 * cmap_words, stream));
-            if (skip_now())
+            if (skip_now(batch)) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * 2 * cmap_words, stream));
+            if (skip_now(batch))
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, false><<<grid, block, 0, stream>>>(pa);
             else
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, false><<<grid, block, 0, stream>>>(pa);
@@ -821,12 +841,23 @@ class GridT : public GridBase {
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
 
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
-    // exact skipping of chunks / units / sweeps that cannot change a node: on wherever it was measured to pay (profiles/r03)
-    int skip_default() const { return dim == 3 ? 1 : 0; }
+    // Exact skipping of chunks / units / sweeps that cannot change a node: on wherever it was measured to pay
+    // (profiles/r03/skip_sweep.txt).  What it saves is work, what it costs is a little of every chunk's time: a win once
+    // the chip is busy (512^3: from two slot groups on, 1.13x ... 1.6x at 32 groups), a loss of 5-15 % where a solve is
+    // bound by the dependent chain of its units anyway (a lone source or pair; 256^3 and smaller up to 8 sources).  The
+    // WENO stage gains at every batch size (its chunks are expensive).  TTCR_FSM_SKIP_UNITS: work units per sweep from
+    // which the first-order 3-D sweeps skip.
+    int skip_units_min = 2048;
+    int skip_default(int entries) const {
+        if (dim != 3) return 0;
+        if (stage == 1) return 1;
+        return (long long)n_patches * entries >= skip_units_min ? 1 : 0;
+    }
     bool persistent_now() const { return mode >= 1 || stage == 1; }
     // the rotated-template sweeps change nodes without stamping their bricks: no skipping next to them
-    bool skip_now() const {
-        const int on = skip < 0 ? skip_default() : skip;
+    // `entries`: batch entries (slot groups / slots) swept together
+    bool skip_now(int entries) const {
+        const int on = skip < 0 ? skip_default(entries) : skip;
         // (the SKIP kernels pack a level count and 8 flag bits into one progress word, and keep one mask bit per F brick)
         const bool fits = (long long)geom.NF + geom.NJ + geom.NK < (1ll << 22) && nbf <= 32 * FSM_SLAB_WORDS;
         return on != 0 && fits && !(dim == 2 && rotated && !weno && dx == dz);
@@ -883,7 +914,7 @@ class GridT : public GridBase {
         if (use_graph) {
             hipGraph_t& graph = graphs[stage];
             hipGraphExec_t& graph_exec = graph_execs[stage];
-            const int key = mode * 2 + (skip_now() ? 1 : 0);
+            const int key = mode * 2 + (skip_now(batch) ? 1 : 0);
             if (!graph_exec || graph_batches[stage] != batch || graph_modes[stage] != key) {
                 if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
                 if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
@@ -1032,7 +1063,7 @@ class GridT : public GridBase {
             timing.iterations = std::max(timing.iterations, it_total);
             // the stamps of the first-order stage say nothing about the WENO stencil: every brick counts as changed in the
             // last sweep, so that the first WENO sweep visits every node once with the new formula
-            if (stage == 0 && weno && skip_now()) {
+            if (stage == 0 && weno) {
                 // (and no whole-sweep shortcut across the stage boundary: a tally of zero finished units never qualifies)
                 HIP_CHECK(hipMemsetAsync(d_sw.p, 0, sizeof(unsigned long long) * (size_t)sw_sweeps * n_groups(), stream));
                 for (int s2 : slot_ids)
@@ -1514,6 +1545,197 @@ class GridT : public GridBase {
     }
 };
 
+// ---- one grid on several devices ---------------------------------------------------------------------------
+// Replaces, for more than one GPU, what Grid3D's multi-source overload does with host threads (ttcr/Grid3D.h:810-853;
+// the reference's OpenCL backend keeps one solver per thread slot in one process, ttcr/Grid3Drnfs_OpenCL.h:172-193):
+// one replica of the grid per device (slowness replicated, traveltime slots divided), the sources of a call block-
+// distributed over the slots exactly like get_blk_size (ttcr/Grid3D.h:451-465), slot s living on device s / spd
+// (spd = slots per device), one host thread per device driving its replica, no exchange between devices during a
+// solve.  Everything else (getTT, receivers, iteration counts, rays) is forwarded to the replica that owns the slot.
+class MultiGrid : public GridBase {
+   public:
+    std::vector<std::unique_ptr<GridBase>> rep;
+    int spd = 1;   // slots per replica (the last one may hold fewer)
+    std::vector<long long> rays_off{0};
+    std::vector<char> rays_pts;
+    size_t pt_bytes = 12;
+
+    template <typename Make>
+    MultiGrid(int n_slots_, const std::vector<int>& devs, Make&& make) {
+        n_slots = n_slots_;
+        const int nd = std::min<int>((int)devs.size(), n_slots);
+        spd = (n_slots + nd - 1) / nd;
+        for (int r = 0; r * spd < n_slots; ++r) rep.emplace_back(make(std::min(spd, n_slots - r * spd), devs[r]));
+        const GridBase& g0 = *rep[0];
+        dim = g0.dim; dtype = g0.dtype; device = g0.device; n_nodes = g0.n_nodes; n_cells = g0.n_cells;
+        elem_size = g0.elem_size; weno = g0.weno;
+        pt_bytes = elem_size * (dim == 3 ? 3 : 2);
+        niter.assign(n_slots, 0);
+        niterw.assign(n_slots, 0);
+        // the slowness of one device is handed to the others device to device
+        for (size_t a = 0; a < rep.size(); ++a)
+            for (size_t b = 0; b < rep.size(); ++b)
+                if (rep[a]->device != rep[b]->device) {
+                    (void)hipSetDevice(rep[a]->device);
+                    (void)hipDeviceEnablePeerAccess(rep[b]->device, 0);   // (already enabled / not possible: the copy is staged)
+                    (void)hipGetLastError();
+                }
+    }
+    GridBase& of(int slot, int& local) const {
+        if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
+        local = slot % spd;
+        return *rep[slot / spd];
+    }
+    void apply_option(const std::string& k, double value) override {
+        GridBase::apply_option(k, value);
+        for (auto& r : rep) r->apply_option(k, value);
+    }
+    void set_slowness(const void* s, size_t n, bool on_device, bool c_order = false) override {
+        for (auto& r : rep) r->set_slowness(s, n, on_device, c_order);
+    }
+    void get_slowness(void* out, size_t n) override { rep[0]->get_slowness(out, n); }
+    void validate_points(int n_tx, const void* tx, int n_rx, const void* rx) override { rep[0]->validate_points(n_tx, tx, n_rx, rx); }
+    void get_tt(int slot, void* out, size_t n) override { int l; GridBase& g = of(slot, l); g.get_tt(l, out, n); }
+    void* tt_device(int slot) override { int l; GridBase& g = of(slot, l); return g.tt_device(l); }
+    void* tt_device_view(int slot, size_t* stride) override { int l; GridBase& g = of(slot, l); return g.tt_device_view(l, stride); }
+    void interp(int slot, int n, const void* pts, void* out) override { int l; GridBase& g = of(slot, l); g.interp(l, n, pts, out); }
+    void compute_slowness(int n, const void* pts, bool translated, void* out) override { rep[0]->compute_slowness(n, pts, translated, out); }
+    void get_niter(int slot, int* it, int* itw) const override { int l; GridBase& g = of(slot, l); g.get_niter(l, it, itw); }
+    void rays_size(size_t* n_rays, size_t* n_points) const override { *n_rays = rays_off.size() - 1; *n_points = (size_t)rays_off.back(); }
+    void get_rays(long long* offsets, void* pts) const override {
+        std::memcpy(offsets, rays_off.data(), rays_off.size() * sizeof(long long));
+        if (!rays_pts.empty()) std::memcpy(pts, rays_pts.data(), rays_pts.size());
+    }
+    void raytrace_rays(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) override {
+        int l; GridBase& g = of(slot, l);
+        g.raytrace_rays(l, n_tx, tx, t0, n_rx, rx, tt_out);
+        timing = g.timing;
+    }
+    void slot_rays_size(int slot, size_t* n_rays, size_t* n_points) const override { int l; GridBase& g = of(slot, l); g.slot_rays_size(l, n_rays, n_points); }
+    void get_slot_rays(int slot, long long* offsets, void* pts) const override { int l; GridBase& g = of(slot, l); g.get_slot_rays(l, offsets, pts); }
+
+    void raytrace_multi(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off, const void* rx_v,
+                        void* tt_out_v, int forced_slot, const int* explicit_slots = nullptr, bool force_rays = false) override {
+        const auto wall0 = std::chrono::steady_clock::now();
+        timing = Timing();
+        timing.n_sources = n_src;
+        rays_off.assign(1, 0);
+        rays_pts.clear();
+        if (n_src <= 0) return;
+        const bool want_rays = return_rays.load() || force_rays;
+        const char* tx = (const char*)tx_v; const char* t0 = (const char*)t0_v; const char* rx = (const char*)rx_v;
+        char* tt_out = (char*)tt_out_v;
+        if (forced_slot >= 0) {
+            if (n_src != 1) throw ValueError("a thread number can only be given for a single source");
+            int l; GridBase& g = of(forced_slot, l);
+            g.raytrace_multi(n_src, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, l, nullptr, force_rays);
+            timing = g.timing;
+            if (want_rays) {
+                size_t nr = 0, np = 0;
+                g.rays_size(&nr, &np);
+                rays_off.resize(nr + 1);
+                rays_pts.resize(np * pt_bytes);
+                g.get_rays(rays_off.data(), rays_pts.data());
+            }
+            return;
+        }
+        // every point of the call is checked before anything is solved, like on one device
+        for (int n = 0; n < n_src; ++n) {
+            if (tx_off[n + 1] <= tx_off[n]) throw ValueError("every source needs at least one point");
+            rep[0]->validate_points(tx_off[n + 1] - tx_off[n], tx + pt_bytes * tx_off[n], rx_off[n + 1] - rx_off[n], rx + pt_bytes * rx_off[n]);
+        }
+        // (source, slot, round): the block distribution of get_blk_size over ALL slots, or the slots the caller names
+        struct Item { int src, slot, round; };
+        std::vector<Item> items;
+        if (explicit_slots) {
+            for (int n = 0; n < n_src; ++n) {
+                if (explicit_slots[n] < 0 || explicit_slots[n] >= n_slots) throw ValueError("Thread number is larger than number of threads");
+                if (n > 0 && explicit_slots[n] <= explicit_slots[n - 1]) throw ValueError("explicit slots must be ascending and distinct");
+                items.push_back({n, explicit_slots[n], 0});
+            }
+        } else {
+            const int n_blk = std::min(n_slots, n_src);
+            std::vector<int> blk(n_blk, 0), start(n_blk, 0);
+            for (int n = 0; n < n_src; ++n) blk[n % n_blk] += 1;
+            for (int b = 1; b < n_blk; ++b) start[b] = start[b - 1] + blk[b - 1];
+            for (int b = 0; b < n_blk; ++b)
+                for (int r = 0; r < blk[b]; ++r) items.push_back({start[b] + r, b, r});
+        }
+        int rounds = 0;
+        for (const Item& it : items) rounds = std::max(rounds, it.round + 1);
+        std::vector<std::vector<long long>> src_ray_len(want_rays ? n_src : 0);
+        std::vector<std::vector<char>> src_ray_pts(want_rays ? n_src : 0);
+        std::vector<std::exception_ptr> errs(rep.size());
+        std::vector<Timing> dev_t(rep.size());
+        auto work = [&](int d) {
+            try {
+                GridBase& g = *rep[d];
+                for (int r = 0; r < rounds; ++r) {
+                    std::vector<Item> mine;
+                    for (const Item& it : items)
+                        if (it.round == r && it.slot / spd == d) mine.push_back(it);
+                    if (mine.empty()) continue;
+                    std::sort(mine.begin(), mine.end(), [](const Item& a, const Item& b) { return a.slot < b.slot; });
+                    const int m = (int)mine.size();
+                    std::vector<int> to(m + 1, 0), ro(m + 1, 0), ls(m);
+                    for (int q = 0; q < m; ++q) {
+                        to[q + 1] = to[q] + tx_off[mine[q].src + 1] - tx_off[mine[q].src];
+                        ro[q + 1] = ro[q] + rx_off[mine[q].src + 1] - rx_off[mine[q].src];
+                        ls[q] = mine[q].slot % spd;
+                    }
+                    std::vector<char> stx(pt_bytes * to[m]), st0(elem_size * to[m]), srx(pt_bytes * std::max(ro[m], 1)), stt(elem_size * std::max(ro[m], 1));
+                    for (int q = 0; q < m; ++q) {
+                        const int n = mine[q].src;
+                        std::memcpy(stx.data() + pt_bytes * to[q], tx + pt_bytes * tx_off[n], pt_bytes * (to[q + 1] - to[q]));
+                        std::memcpy(st0.data() + elem_size * to[q], t0 + elem_size * tx_off[n], elem_size * (to[q + 1] - to[q]));
+                        std::memcpy(srx.data() + pt_bytes * ro[q], rx + pt_bytes * rx_off[n], pt_bytes * (ro[q + 1] - ro[q]));
+                    }
+                    g.raytrace_multi(m, to.data(), stx.data(), st0.data(), ro.data(), srx.data(), stt.data(), -1, ls.data(), want_rays);
+                    dev_t[d].sweep_ms += g.timing.sweep_ms;
+                    dev_t[d].launches += g.timing.launches;
+                    dev_t[d].node_updates += g.timing.node_updates;
+                    dev_t[d].evaluated_updates += g.timing.evaluated_updates;
+                    dev_t[d].iterations = std::max(dev_t[d].iterations, g.timing.iterations);
+                    for (int q = 0; q < m; ++q)
+                        std::memcpy(tt_out + elem_size * rx_off[mine[q].src], stt.data() + elem_size * ro[q], elem_size * (ro[q + 1] - ro[q]));
+                    if (want_rays) {   // the replica's rays are in the row order of ITS call
+                        size_t nr = 0, np = 0;
+                        g.rays_size(&nr, &np);
+                        std::vector<long long> off(nr + 1);
+                        std::vector<char> pts(np * pt_bytes);
+                        g.get_rays(off.data(), pts.data());
+                        for (int q = 0; q < m; ++q) {
+                            const int n = mine[q].src;
+                            for (int k = ro[q]; k < ro[q + 1]; ++k) src_ray_len[n].push_back(off[k + 1] - off[k]);
+                            src_ray_pts[n].assign(pts.begin() + off[ro[q]] * pt_bytes, pts.begin() + off[ro[q + 1]] * pt_bytes);
+                        }
+                    }
+                }
+            } catch (...) { errs[d] = std::current_exception(); }
+        };
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < rep.size(); ++d) th.emplace_back(work, (int)d);
+        work(0);
+        for (auto& t : th) t.join();
+        for (auto& e : errs)
+            if (e) std::rethrow_exception(e);
+        for (int s2 = 0; s2 < n_slots; ++s2) { int l; GridBase& g = of(s2, l); g.get_niter(l, &niter[s2], &niterw[s2]); }
+        for (const Timing& t : dev_t) {   // the devices run side by side: times are the slowest one's, counts add up
+            timing.sweep_ms = std::max(timing.sweep_ms, t.sweep_ms);
+            timing.launches += t.launches;
+            timing.node_updates += t.node_updates;
+            timing.evaluated_updates += t.evaluated_updates;
+            timing.iterations = std::max(timing.iterations, t.iterations);
+        }
+        if (want_rays)
+            for (int n = 0; n < n_src; ++n) {
+                for (long long len : src_ray_len[n]) rays_off.push_back(rays_off.back() + len);
+                rays_pts.insert(rays_pts.end(), src_ray_pts[n].begin(), src_ray_pts[n].end());
+            }
+        timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+};
+
 }  // namespace ttcr_amd
 
 // =============================================================================== C ABI
@@ -1568,6 +1790,95 @@ static int pick_device(int device) {
     return device;
 }
 
+// device list of a grid: the caller's, else TTCR_AMD_DEVICES ("0,1,2,3") when the caller asks for "the current device"
+// (an unmodified ttcrpy script is spread over the GPUs of a node by setting the variable), else the one device
+static std::vector<int> device_list(int device, const int* devices, int n_devices) {
+    std::vector<int> devs;
+    if (devices && n_devices > 0) {
+        for (int q = 0; q < n_devices; ++q) devs.push_back(pick_device(devices[q]));
+    } else if (device < 0 && std::getenv("TTCR_AMD_DEVICES") && *std::getenv("TTCR_AMD_DEVICES")) {
+        std::stringstream ss(std::getenv("TTCR_AMD_DEVICES"));
+        std::string tok;
+        while (std::getline(ss, tok, ',')) {
+            if (tok.empty()) continue;
+            char* endp = nullptr;
+            const long v = std::strtol(tok.c_str(), &endp, 10);
+            if (*endp) throw ValueError("TTCR_AMD_DEVICES: expected a comma-separated list of device ordinals");
+            devs.push_back(pick_device((int)v));
+        }
+    }
+    if (devs.empty()) devs.push_back(pick_device(device));
+    return devs;
+}
+
+template <typename Make>
+static std::unique_ptr<GridBase> make_grid(int n_slots, const std::vector<int>& devs, Make&& make) {
+    if (devs.size() == 1 || n_slots == 1) return std::unique_ptr<GridBase>(make(n_slots, devs[0]));
+    return std::unique_ptr<GridBase>(new MultiGrid(n_slots, devs, make));
+}
+
+static void create3d(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz, double dx,
+                     double xmin, double ymin, double zmin, double eps, int maxit, int weno, int translate_origin, int n_slots,
+                     int device, const int* devices, int n_devices) {
+    if (!out) throw ValueError("null output handle");
+    *out = nullptr;
+    if (dtype != TTCR_F32 && dtype != TTCR_F64) throw ValueError("dtype must be TTCR_F32 or TTCR_F64");
+    if (ncx < 1 || ncy < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
+    if (n_slots < 1) throw ValueError("n_slots must be >= 1");
+    if (!(dx > 0)) throw ValueError("dx must be positive");
+    if (weno && (ncx < 3 || ncy < 3 || ncz < 3)) throw ValueError("weno=True needs at least 3 cells per axis");
+    const std::vector<int> devs = device_list(device, devices, n_devices);
+    auto g = std::make_unique<ttcr_fsm_grid>();
+    auto make = [&](int ns, int dev) -> GridBase* {
+        GridBase* r;
+        if (dtype == TTCR_F32)
+            r = new GridT<float>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, ns, translate_origin != 0, dev, weno != 0);
+        else
+#ifdef FSM_DEV_F32_ONLY   // tuning builds: half the instantiations
+            throw ValueError("tuning build without double grids");
+#else
+            r = new GridT<double>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, ns, translate_origin != 0, dev, weno != 0);
+#endif
+        r->weno = weno != 0;
+        return r;
+    };
+    g->impl = make_grid(n_slots, devs, make);
+    g->impl->weno = weno != 0;
+    *out = g.release();
+}
+
+static void create2d(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncz, double dx, double dz,
+                     double xmin, double zmin, double eps, int maxit, int weno, int rotated_template, int n_slots, int device,
+                     const int* devices, int n_devices) {
+    if (!out) throw ValueError("null output handle");
+    *out = nullptr;
+    if (dtype != TTCR_F32 && dtype != TTCR_F64) throw ValueError("dtype must be TTCR_F32 or TTCR_F64");
+    if (ncx < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
+    if (n_slots < 1) throw ValueError("n_slots must be >= 1");
+    if (!(dx > 0) || !(dz > 0)) throw ValueError("dx and dz must be positive");
+    if (weno && (ncx < 3 || ncz < 3)) throw ValueError("weno=True needs at least 3 cells per axis");
+    const std::vector<int> devs = device_list(device, devices, n_devices);
+    auto g = std::make_unique<ttcr_fsm_grid>();
+    auto make = [&](int ns, int dev) -> GridBase* {
+        GridBase* r;
+        if (dtype == TTCR_F32)
+            r = new GridT<float>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, ns, false, dev, weno != 0);
+        else
+#ifdef FSM_DEV_F32_ONLY
+            throw ValueError("tuning build without double grids");
+#else
+            r = new GridT<double>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, ns, false, dev, weno != 0);
+#endif
+        r->weno = weno != 0;
+        r->rotated = rotated_template != 0;
+        return r;
+    };
+    g->impl = make_grid(n_slots, devs, make);
+    g->impl->weno = weno != 0;
+    g->impl->rotated = rotated_template != 0;
+    *out = g.release();
+}
+
 extern "C" {
 
 int ttcr_fsm_device_count(void) {
@@ -1578,57 +1889,36 @@ int ttcr_fsm_device_count(void) {
 
 const char* ttcr_fsm_last_error(void) { return g_last_error.c_str(); }
 
-int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz,
-                      double dx, double xmin, double ymin, double zmin, double eps, int maxit, int weno, int n_slots,
-                      int translate_origin, int device) {
+int ttcr_fsm3d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz, double dx,
+                      double xmin, double ymin, double zmin, double eps, int maxit, int weno, int n_slots, int translate_origin,
+                      int device) {
+    return guarded([&] { create3d(out, dtype, cell_slowness, ncx, ncy, ncz, dx, xmin, ymin, zmin, eps, maxit, weno, translate_origin, n_slots, device, nullptr, 0); });
+}
+int ttcr_fsm3d_create_multi(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncy, uint32_t ncz, double dx,
+                            double xmin, double ymin, double zmin, double eps, int maxit, int weno, int n_slots, int translate_origin,
+                            const int* devices, int n_devices) {
     return guarded([&] {
-        if (!out) throw ValueError("null output handle");
-        *out = nullptr;
-        if (dtype != TTCR_F32 && dtype != TTCR_F64) throw ValueError("dtype must be TTCR_F32 or TTCR_F64");
-        if (ncx < 1 || ncy < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
-        if (n_slots < 1) throw ValueError("n_slots must be >= 1");
-        if (!(dx > 0)) throw ValueError("dx must be positive");
-        if (weno && (ncx < 3 || ncy < 3 || ncz < 3))
-            throw ValueError("weno=True needs at least 3 cells per axis (the reference's stencil reads idx+2 at idx == 1, ttcr/Grid3Drn.h:3086-3092)");
-        const int dev = pick_device(device);
-        auto g = std::make_unique<ttcr_fsm_grid>();
-        if (dtype == TTCR_F32)
-            g->impl.reset(new GridT<float>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev, weno != 0));
-#ifdef FSM_DEV_F32_ONLY   // tuning builds: half the instantiations
-        else throw ValueError("tuning build without double grids");
-#else
-        else
-            g->impl.reset(new GridT<double>(3, cell_slowness != 0, ncx, ncy, ncz, dx, dx, xmin, ymin, zmin, eps, maxit, n_slots, translate_origin != 0, dev, weno != 0));
-#endif
-        g->impl->weno = weno != 0;
-        *out = g.release();
+        if (!devices || n_devices < 1) throw ValueError("device list is empty");
+        create3d(out, dtype, cell_slowness, ncx, ncy, ncz, dx, xmin, ymin, zmin, eps, maxit, weno, translate_origin, n_slots, -1, devices, n_devices);
     });
 }
 
 int ttcr_fsm2d_create(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncz, double dx, double dz,
                       double xmin, double zmin, double eps, int maxit, int weno, int rotated_template, int n_slots, int device) {
+    return guarded([&] { create2d(out, dtype, cell_slowness, ncx, ncz, dx, dz, xmin, zmin, eps, maxit, weno, rotated_template, n_slots, device, nullptr, 0); });
+}
+int ttcr_fsm2d_create_multi(ttcr_fsm_grid** out, int dtype, int cell_slowness, uint32_t ncx, uint32_t ncz, double dx, double dz,
+                            double xmin, double zmin, double eps, int maxit, int weno, int rotated_template, int n_slots,
+                            const int* devices, int n_devices) {
     return guarded([&] {
-        if (!out) throw ValueError("null output handle");
-        *out = nullptr;
-        if (dtype != TTCR_F32 && dtype != TTCR_F64) throw ValueError("dtype must be TTCR_F32 or TTCR_F64");
-        if (ncx < 1 || ncz < 1) throw ValueError("grid needs at least one cell per axis");
-        if (n_slots < 1) throw ValueError("n_slots must be >= 1");
-        if (!(dx > 0) || !(dz > 0)) throw ValueError("dx and dz must be positive");
-        if (weno && (ncx < 3 || ncz < 3)) throw ValueError("weno=True needs at least 3 cells per axis");
-        const int dev = pick_device(device);
-        auto g = std::make_unique<ttcr_fsm_grid>();
-        if (dtype == TTCR_F32)
-            g->impl.reset(new GridT<float>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev, weno != 0));
-#ifdef FSM_DEV_F32_ONLY
-        else throw ValueError("tuning build without double grids");
-#else
-        else
-            g->impl.reset(new GridT<double>(2, cell_slowness != 0, ncx, 0, ncz, dx, dz, xmin, 0.0, zmin, eps, maxit, n_slots, false, dev, weno != 0));
-#endif
-        g->impl->weno = weno != 0;
-        g->impl->rotated = rotated_template != 0;
-        *out = g.release();
+        if (!devices || n_devices < 1) throw ValueError("device list is empty");
+        create2d(out, dtype, cell_slowness, ncx, ncz, dx, dz, xmin, zmin, eps, maxit, weno, rotated_template, n_slots, -1, devices, n_devices);
     });
+}
+int ttcr_fsm_n_devices(const ttcr_fsm_grid* g) {
+    if (!g) return 0;
+    const MultiGrid* m = dynamic_cast<const MultiGrid*>(g->impl.get());
+    return m ? (int)m->rep.size() : 1;
 }
 
 void ttcr_fsm_destroy(ttcr_fsm_grid* g) { delete g; }
@@ -1812,32 +2102,14 @@ int ttcr_fsm_compute_slowness(ttcr_fsm_grid* g, int n_pts, const void* pts, int 
     return guarded_on(g, [&] { g->impl->compute_slowness(n_pts, pts, translated != 0, out); });
 }
 int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw) {
-    return guarded_on(g, [&] {
-        if (slot < 0 || slot >= g->impl->n_slots) throw ValueError("Thread number is larger than number of threads");
-        if (niter) *niter = g->impl->niter[slot];
-        if (niterw) *niterw = g->impl->niterw[slot];
-    });
+    return guarded_on(g, [&] { g->impl->get_niter(slot, niter, niterw); });
 }
 int ttcr_fsm_n_slots(const ttcr_fsm_grid* g) { return g->impl->n_slots; }
 size_t ttcr_fsm_n_nodes(const ttcr_fsm_grid* g) { return g->impl->n_nodes; }
 size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g) { return g->impl->n_cells; }
 
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value) {
-    return guarded_on(g, [&] {
-        const std::string k(key ? key : "");
-        if (k == "fixed_iters") g->impl->fixed_iters = (int)value;
-        else if (k == "max_batch") g->impl->max_batch = (int)value;
-        else if (k == "use_graph") g->impl->use_graph = value != 0;
-        else if (k == "combine_window_us") g->impl->combine_window_us = (int)value;
-        else if (k == "mode") g->impl->mode = (int)value;
-        else if (k == "skip") g->impl->skip = (int)value;
-        else if (k == "tt_from_rp") {
-            g->impl->ttrp = value != 0;
-        } else if (k == "interp_vel") g->impl->interp_vel = value != 0;
-        else if (k == "return_rays") {
-            g->impl->return_rays = value != 0;
-        } else throw ValueError("unknown option '" + k + "'");
-    });
+    return guarded_on(g, [&] { g->impl->apply_option(std::string(key ? key : ""), value); });
 }
 
 int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points) {

@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
             s_u[U_RSJLO] = jlo; s_u[U_RSNJ] = jhi - jlo + 1;
             s_u[U_RSKLO] = klo; s_u[U_RSNK] = khi - klo + 1;
             const int sg = pa.ndir * pa.iter_ptr[0] + dir + 1;   // this sweep's number, 1-based
-            s_u[U_THR] = sg - 1 > 0 ? sg - 1 : 0;
+            s_u[U_THR] = pa.skip == 2 ? -(1 << 30) : (sg - 1 > 0 ? sg - 1 : 0);   // (skip == 2, tuning: every brick counts as changed)
             s_u[U_LCF] = Lc;
             // first chunk start of the two upwind units (their chunk index = (level - start) / C)
             const int lsj = Ls - PJ, lsk = Ls - PK, mu = TJ + TK - 1;

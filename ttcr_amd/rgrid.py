@@ -66,6 +66,18 @@ def _first_rows(a):
     return np.sort(order[bounds[:-1]])
 
 
+def _device_arg(device):
+    """`device` keyword of the grid classes: a HIP device ordinal (-1: the current device; with TTCR_AMD_DEVICES set,
+    the devices it lists), or a sequence of ordinals -- one replica of the grid per entry, the traveltime slots
+    (n_threads) divided over them and the sources of a call block-distributed over all slots (ttcr_fsm3d_create_multi)."""
+    if isinstance(device, (list, tuple, np.ndarray)):
+        devs = tuple(int(d) for d in device)
+        if not devs:
+            raise ValueError("device list is empty")
+        return devs if len(devs) > 1 else devs[0]
+    return int(device)
+
+
 class _GridBase:
     """State and helpers shared by the 3-D and 2-D wrappers."""
 
@@ -89,6 +101,11 @@ class _GridBase:
     def n_threads(self):
         """int: number of threads (here: device-resident traveltime slots) for raytracing"""
         return self._n_threads
+
+    @property
+    def n_devices(self):
+        """int: replicas of the grid (one per device of the `device` list) behind this object"""
+        return int(self._lib.ttcr_fsm_n_devices(self._h))
 
     def set_use_thread_pool(self, use_thread_pool):
         """No-op: sources of one call are always swept concurrently on the device
@@ -370,7 +387,7 @@ class _Grid3d(_GridBase):
         self.translate_grid = bool(translate_grid)
         self.fsm_gpu = bool(fsm_gpu)
         self.method = method
-        self._device = int(device)
+        self._device = _device_arg(device)
 
         if method == 'FSM':
             if np.abs(self._dx - self._dy) > 0.000001 or np.abs(self._dx - self._dz) > 0.000001:
@@ -380,10 +397,15 @@ class _Grid3d(_GridBase):
         else:
             raise ValueError('Method {0:s} undefined'.format(method))
         self._lib = _lib.load()
-        st = self._lib.ttcr_fsm3d_create(C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
-                                         int(self.cell_slowness), x.size - 1, y.size - 1, z.size - 1, self._dx,
-                                         float(x[0]), float(y[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
-                                         self._n_threads, int(self.translate_grid), self._device)
+        args = (C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
+                int(self.cell_slowness), x.size - 1, y.size - 1, z.size - 1, self._dx,
+                float(x[0]), float(y[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
+                self._n_threads, int(self.translate_grid))
+        if isinstance(self._device, tuple):   # one replica of the grid per listed device, slots divided (ttcr_amd.h)
+            devs = (C.c_int * len(self._device))(*self._device)
+            st = self._lib.ttcr_fsm3d_create_multi(*args, devs, len(self._device))
+        else:
+            st = self._lib.ttcr_fsm3d_create(*args, self._device)
         _lib.check(st)
         if self.tt_from_rp:
             self.set_option("tt_from_rp", 1)
@@ -624,7 +646,7 @@ class _Grid2d(_GridBase):
         self.fsm_gpu = bool(fsm_gpu)
         self.method = method
         self.aniso = aniso
-        self._device = int(device)
+        self._device = _device_arg(device)
         if method in ('SPM', 'DSPM'):
             raise NotImplementedError("method '%s' is outside the MI355X FSM path (SURVEY.md section 8)" % method)
         if method != 'FSM':
@@ -632,10 +654,15 @@ class _Grid2d(_GridBase):
         if aniso != 'iso':
             raise NotImplementedError('Anisotropic raytracing implemented only for SPM')
         self._lib = _lib.load()
-        st = self._lib.ttcr_fsm2d_create(C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
-                                         int(self.cell_slowness), x.size - 1, z.size - 1, self._dx, self._dz,
-                                         float(x[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
-                                         int(self.rotated_template), self._n_threads, self._device)
+        args = (C.byref(self._h), _lib.TTCR_F32 if dt == np.float32 else _lib.TTCR_F64,
+                int(self.cell_slowness), x.size - 1, z.size - 1, self._dx, self._dz,
+                float(x[0]), float(z[0]), self.eps, self.maxit, int(self.weno),
+                int(self.rotated_template), self._n_threads)
+        if isinstance(self._device, tuple):
+            devs = (C.c_int * len(self._device))(*self._device)
+            st = self._lib.ttcr_fsm2d_create_multi(*args, devs, len(self._device))
+        else:
+            st = self._lib.ttcr_fsm2d_create(*args, self._device)
         _lib.check(st)
         if self.tt_from_rp:   # Grid2Drn::getTraveltimeFromRaypath (ttcr/Grid2Drn.h:1478-1661)
             self.set_option("tt_from_rp", 1)
