@@ -155,6 +155,11 @@ int ttcr_fsm_compute_slowness(ttcr_fsm_grid* g, int n_pts, const void* pts, int 
 /* Replaces: get_niter()/get_niterw() (ttcr/Grid3Drnfs.h:56-57); per slot here
  * (the reference keeps one racy value per grid). */
 int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw);
+/* The quantity the stopping rule of the driver loop compared with eps * N (ttcr/Grid3Drnfs.h:141-152: `change`), for
+ * every sweep-iteration of the last solve of `slot`: first_order[0..n_first) and weno[0..n_weno) (entries beyond the
+ * iterations that ran are 0).  Here it is the fp64 sum of the decreases of all nodes over the iteration's sweeps (equal to
+ * the reference's sum of |T_old - T_new| in exact arithmetic; the reference adds it up sequentially in T1). */
+int ttcr_fsm_get_changes(ttcr_fsm_grid* g, int slot, double* first_order, int n_first, double* weno, int n_weno);
 
 /* Replaces: getNthreads() (ttcr/Grid3D.h) and the node/cell counts of rgrid.pyx:386-404. */
 int ttcr_fsm_n_slots(const ttcr_fsm_grid* g);

@@ -205,3 +205,44 @@ def test_heterogeneous_1e7_nodes_pins_niter(oracle):
     o_rcv = _check_all(g, solve_one, 2, bytes_per_job=5 * flat.size * 4)
     np.testing.assert_array_equal(tt, np.concatenate(o_rcv))
     assert g.get_niter(0) >= 4   # the case really iterates
+
+
+def test_stopping_rule_at_512_cubed_rough_model(oracle, capsys):
+    """The stopping rule at the headline size (1.3e8 nodes) on a model where it decides: a rough 512^3 fp32 medium (16^3-
+    node blocks of random slowness), one source, run to convergence.  The reference adds abs(T_old - T_new) over all
+    nodes sequentially in fp32 (ttcr/Grid3Drnfs.h:141-152): beyond ~1e7 nodes increments below half an ulp of the
+    running sum are lost, so its `change` UNDER-estimates the true L1 change; the kernels accumulate the decreases of
+    an iteration in fp64.  Checked: the field and `niter` against the oracle (= the reference's rule), and the per-
+    iteration change of both sums side by side -- the window in which the two rules could disagree is the gap between
+    them, reported relative to the threshold eps * N."""
+    import ttcr_amd
+
+    n = 512
+    dx = 20.0 / (n - 1)
+    x = np.arange(n) * dx
+    rng = np.random.default_rng(5)
+    c = rng.uniform(0.4, 1.0, (n // 16 + 2,) * 3)
+    s = np.repeat(np.repeat(np.repeat(c, 16, 0), 16, 1), 16, 2)[:n, :n, :n].astype(np.float32).copy()
+    src = cases.mt_sources(1)
+    rcv = cases.rcv_lattice3d()
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=1, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32)
+    tt = g.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv, slowness=s)
+    chg_gpu, _ = g.get_changes(0)
+    o = oracle.solve3d(np.float32, (n - 1,) * 3, dx, (0, 0, 0), s.flatten("F"), src, rcv=rcv)
+    chg_ref = np.asarray(o["change"], dtype=np.float64)
+    thr = float(np.float32(np.float32(1e-5) * np.float32(n ** 3)))   # epsilon *= N in T1 (ttcr/Grid3Drnfs.h:49)
+    with capsys.disabled():
+        print(f"\n512^3 rough model: niter gpu {g.get_niter(0)} / oracle {o['niter']}, threshold eps*N = {thr:.4g}")
+        for k in range(max(len(chg_gpu), len(chg_ref))):
+            a = chg_gpu[k] if k < len(chg_gpu) else float('nan')
+            b = chg_ref[k] if k < len(chg_ref) else float('nan')
+            print(f"  iteration {k + 1}: fp64 sum of decreases {a:.6e} | reference's sequential fp32 sum {b:.6e} | ratio {b / a if a else float('nan'):.4f}"
+                  f" | fp64 / threshold {a / thr:.3e}")
+    assert g.get_niter(0) == o["niter"] and o["niter"] >= 4
+    assert np.array_equal(g._flat_tt(0), o["tt"])
+    np.testing.assert_array_equal(tt, o["tt_rcv"])
+    # both sums agree on which side of the threshold every iteration falls
+    m = min(len(chg_gpu), len(chg_ref))
+    assert np.array_equal(chg_gpu[:m] >= thr, chg_ref[:m] >= thr)
+    # ... and the fp32 sum never exceeds the fp64 one by more than rounding (it loses increments, it does not invent them)
+    assert np.all(chg_ref[:m] <= chg_gpu[:m] * (1 + 1e-3))

@@ -120,6 +120,14 @@ class GridBase {
     int dim = 3, dtype = 0, n_slots = 1, device = 0;
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter, niterw;
+    // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
+    // order stage then WENO stage
+    std::vector<std::vector<double>> change_hist, change_histw;
+    virtual void get_changes(int slot, double* first, int n_first, double* wen, int n_weno) const {
+        if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
+        for (int q = 0; q < n_first; ++q) first[q] = (!change_hist.empty() && q < (int)change_hist[slot].size()) ? change_hist[slot][q] : 0.0;
+        for (int q = 0; q < n_weno; ++q) wen[q] = (!change_histw.empty() && q < (int)change_histw[slot].size()) ? change_histw[slot][q] : 0.0;
+    }
     bool weno = false;
     bool sweep45_strips = false;  // force the strip kernel of sweep45 (env TTCR_FSM_SWEEP45=strips; tests)
     bool rotated = false;  // 2-D rotated_template: sweep45 after every first-order sweep (ttcr/Grid2Drnfs.h:277-286)
@@ -999,6 +1007,9 @@ class GridT : public GridBase {
             fsm_init_source<T><<<1, 128, 0, stream>>>(ia);
             niter[slot] = 0;
             niterw[slot] = 0;
+            if (change_hist.empty()) { change_hist.resize(n_slots); change_histw.resize(n_slots); }
+            change_hist[slot].clear();
+            change_histw[slot].clear();
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(stream));  // pts vector goes out of scope below; also surfaces errors early
@@ -1054,6 +1065,7 @@ class GridT : public GridBase {
                 std::vector<int> next;
                 for (int s2 : active) {
                     (stage == 0 ? niter : niterw)[s2] = it;
+                    (stage == 0 ? change_hist : change_histw)[s2].push_back(h_change[s2]);
                     timing.node_updates += (long long)n_nodes * ndir;
                     const bool go_on = fixed_iters > 0 ? true : (h_change[s2] >= (double)epsilon);
                     if (go_on) next.push_back(s2);
@@ -1601,6 +1613,9 @@ class MultiGrid : public GridBase {
     void interp(int slot, int n, const void* pts, void* out) override { int l; GridBase& g = of(slot, l); g.interp(l, n, pts, out); }
     void compute_slowness(int n, const void* pts, bool translated, void* out) override { rep[0]->compute_slowness(n, pts, translated, out); }
     void get_niter(int slot, int* it, int* itw) const override { int l; GridBase& g = of(slot, l); g.get_niter(l, it, itw); }
+    void get_changes(int slot, double* first, int n_first, double* wen, int n_weno) const override {
+        int l; GridBase& g = of(slot, l); g.get_changes(l, first, n_first, wen, n_weno);
+    }
     void rays_size(size_t* n_rays, size_t* n_points) const override { *n_rays = rays_off.size() - 1; *n_points = (size_t)rays_off.back(); }
     void get_rays(long long* offsets, void* pts) const override {
         std::memcpy(offsets, rays_off.data(), rays_off.size() * sizeof(long long));
@@ -2103,6 +2118,12 @@ int ttcr_fsm_compute_slowness(ttcr_fsm_grid* g, int n_pts, const void* pts, int 
 }
 int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw) {
     return guarded_on(g, [&] { g->impl->get_niter(slot, niter, niterw); });
+}
+int ttcr_fsm_get_changes(ttcr_fsm_grid* g, int slot, double* first_order, int n_first, double* weno, int n_weno) {
+    return guarded_on(g, [&] {
+        if ((n_first > 0 && !first_order) || (n_weno > 0 && !weno) || n_first < 0 || n_weno < 0) throw ValueError("bad output buffers");
+        g->impl->get_changes(slot, first_order, n_first, weno, n_weno);
+    });
 }
 int ttcr_fsm_n_slots(const ttcr_fsm_grid* g) { return g->impl->n_slots; }
 size_t ttcr_fsm_n_nodes(const ttcr_fsm_grid* g) { return g->impl->n_nodes; }

@@ -139,6 +139,14 @@ class _GridBase:
         _lib.check(self._lib.ttcr_fsm_get_niter(self._h, int(thread_no), C.byref(a), C.byref(b)))
         return b.value
 
+    def get_changes(self, thread_no=0):
+        """(first-order, WENO) arrays with the L1 change of every sweep-iteration of the last solve in a slot -- the
+        quantity the stopping rule compares with eps * N (`change`, ttcr/Grid3Drnfs.h:141-152); fp64 sums of decreases here."""
+        n1, n2 = self.get_niter(thread_no), self.get_niterw(thread_no)
+        a, b = (C.c_double * max(n1, 1))(), (C.c_double * max(n2, 1))()
+        _lib.check(self._lib.ttcr_fsm_get_changes(self._h, int(thread_no), a, n1, b, n2))
+        return np.array(a[:n1]), np.array(b[:n2])
+
     def timing(self):
         """HIP-event timing of the last raytrace call (dict)."""
         t = _lib.Timing()
