@@ -73,44 +73,58 @@ def cpu_baseline(n=256, n_src=3):
         out["all_cores_sample"] = f"{nthr} sources, one per thread, {n}^3 nodes, {sum(its)} sweep-iterations in {el:.1f} s"
     except Exception as e:
         out["all_cores_error"] = str(e)[:200]
-    # the unmodified compiled reference, when its build travelled with the tree (kind would be "reference")
+    # the unmodified compiled reference, when its build travelled with the tree, on the SAME sample as the restatement
+    # (the first source on the n^3-node model): SURVEY 8(d)'s calibration ratio is taken on one sample, one core each
     try:
         if O.have_ref():
-            m = 129
-            dxm = 20.0 / (m - 1)
-            sm = np.repeat(gradient_slowness_f32(m, dxm), m * m)
             t = time.perf_counter()
-            r = O.ref_solve3d(np.float32, (m - 1,) * 3, dxm, (0, 0, 0), sm, [srcs[0]])
+            r1 = O.solve3d(np.float32, (n - 1,) * 3, dx, (0, 0, 0), s, [srcs[0]])
+            el_port = time.perf_counter() - t
+            t = time.perf_counter()
+            r = O.ref_solve3d(np.float32, (n - 1,) * 3, dx, (0, 0, 0), s, [srcs[0]])
             el = time.perf_counter() - t
-            out["reference_value"] = round(m ** 3 * r["niter"] / el / 1e6, 3)
-            out["reference_sample"] = f"unmodified reference (oracle/_ref), 1 source on {m}^3 nodes, {el:.1f} s, 1 core"
+            out["reference_value"] = round(n ** 3 * r["niter"] / el / 1e6, 3)
+            out["reference_sample"] = (f"unmodified reference (oracle/_ref), source 0 on the same {n}^3-node model, {r['niter']} sweep-iterations, "
+                                       f"{el:.1f} s on 1 core (grid construction included, as in ttcrpy)")
+            out["restatement_same_sample_value"] = round(n ** 3 * r1["niter"] / el_port / 1e6, 3)
+            out["calibration_ratio_restatement_over_reference"] = round(el / el_port, 2)
     except Exception as e:  # the baseline must never take the bench down
         out["reference_error"] = str(e)[:200]
     return out
 
 
-KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,true,true> (one launch per sweep-iteration)",
-           "1": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,false,false> (one launch per directional sweep)",
+KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,SKIP,1,2,true,true> (one launch per sweep-iteration; SKIP: template flag of "
+                "the build with the exact-skipping scheduler, the default from two slot groups on)",
+           "1": "fsm_sweep_persistent<float,16,16,8,true,SKIP,1,2,false,false> (one launch per directional sweep)",
            "0": "fsm_sweep_tile<float,16,16,16,true> (one launch per tile wavefront)"}
+PROFILE_DIRS = ("r03", "r02")
 
 
 def profiled_traffic(n, n_src_rank0, world):
     """HBM bytes per launch (one sweep-iteration of the batch) from the committed rocprofv3 PMC passes of this very command
-    (profiles/r02/traffic.json, written by scripts/pmc_run.sh + scripts/pmc_to_json.py: separate --pmc passes, KB units,
+    (profiles/rNN/traffic.json, written by scripts/pmc_run.sh + scripts/pmc_to_json.py: separate --pmc passes, KB units,
     gfx950 x2 correction of the read counter calibrated in the same run).  bench.py cannot profile itself; the record is
     tagged with the hash of the kernel sources it was taken with and is only reported when that hash is the one of the
-    library being benchmarked now -- otherwise `traffic` is null rather than stale."""
+    library being benchmarked now -- otherwise `traffic` is null rather than stale.  Returns (bytes, source, reads, writes)."""
     try:
         from ttcr_amd.build import source_hash
-        with open(os.path.join(ROOT, "profiles", "r02", "traffic.json")) as f:
-            rec = json.load(f)
-        if rec.get("source_hash") != source_hash():
-            return None, "profiles/r02/traffic.json is from other kernel sources (%s): not reported" % rec.get("source_hash")
-        if not (n == rec["size"] and n_src_rank0 == rec["sources"] and world == 1 and os.environ.get("TTCR_FSM_MODE", "2") == "2"):
-            return None, None
-        return (2.0 * rec["fetch_kb_per_launch"] + rec["write_kb_per_launch"]) * 1024.0, "profiles/r02/traffic.json"
+        note = None
+        for d in PROFILE_DIRS:
+            path = os.path.join(ROOT, "profiles", d, "traffic.json")
+            if not os.path.exists(path):
+                continue
+            with open(path) as f:
+                rec = json.load(f)
+            if rec.get("source_hash") != source_hash():
+                note = note or "profiles/%s/traffic.json is from other kernel sources (%s): not reported" % (d, rec.get("source_hash"))
+                continue
+            if not (n == rec["size"] and n_src_rank0 == rec["sources"] and world == 1 and os.environ.get("TTCR_FSM_MODE", "2") == "2"):
+                return None, None, None, None
+            rd, wr = 2.0 * rec["fetch_kb_per_launch"] * 1024.0, rec["write_kb_per_launch"] * 1024.0
+            return rd + wr, "profiles/%s/traffic.json" % d, rd, wr
+        return None, note, None, None
     except Exception:
-        return None, None
+        return None, None, None, None
 
 
 def measured_copy_bandwidth(dev, reps=5):
@@ -305,7 +319,7 @@ def main():
         bytes_total = BYTES_PER_NODE_ITER / 8.0 * evaluated
         achieved = bytes_total / (sweep_ms * 1e-3) / 1e9
         nominal = BYTES_PER_NODE_ITER * node_iters / (sweep_ms * 1e-3) / 1e9
-        traffic, traffic_src = profiled_traffic(n, S, world)
+        traffic, traffic_src, traffic_rd, traffic_wr = profiled_traffic(n, S, world)
         out = {
             "metric": "Mnodes/s per sweep-iteration (512^3 fp32 grid, first-order FSM)",
             "value": round(value, 1),
@@ -330,17 +344,20 @@ def main():
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, all_gather of receiver traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_reads": traffic_rd, "traffic_writes": traffic_wr,
+                         "frac_real_traffic": (round(traffic * launches / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                         "frac_contract_all_updates": round(nominal / HBM_PEAK_GBS, 4),
                          "kernel": KERNELS.get(os.environ.get("TTCR_FSM_MODE", "2"), "?"),
                          "algorithmic_bytes_per_node_per_sweep_iteration": BYTES_PER_NODE_ITER,
                          "evaluated_fraction": round(evaluated / max(node_iters * 8, 1), 4),
                          "nominal_GBs_all_updates": round(nominal, 1),
                          "launches": int(launches), "avg_launch_us_hip_events": round(sweep_ms * 1e3 / max(launches, 1), 3),
                          "algorithmic_bytes_per_launch": round(bytes_total / max(launches, 1), 1),
-                         "pricing_note": "contract figure: every evaluated node update at 104/8 B (T read, s read, T write + the "
-                                         "snapshot share), whether or not it changed the node -- the last sweep-iteration of a "
-                                         "converged solve evaluates everything and writes nothing (unchanged chunks skip their "
-                                         "write-back), and this design keeps no snapshot array"},
+                         "pricing_note": "achieved / frac price only the node updates the kernel EVALUATED, at the contract's 104/8 B "
+                                         "each (T read, s read, T write + the snapshot share), whether or not they changed the node; "
+                                         "chunks, units and sweeps that provably cannot change a node are stepped over (exact) and "
+                                         "priced at nothing -- frac_contract_all_updates is SURVEY 8(d)'s 104 B x N x iterations / time, "
+                                         "which counts them; frac_real_traffic is the PMC traffic of profiles/ over the same time"},
         }
         if world == 1:
             try:

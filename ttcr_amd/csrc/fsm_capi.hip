@@ -647,10 +647,14 @@ class GridT : public GridBase {
         // sheared copies (fsm_kernels.h: fsm_shear_slowness): family = F/J flips with K (3-D) or
         // J (2-D) not flipped; a direction and its opposite share one copy
         {
-            const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
             const int nfam = dim == 3 ? 4 : 2;
-            for (int f = 0; f < nfam; ++f)
-                fsm_shear_slowness<T><<<blocks, 256, 0, stream>>>(d_s.p, d_ssh.p + (size_t)f * ssh_stride, geom, f & 1, (f >> 1) & 1);
+            const dim3 grid((geom.M + 15) / 16, (geom.NJ + 15) / 16, geom.NK);
+            const bool lines = grid.y <= 65535 && grid.z <= 65535 && !std::getenv("TTCR_FSM_SHEAR_SCATTER");
+            const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
+            for (int f = 0; f < nfam; ++f) {
+                if (lines) fsm_shear_slowness_lines<T><<<grid, 256, 0, stream>>>(d_s.p, d_ssh.p + (size_t)f * ssh_stride, geom, f & 1, (f >> 1) & 1);
+                else fsm_shear_slowness<T><<<blocks, 256, 0, stream>>>(d_s.p, d_ssh.p + (size_t)f * ssh_stride, geom, f & 1, (f >> 1) & 1);
+            }
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipStreamSynchronize(stream));

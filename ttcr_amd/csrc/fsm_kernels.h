@@ -257,6 +257,23 @@ __global__ void fsm_shear_slowness(const T* __restrict__ s, T* __restrict__ out,
     }
 }
 
+// The same copy written a line at a time: a workgroup produces 16 consecutive x of one 16-column block of one k' plane,
+// lanes ordered (x, j') like the copy itself, so that a wavefront stores whole 128-byte lines (fsm_shear_slowness above walks
+// the natural array and scatters 4-byte stores over as many lines: the fabric counted 8x the payload in write requests,
+// profiles/r02/traffic.json).  The loads walk 16 rows of the natural array along an anti-diagonal band -- a compact region
+// that stays in the caches across the workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void fsm_shear_slowness_lines(const T* __restrict__ s, T* __restrict__ out, SweepGeom g, int rf, int rj) {
+    const int jj = threadIdx.x & 15, xx = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + xx, jp = blockIdx.y * 16 + jj, k = blockIdx.z;
+    if (x >= g.M || jp >= g.NJ) return;
+    int ip = x - jp;
+    ip = ip < 0 ? ip + g.M : ip;
+    if (ip >= g.NF) return;   // (no node with this i' + j': the entry is never read)
+    const int i = rf ? g.NF - 1 - ip : ip, j = rj ? g.NJ - 1 - jp : jp;
+    out[shear_index(g, k, x, jp)] = s[((size_t)k * g.NJ + j) * g.NF + i];
+}
+
 template <typename T>
 struct SweepArgs {
     T* tt;                    // [n_slots][n_nodes] traveltime fields
@@ -673,6 +690,9 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 // SKIP kernels publish progress as (levels << 8) | change flags of the last four chunks (two bits each: J-edge, K-edge columns);
 // a finished unit publishes FSM_FIN | (ever changed its J edge) | (ever changed its K edge) << 1
 #define FSM_FIN 0x7ffffff0
+#ifndef FSM_SKIP_ABL
+#define FSM_SKIP_ABL 0   // tuning builds: leave parts of the skip bookkeeping out (wrong results unless every brick is dirty)
+#endif
 #ifndef FSM_EARLY_PUB
 #define FSM_EARLY_PUB 0   // first chunks of a unit whose progress is published right after their write-back
 #endif
@@ -764,7 +784,6 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
     __shared__ P Tt[NROWS * RS];
     __shared__ int s_ticket;
     __shared__ int s_anychg;
-    __shared__ int s_chg[64];  // bricks of the read set changed by this chunk
     // scheduler state of the SKIP kernels (thread 0 only, apart from s_slab's set-up and s_next / s_act)
     constexpr int SLABW = SKIP ? FSM_SLAB_WORDS : 1;
     __shared__ unsigned s_stamped[SKIP ? 9 : 1][SLABW];   // bricks of the read set (J/K position, F index) this unit has already stamped
@@ -1179,7 +1198,6 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
         const int nsw = (pa.nbf + 31) >> 5;
         for (int w = tid; w < nsw; w += NT) s_slab[w] = 0u;
         for (int w = tid; w < 9 * SLABW; w += NT) s_stamped[w / SLABW][w % SLABW] = 0u;
-        if (tid < 64) s_chg[tid] = 0;
         if (tid == 0) {
             s_cwi[0] = -1; s_cwi[1] = -1; s_mywi = -1;
             // natural J / K extent of the read set (own + halo columns) in bricks, fixed for the whole unit
@@ -1326,7 +1344,11 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
                     if (pending) { act = 2; break; }   // the stores of the chunk before have to drain before progress moves on
                     L += C;
                     h = (h << 2) & 0xff;
-                    __hip_atomic_store(my_prog, L > Le ? (FSM_FIN | s_u[U_EVER]) : ((L << 8) | h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (L > Le && s_u[U_UCHG]) {
+                        s_u[U_PENDV] = FSM_FIN | s_u[U_EVER];   // (goes out after the unit's stamps, below the loop)
+                    } else {
+                        __hip_atomic_store(my_prog, L > Le ? (FSM_FIN | s_u[U_EVER]) : ((L << 8) | h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 s_u[U_HIST] = h;
                 s_next = L;
@@ -1548,20 +1570,17 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
             const bool ej = changed && jp + H > jmaxp, ek = IS3D && changed && kp + H > kmaxp;
             const int f = (wave_any(changed) ? 1 : 0) | (wave_any(ej) ? 2 : 0) | (wave_any(ek) ? 4 : 0);
             if (f && (tid & 63) == 0) atomicOr(&s_anychg, f);
-            if (changed) {
-                // flag the bricks this thread changed (its nodes of the chunk lie in at most two bricks along F); the
-                // flags are turned into stamps, and cleared, after the barrier
-                int flo, fhi;
-                chunk_frange(L0, H, flo, fhi);
-                const int rs_flo = flo / FSM_BRICK, rs_nf = fhi / FSM_BRICK - rs_flo + 1;
+            if (!(FSM_SKIP_ABL & 2) && changed) {
+                // note the bricks this thread changed (its nodes of the chunk lie in at most two bricks along F): one bit per
+                // brick of the unit's read set; they become stamps when the unit is over (the units that read them -- the
+                // next sweep's -- wait for that; this sweep's units get the news with the progress values)
                 const int ip0 = L0 - jp - kp;                                  // i' of this thread's node at e = 0
                 const int ia = ip0 + ea, ib = ip0 + eb;                        // its nodes in the chunk (ea <= eb: it changed one)
-                const int na = rf ? NF - 1 - ib : ia, nb2 = rf ? NF - 1 - ia : ib;
+                const int ba = (rf ? NF - 1 - ib : ia) / FSM_BRICK, bb2 = (rf ? NF - 1 - ia : ib) / FSM_BRICK;
                 const int my_bj = (rj ? NJ - 1 - jp : jp) / FSM_BRICK - s_u[U_RSJLO], my_bk = (rk ? NK - 1 - kp : kp) / FSM_BRICK - s_u[U_RSKLO];
-                const int base = (my_bk * s_u[U_RSNJ] + my_bj) * rs_nf;
-                const int ba = na / FSM_BRICK - rs_flo, bb2 = nb2 / FSM_BRICK - rs_flo;
-                if (ba >= 0 && ba < rs_nf) s_chg[base + ba] = 1;
-                if (bb2 != ba && bb2 >= 0 && bb2 < rs_nf) s_chg[base + bb2] = 1;
+                const int jk = my_bk * s_u[U_RSNJ] + my_bj;
+                atomicOr(&s_stamped[jk][ba >> 5], 1u << (ba & 31));
+                if (bb2 != ba) atomicOr(&s_stamped[jk][bb2 >> 5], 1u << (bb2 & 31));
             }
         } else {
             if (wave_any(changed) && (tid & 63) == 0) s_anychg = 1;
@@ -1583,30 +1602,9 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
                 }
             }
         }
-        // (5b) stamp the changed bricks with this sweep's number; ordered before the progress value by the drain below
+        // (5b) the unit's own changes: slab mask, change map, flags of the progress word
         if constexpr (SKIP) {
-            if (any_changed && tid < 64) {
-                int flo, fhi;
-                chunk_frange(L0, H, flo, fhi);
-                const int rs_flo = flo / FSM_BRICK, rs_nf = fhi / FSM_BRICK - rs_flo + 1;   // read set of the chunk along F, in bricks
-                const int rs_jlo = s_u[U_RSJLO], rs_nj = s_u[U_RSNJ], rs_klo = s_u[U_RSKLO], rs_nk = s_u[U_RSNK];
-                int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;
-                const int sigma = pa.ndir * pa.iter_ptr[0] + dir + 1;
-                const int nb = rs_nf * rs_nj * rs_nk;
-                for (int b = tid; b < nb; b += 64) {
-                    if (s_chg[b]) {
-                        s_chg[b] = 0;
-                        const int jk = b / rs_nf, bf = rs_flo + b % rs_nf;
-                        // one atomic per brick and unit: a brick is in the read set of several consecutive chunks
-                        if (!((s_stamped[jk][bf >> 5] >> (bf & 31)) & 1u)) {
-                            atomicOr(&s_stamped[jk][bf >> 5], 1u << (bf & 31));
-                            const int bj = rs_jlo + jk % rs_nj, bk = rs_klo + jk / rs_nj;
-                            atomicMax(stamp + ((size_t)bk * pa.nbj + bj) * pa.nbf + bf, sigma);
-                        }
-                    }
-                }
-            }
-            if (tid == 0) {
+            if (!(FSM_SKIP_ABL & 4) && tid == 0) {
                 if (any_changed) {
                     // own changes into the slab mask (the next chunks read these bricks) and into the unit's change map
                     int flo, fhi;
@@ -1643,6 +1641,23 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
         }
         ++n_done;
         FSM_PMARK(4)
+    }
+    if constexpr (SKIP) {
+        // stamp the bricks the unit changed with this sweep's number -- before the final progress value goes out: the units
+        // of the next sweep wait for that value and then read the stamps
+        __syncthreads();
+        if (s_u[U_UCHG]) {
+            const int nsw = (pa.nbf + 31) >> 5;
+            const int rs_jlo = s_u[U_RSJLO], rs_nj = s_u[U_RSNJ], rs_klo = s_u[U_RSKLO], njk = rs_nj * s_u[U_RSNK];
+            int* __restrict__ stamp = pa.stamp + (size_t)grp * pa.nbf * pa.nbj * pa.nbk;
+            const int sigma = pa.ndir * pa.iter_ptr[0] + dir + 1;
+            for (int q = tid; q < njk * nsw * 32; q += NT) {
+                const int jk = q / (nsw * 32), bf = q % (nsw * 32);
+                if (bf < pa.nbf && ((s_stamped[jk][bf >> 5] >> (bf & 31)) & 1u))
+                    atomicMax(stamp + ((size_t)(rs_klo + jk / rs_nj) * pa.nbj + rs_jlo + jk % rs_nj) * pa.nbf + bf, sigma);
+            }
+            pending = 1;   // (the drain below covers the atomics; the value to publish is already in s_u[U_PENDV])
+        }
     }
     if (pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

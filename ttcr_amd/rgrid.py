@@ -238,79 +238,63 @@ class _GridBase:
             _io.write_vtr(filename + '.vtr', xyz[0], xyz[1], xyz[2], point_data=pd, cell_data=cd)
 
     def _split_sources(self, source, rcv, aggregate_src):
+        """The data rows of a raytrace call as a list of events -> (points, origin times, receivers, receiver rows), one
+        entry per event.  What ttcrpy's raytrace does before it reaches C++ (rgrid.pyx:917-1030): an event is a distinct
+        source row (3 / 4 columns: x y z / t0 x y z; 2-D one column less), taken in order of first appearance, or an
+        event number (5 columns: evID t0 x y z, 3-D only), taken in ascending order; its receivers are the rows that carry
+        it.  One event in all: every row is a receiver of it.  aggregate_src: the distinct rows are the points of ONE
+        source.  Same checks, same messages."""
         nd = self._ndim
         if source.ndim != 2 or rcv.ndim != 2:
             raise ValueError('source and rcv should be 2D arrays')
-        evID = None
-        if nd == 3 and source.shape[1] == 5:
-            src = source[:, 2:5]
-            t0 = source[:, 1]
-            evID = source[:, 0]
-            eid = np.sort(np.unique(evID))
-            nTx = len(eid)
-            Tx = None
-        elif source.shape[1] == nd:
-            src = source
-            Tx = source[_first_rows(source), :]  # unique rows, original order kept
-            t0 = np.zeros((Tx.shape[0],))
-            nTx = Tx.shape[0]
-        elif source.shape[1] == nd + 1:
-            src = source[:, 1:nd + 1]
-            tmp = source[_first_rows(source), :]
-            nTx = tmp.shape[0]
-            Tx = tmp[:, 1:nd + 1]
-            t0 = tmp[:, 0]
-        else:
-            if nd == 3:
-                raise ValueError('source should be either nsrc x 3, 4 or 5')
-            raise ValueError('source should be either nsrc x 2 or 3')
-        if src.shape[1] != nd or rcv.shape[1] != nd:
+        width = source.shape[1]
+        by_number = nd == 3 and width == 5
+        if not by_number and width not in (nd, nd + 1):
+            raise ValueError('source should be either nsrc x 3, 4 or 5' if nd == 3 else 'source should be either nsrc x 2 or 3')
+        xyz = source[:, width - nd:]                       # coordinates are always the last nd columns
+        if xyz.shape[1] != nd or rcv.shape[1] != nd:
             raise ValueError('src and rcv should be ndata x %d' % nd)
-        if self.is_outside(src):
+        if self.is_outside(xyz):
             raise ValueError('Source point outside grid')
         if self.is_outside(rcv):
             raise ValueError('Receiver outside grid')
+        times = source[:, width - nd - 1] if width > nd else None   # the column in front of the coordinates, when there is one
+        everything = np.arange(rcv.shape[0])
 
-        vTx, vt0, vRx, iRx = [], [], [], []
-        if evID is None:
-            if nTx == 1:
-                vTx.append(src[0:1, :])
-                vt0.append(np.array([t0[0]]))
-                vRx.append(rcv)
-                iRx.append(np.arange(rcv.shape[0]))
-            elif aggregate_src:
-                vTx.append(Tx)
-                vt0.append(np.asarray(t0))
-                vRx.append(rcv)
-                iRx.append(np.arange(rcv.shape[0]))
-                nTx = 1
-            else:
-                if src.shape != rcv.shape:
-                    raise ValueError('src and rcv should be of equal size')
-                # rows of every unique source, i.e. np.nonzero(np.sum(Tx[n] == src, axis=1) == nd) of the
-                # reference (rgrid.pyx:1000-1007), found with one grouping pass instead of nTx passes over the rows
-                order, bounds, gkeys = _row_groups(src)
-                tkey = np.ascontiguousarray(Tx, dtype=np.float64) + 0.0
-                first = {gkeys[gid].tobytes(): gid for gid in range(gkeys.shape[0])}
-                for n in range(nTx):
-                    gid = first[tkey[n].tobytes()]
-                    rows = order[bounds[gid]:bounds[gid + 1]]   # ascending: the sort is stable
-                    iRx.append(rows)
-                    vTx.append(Tx[n:n + 1, :])
-                    vt0.append(np.array([t0[n]]))
-                    vRx.append(rcv[rows, :])
-        else:
-            if src.shape != rcv.shape:
+        if by_number:
+            if xyz.shape != rcv.shape:
                 raise ValueError('src and rcv should be of equal size')
-            for n in range(nTx):
-                i0 = int(np.nonzero(evID == eid[n])[0][0])
-                vTx.append(src[i0:i0 + 1, :])
-                vt0.append(np.array([t0[i0]]))
-            for i in eid:
-                iRx.append(np.nonzero(evID == i)[0])
-            for n in range(nTx):
-                vRx.append(rcv[iRx[n], :])
-        return vTx, vt0, vRx, iRx
+            numbers = source[:, 0]
+            events = []
+            for ev in np.unique(numbers):                  # ascending
+                rows = np.nonzero(numbers == ev)[0]
+                events.append((xyz[rows[:1]], times[rows[:1]].copy(), rows))
+        else:
+            # distinct rows of the whole source array (t0 included), first occurrences in row order
+            order, bounds, _ = _row_groups(source)
+            heads = order[bounds[:-1]]                     # first row of every group (the grouping sort is stable)
+            rank = np.argsort(heads, kind='stable')        # groups in order of first appearance
+            heads = heads[rank]
+            t_of = (lambda r: times[r].copy()) if times is not None else (lambda r: np.zeros(len(r)))
+            if len(heads) == 1:
+                events = [(xyz[:1], t_of(heads), everything)]
+            elif aggregate_src:
+                events = [(xyz[heads], t_of(heads), everything)]
+            else:
+                if xyz.shape != rcv.shape:
+                    raise ValueError('src and rcv should be of equal size')
+                events = []
+                for h, gidx in zip(heads, rank):
+                    if times is None:
+                        rows = order[bounds[gidx]:bounds[gidx + 1]]
+                    else:
+                        # the reference matches receivers on the coordinates alone (rgrid.pyx:1000-1007): rows with the
+                        # same point and another origin time belong to every event at that point
+                        rows = np.nonzero(np.all(xyz == xyz[h], axis=1))[0]
+                    events.append((xyz[h:h + 1], t_of(np.array([h])), rows))
+        pts = [e[0] for e in events]
+        tms = [np.asarray(e[1], dtype=np.float64) for e in events]
+        return pts, tms, [rcv[e[2], :] for e in events], [e[2] for e in events]
 
     def _run(self, vTx, vt0, vRx, iRx, n_rcv, thread_no, return_rays=False):
         dt = self._dtype
