@@ -20,7 +20,7 @@ for r in range(reps):
     g.raytrace(src, rcv)
     tm = g.timing()
     best = min(best, tm['sweep_ms'])
-    print(f"rep {r}: sweep_ms {tm['sweep_ms']:.3f} total_ms {tm['total_ms']:.3f}", flush=True)
+    print(f"rep {r}: sweep_ms {tm['sweep_ms']:.3f} total_ms {tm['total_ms']:.3f} evaluated {tm['evaluated_updates'] / max(tm['node_updates'], 1):.3f}", flush=True)
 per_it = best / iters
 print(f"n={n} S={S} iters={iters}: best {best:.3f} ms = {per_it:.3f} ms/sweep-iteration = {n**3*S/per_it/1e3:.0f} Mnodes/s/iter, "
       f"roofline frac {104.0*n**3*S/(per_it*1e-3)/8e12:.4f}", flush=True)

@@ -898,8 +898,11 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
             }
         }
     }
-    const int* up_j = TJ > 0 ? prog + (TK * npj + TJ - 1) : nullptr;
-    const int* up_k = (IS3D && TK > 0) ? prog + ((TK - 1) * npj + TJ) : nullptr;
+#ifndef FSM_EXP_NOWAIT
+#define FSM_EXP_NOWAIT 0   // TIMING experiment (wrong results): no unit ever waits for another one
+#endif
+    const int* up_j = (!FSM_EXP_NOWAIT && TJ > 0) ? prog + (TK * npj + TJ - 1) : nullptr;
+    const int* up_k = (!FSM_EXP_NOWAIT && IS3D && TK > 0) ? prog + ((TK - 1) * npj + TJ) : nullptr;
 
     const int j0 = TJ * PJ, k0 = TK * PK;
     const int jmaxp = (j0 + PJ < NJ ? j0 + PJ : NJ) - 1;
@@ -1164,7 +1167,7 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
             near_hi[l] = jk ? b1 + jmaxp + kmaxp : 0;
         }
     }
-    if (XS && dir > 0 && !chase) {
+    if (!FSM_EXP_NOWAIT && XS && dir > 0 && !chase) {
         // previous sweep of this iteration: wait for the patches (of ITS oriented partition) that own
         // a column within 2H of ours -- at most 3 x 3 of them, one lane each
         if (tid < 16) {
