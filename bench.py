@@ -368,6 +368,25 @@ def main():
                 out["roofline"]["measured_copy_GBs"] = None
                 sys.stderr.write("copy bandwidth not measured: %s\n" % e)
         if world == 1 and not args.no_single_source:
+            # the kernel with every node update evaluated (exact skipping switched off), same grid, same sources, same
+            # process: the roofline of the sweep kernel itself, where algorithmic bytes and evaluated work coincide
+            try:
+                if os.environ.get("TTCR_FSM_SKIP") is None:
+                    grid.set_option("skip", 0)
+                    grid.raytrace(src_rows, rcv_rows)
+                    ms0, l0, ev0 = 0.0, 0, 0
+                    for _ in range(2):
+                        grid.raytrace(src_rows, rcv_rows)
+                        tm0 = grid.timing()
+                        ms0 += tm0["sweep_ms"]; l0 += tm0["kernel_launches"]; ev0 += tm0["evaluated_updates"]
+                    grid.set_option("skip", -1)
+                    a0 = BYTES_PER_NODE_ITER / 8.0 * ev0 / (ms0 * 1e-3) / 1e9
+                    out["roofline"]["evaluate_all_kernel"] = {
+                        "kernel": "fsm_sweep_persistent<float,16,16,8,true,false,1,2,true,true>", "frac": round(a0 / HBM_PEAK_GBS, 4),
+                        "achieved": round(a0, 1), "avg_launch_us_hip_events": round(ms0 * 1e3 / max(l0, 1), 3), "launches": int(l0),
+                        "note": "option skip = 0: every node update of every sweep evaluated (what round 2 reported as roofline); 2 steps after the timed region"}
+            except Exception as e:
+                sys.stderr.write("evaluate-all leg failed: %s\n" % e)
             out["single_source"] = single_source_leg(n, dx, x, s_dev, local_rank)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline()

@@ -194,7 +194,8 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                     change flags its upwind patches publish with their progress) holds no change since its nodes
  *                     were last visited is a no-op, and so is every sweep that follows a sweep without a change --
  *                     exact, fields and iteration counts are unchanged; 0: evaluate every chunk; -1 (default): on
- *                     where it was measured to pay (3-D grids; off for a lone first-order source), see DESIGN.md 4a */
+ *                     where it was measured to pay (2-D grids, the WENO stage, first-order 3-D batches with at least 2048 work
+ *                     units per sweep -- not a lone first-order 3-D source), see DESIGN.md 4a */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 /* Replaces: the r_data output of the raytrace overloads above (std::vector<std::vector<sxyz<T1>>>&,

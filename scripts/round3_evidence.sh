@@ -8,9 +8,9 @@ python bench.py --steps 5 --warmup 1 > $O/bench_512x64.json 2> $O/bench.err; tai
 # the evaluate-all kernel on the same workload (exact skipping off): what the roofline of the kernel itself is
 TTCR_FSM_SKIP=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single-source > $O/bench_512x64_skip0.json 2>> $O/bench.err
 # kernel stats + PMC traffic: default run, skip off, one source
-bash scripts/prof_cmd.sh r03_512x64 $O python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-source
-TTCR_FSM_SKIP=0 bash scripts/prof_cmd.sh r03_512x64_skip0 $O python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-source
-bash scripts/prof_cmd.sh r03_512x1 $O python bench.py --steps 3 --warmup 1 --sources 1 --no-cpu-baseline --no-single-source
+bash scripts/prof_cmd.sh r03_512x64 $O python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-source
+TTCR_FSM_SKIP=0 bash scripts/prof_cmd.sh r03_512x64_skip0 $O python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-source
+bash scripts/prof_cmd.sh r03_512x1 $O python $ROOT/bench.py --steps 3 --warmup 1 --sources 1 --no-cpu-baseline --no-single-source
 python - <<PY
 import csv, json, os, sys
 sys.path.insert(0, "$ROOT")
@@ -34,7 +34,7 @@ for tag, name in (("r03_512x64", "traffic.json"), ("r03_512x64_skip0", "traffic_
 PY
 # the other configurations: one line each, then kernel stats + traffic per configuration
 python scripts/configs_run.py > $O/configs.txt 2>&1
-for C in C2 C4 C5 W1 W8; do bash scripts/prof_cmd.sh r03_$C $O python scripts/config_one.py $C 2; done
+for C in C2 C4 C5 W1 W8; do bash scripts/prof_cmd.sh r03_$C $O python $ROOT/scripts/config_one.py $C 2; done
 # WENO stage: SQ counters of the lone 256^3 source
 cd /tmp && export TMPDIR=/tmp
 for G in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"; do

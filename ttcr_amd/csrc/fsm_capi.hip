@@ -855,13 +855,14 @@ class GridT : public GridBase {
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
     // Exact skipping of chunks / units / sweeps that cannot change a node: on wherever it was measured to pay
     // (profiles/r03/skip_sweep.txt).  What it saves is work, what it costs is a little of every chunk's time: a win once
-    // the chip is busy (512^3: from two slot groups on, 1.13x ... 1.6x at 32 groups), a loss of 5-15 % where a solve is
+    // the chip is busy (512^3: from two slot groups on, 1.13x ... 1.7x at 32 groups), a loss of 1-15 % where a 3-D solve is
     // bound by the dependent chain of its units anyway (a lone source or pair; 256^3 and smaller up to 8 sources).  The
-    // WENO stage gains at every batch size (its chunks are expensive).  TTCR_FSM_SKIP_UNITS: work units per sweep from
-    // which the first-order 3-D sweeps skip.
+    // WENO stage gains at every batch size (its chunks are expensive), and so do the one-wave patches of the 2-D solver
+    // (1.03x ... 1.19x from 1 to 64 sources on 1024^2 ... 8192^2 nodes, although the SKIP kernels do not follow the
+    // previous sweep up the columns).  TTCR_FSM_SKIP_UNITS: work units per sweep from which the first-order 3-D sweeps skip.
     int skip_units_min = 2048;
     int skip_default(int entries) const {
-        if (dim != 3) return 0;
+        if (dim != 3) return 1;
         if (stage == 1) return 1;
         return (long long)n_patches * entries >= skip_units_min ? 1 : 0;
     }
