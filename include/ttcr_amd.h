@@ -217,15 +217,27 @@ int ttcr_fsm_raytrace_rays(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx,
 int ttcr_fsm_slot_rays_size(const ttcr_fsm_grid* g, int slot, size_t* n_rays, size_t* n_points);
 int ttcr_fsm_get_slot_rays(const ttcr_fsm_grid* g, int slot, long long* offsets, void* pts);
 
-/* NOT provided (reference overloads without an entry point here):
- *   - raytrace with l_data (ray projection matrix L): ttcrpy itself raises "compute_L not implemented for FSM"
- *     (src/ttcrpy/rgrid.pyx:916-917);
- *   - raytrace with m_data (velocity-derivative matrix M, `compute_M`): Grid3Drn::getRaypath(..., m_data, ...)
- *     (ttcr/Grid3Drn.h:1503-1800) overwrites prev_pt with curr_pt BEFORE it forms the segment mid-point and length
- *     (:1589-1597), so every interior segment contributes -s^2 * 0 * w and only the last hop carries weight, and its
- *     weights index one node past the grid on the max faces: reproducing that bit for bit would pin a defect.
- *   A binding must refuse both (the adapters in integration/ throw, ttcr_amd/rgrid.py raises NotImplementedError);
- *   TTCR_ERR_UNSUPPORTED is reserved for an entry point that would take such a request. */
+/* Replaces: Grid3D::raytrace(Tx, t0, Rx, traveltimes, m_data, threadNo) (ttcr/Grid3D.h:743-772) -> Grid3Drn::getRaypath(Tx,
+ * t0, Rx, m_data, RxNo, tt, threadNo) (ttcr/Grid3Drn.h:1503-1800): what `compute_M=True` of the Python layer reaches
+ * (src/ttcrpy/rgrid.pyx:1040-1060, :1171-1191).  One call solves the source in `slot`, walks every receiver's ray on the
+ * device and assembles, per receiver, the (node index, value) entries of the matrix of traveltime derivatives in the order
+ * the reference pushes them; traveltimes are those of that overload (integrated along the ray; 0 for a receiver on the
+ * source).  The reference's formula is restated AS IT STANDS: it overwrites prev_pt with curr_pt before it forms a
+ * segment's mid-point and length (:1590-1597), so every step of the walk contributes signed zeros at the eight nodes around
+ * the step's end point and only the last hop (or two) to the source carries weight; its weights drop xmin and its node
+ * indices may lie one node past the grid (the Python layer drops those).  Bit-identical to the compiled reference
+ * (tests/golden, tests/test_parity_gpu.py).  3-D node grids, sources of ONE point (TTCR_ERR_UNSUPPORTED otherwise).
+ * ttcr_fsm_slot_m_size: rows (= receivers) and entries of the last call on `slot`; ttcr_fsm_get_slot_m: row_off[n_rows+1],
+ * j[nnz] node indices, v[nnz] values of the grid dtype.  The rays of the same call are available through
+ * ttcr_fsm_slot_rays_size / ttcr_fsm_get_slot_rays (the overload with r_data AND m_data, ttcr/Grid3D.h:646-680). */
+int ttcr_fsm_raytrace_m(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx,
+                        const void* rx, void* tt_out);
+int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz);
+int ttcr_fsm_get_slot_m(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* j, void* v);
+
+/* NOT provided (reference overload without an entry point here): raytrace with l_data (ray projection matrix L) -- ttcrpy
+ * itself raises "compute_L not implemented for FSM" (src/ttcrpy/rgrid.pyx:916-917).  A binding must refuse it (the adapters in
+ * integration/ throw, ttcr_amd/rgrid.py raises NotImplementedError). */
 
 typedef struct {
     double sweep_ms;        /* HIP-event time of all sweep launches of the last raytrace call   */

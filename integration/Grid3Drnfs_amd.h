@@ -137,13 +137,7 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
         chk(ttcr_fsm_set_option(h, "tt_from_rp", this->tt_from_rp ? 1.0 : 0.0));
         chk(ttcr_fsm_raytrace_rays(h, (int)threadNo, (int)Tx.size(), Tx.data(), t0.data(), (int)Rx.size(), Rx.data(), traveltimes.data()));
         last_slot.store((int)threadNo);
-        size_t nr = 0, np = 0;
-        chk(ttcr_fsm_slot_rays_size(h, (int)threadNo, &nr, &np));
-        std::vector<long long> off(nr + 1);
-        std::vector<sxyz<T1>> pts(np ? np : 1);
-        chk(ttcr_fsm_get_slot_rays(h, (int)threadNo, off.data(), pts.data()));
-        r_data.resize(nr);
-        for (size_t n = 0; n < nr; ++n) r_data[n].assign(pts.begin() + off[n], pts.begin() + off[n + 1]);
+        fetch_slot_rays(r_data, threadNo);
     }
     void raytrace(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<std::vector<sxyz<T1>>>& Rx,
                   std::vector<std::vector<T1>*>& traveltimes, std::vector<std::vector<std::vector<sxyz<T1>>>*>& r_data,
@@ -160,16 +154,22 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
             k += Rx[n].size();
         }
     }
-    // L: "compute_L not implemented for FSM" in ttcrpy itself (rgrid.pyx:916-917); M: see DESIGN.md (the reference's
-    // rectilinear M overload is degenerate, ttcr/Grid3Drn.h:1589-1592): both are refused, never silently wrong
+    // L: "compute_L not implemented for FSM" in ttcrpy itself (rgrid.pyx:916-917): refused, never silently wrong
     void raytrace(const std::vector<sxyz<T1>>&, const std::vector<T1>&, const std::vector<sxyz<T1>>&, std::vector<T1>&,
                   std::vector<std::vector<siv<T1>>>&, const size_t = 0) const override { no_LM("l_data"); }
     void raytrace(const std::vector<sxyz<T1>>&, const std::vector<T1>&, const std::vector<sxyz<T1>>&, std::vector<T1>&,
                   std::vector<std::vector<sxyz<T1>>>&, std::vector<std::vector<siv<T1>>>&, const size_t = 0) const override { no_LM("l_data"); }
-    void raytrace(const std::vector<sxyz<T1>>&, const std::vector<T1>&, const std::vector<sxyz<T1>>&, std::vector<T1>&,
-                  std::vector<std::vector<sijv<T1>>>&, const size_t = 0) const override { no_LM("m_data"); }
-    void raytrace(const std::vector<sxyz<T1>>&, const std::vector<T1>&, const std::vector<sxyz<T1>>&, std::vector<T1>&,
-                  std::vector<std::vector<sxyz<T1>>>&, std::vector<std::vector<sijv<T1>>>&, const size_t = 0) const override { no_LM("m_data"); }
+    // M (ttcr/Grid3D.h:743-772 and, with the rays, :646-680): one call behind the ABI, entries per receiver in the
+    // reference's push order (its degenerate interior segments included -- include/ttcr_amd.h, ttcr_fsm_raytrace_m)
+    void raytrace(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<sxyz<T1>>& Rx, std::vector<T1>& traveltimes,
+                  std::vector<std::vector<sijv<T1>>>& m_data, const size_t threadNo = 0) const override {
+        solve_m(Tx, t0, Rx, traveltimes, m_data, threadNo);
+    }
+    void raytrace(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<sxyz<T1>>& Rx, std::vector<T1>& traveltimes,
+                  std::vector<std::vector<sxyz<T1>>>& r_data, std::vector<std::vector<sijv<T1>>>& m_data, const size_t threadNo = 0) const override {
+        solve_m(Tx, t0, Rx, traveltimes, m_data, threadNo);
+        fetch_slot_rays(r_data, threadNo);
+    }
 
     // ---- all sources in one device call: what Grid3D's multi-source overload (ttcr/Grid3D.h:810-853) does with host
     // threads.  Same arguments, same results; r_data (optional) as in the overload of :855-905.
@@ -222,6 +222,30 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
     }
     [[noreturn]] static void no_LM(const char* what) {
         throw std::runtime_error(std::string("Error: raytrace overload with ") + what + " is not available for the FSM backend on MI355X");
+    }
+    void fetch_slot_rays(std::vector<std::vector<sxyz<T1>>>& r_data, const size_t threadNo) const {
+        size_t nr = 0, np = 0;
+        chk(ttcr_fsm_slot_rays_size(h, (int)threadNo, &nr, &np));
+        std::vector<long long> off(nr + 1);
+        std::vector<sxyz<T1>> pts(np ? np : 1);
+        chk(ttcr_fsm_get_slot_rays(h, (int)threadNo, off.data(), pts.data()));
+        r_data.resize(nr);
+        for (size_t n = 0; n < nr; ++n) r_data[n].assign(pts.begin() + off[n], pts.begin() + off[n + 1]);
+    }
+    void solve_m(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<sxyz<T1>>& Rx, std::vector<T1>& traveltimes,
+                 std::vector<std::vector<sijv<T1>>>& m_data, const size_t threadNo) const {
+        if (t0.size() != Tx.size()) throw std::runtime_error("Error: Tx and t0 of different sizes.");
+        traveltimes.resize(Rx.size());
+        chk(ttcr_fsm_raytrace_m(h, (int)threadNo, (int)Tx.size(), Tx.data(), t0.data(), (int)Rx.size(), Rx.data(), traveltimes.data()));
+        last_slot.store((int)threadNo);
+        size_t nrow = 0, nnz = 0;
+        chk(ttcr_fsm_slot_m_size(h, (int)threadNo, &nrow, &nnz));
+        std::vector<long long> off(nrow + 1), j(nnz ? nnz : 1);
+        std::vector<T1> v(nnz ? nnz : 1);
+        chk(ttcr_fsm_get_slot_m(h, (int)threadNo, off.data(), j.data(), v.data()));
+        m_data.assign(Rx.size(), std::vector<sijv<T1>>());
+        for (size_t n = 0; n < nrow && n < Rx.size(); ++n)
+            for (long long e = off[n]; e < off[n + 1]; ++e) m_data[n].push_back(sijv<T1>(n, (size_t)j[e], v[e]));
     }
     struct RaysOn {   // option "return_rays" for the duration of one call
         ttcr_fsm_grid* g;

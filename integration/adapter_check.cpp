@@ -190,8 +190,18 @@ int main() {
         CHECK(what_of([&] { g->checkPts(out); }) == "Error: Point (1 -2 5.6) outside grid.", "checkPts");
         std::vector<std::vector<siv<float>>> l_data;
         CHECK(!what_of([&] { g->raytrace(Tx, t0, Rx, tt, l_data, 0); }).empty(), "l_data overload refuses");
-        std::vector<std::vector<sijv<float>>> m_data;
-        CHECK(!what_of([&] { g->raytrace(Tx, t0, Rx, tt, m_data, 0); }).empty(), "m_data overload refuses");
+        // M through the base class: one entry list per receiver; every value is finite, only the last hops carry weight
+        {
+            const std::vector<sxyz<float>> Rm = {{2.0f, 2.0f, 2.0f}, {9.0f, 4.0f, 4.5f}, {3.3f, 1.1f, 2.7f}};
+            std::vector<std::vector<sijv<float>>> m_data;
+            std::vector<float> ttm;
+            g->raytrace(Tx, t0, Rm, ttm, m_data, 0);
+            bool okm = m_data.size() == 3 && m_data[2].empty() && ttm[2] == 0.0f && !m_data[0].empty() && !m_data[1].empty();
+            size_t nz = 0;
+            for (const auto& row : m_data) for (const auto& e : row) { okm = okm && e.v == e.v; nz += e.v != 0.0f; }
+            CHECK(okm && nz >= 8 && nz <= 48, "m_data overload: entries per receiver, none for a receiver on the source");
+            std::printf("m3_entries %zu %zu nonzero %zu\n", m_data[0].size(), m_data[1].size(), nz);
+        }
     }
     {   // ------------------------------------------------ 3-D cell grid, fp64, translated origin (Grid3Drcfs seat)
         std::unique_ptr<Grid3D<double, uint32_t>> g(new Grid3Drnfs_amd<double, uint32_t>(true, 6, 5, 4, 1.0, 500000.0, 4000000.0, -1000.0,

@@ -774,6 +774,103 @@ int SFX(fsm_raypath3d)(const SFX(fsm_grid3d) * g, const REAL* sn, const REAL* T,
     return over ? 3 : 0;
 }
 
+/* Terms of the matrix M of one ray segment, ttcr/Grid3Drn.h:1586-1623 (and :1674-1707, :1715-1747, :1755-1787, the same
+ * block four times): the eight nodes around the segment's mid-point get -s^2 ds w, entries with the same node index are
+ * merged (linear search, push order kept).  As the reference has it: the weights use iv*dx without xmin, and ix+1 can
+ * lie one node past the grid (the Python layer drops entries whose node index is not below the node count,
+ * src/ttcrpy/rgrid.pyx:1180-1186).  mj / mv: capacity cap entries; *nm counts all of them. */
+static void SFX(m_terms3d)(const SFX(fsm_grid3d) * g, const REAL* sn, const REAL mid[3], REAL ds, int iv, long long* mj, REAL* mv,
+                           long cap, long* nm) {
+    const REAL dx = g->dx, dy = g->dx, dz = g->dx;
+    REAL s = SFX(slowness_at3d)(g, sn, mid[0], mid[1], mid[2], iv);
+    s *= s;
+    const size_t ix = (size_t)((mid[0] - g->xmin) / dx), iy = (size_t)((mid[1] - g->ymin) / dy), iz = (size_t)((mid[2] - g->zmin) / dz);
+    for (size_t ii = 0; ii < 2; ++ii)
+        for (size_t jj = 0; jj < 2; ++jj)
+            for (size_t kk = 0; kk < 2; ++kk) {
+                const size_t ivx = ix + ii, jv = iy + jj, kv = iz + kk;
+                /* the 1. literals make the three factors and their product double; dvdv is a T1 */
+                const REAL dvdv = (REAL)((1. - FABS(mid[0] - ivx * dx) / dx) * (1. - FABS(mid[1] - jv * dy) / dy) *
+                                         (1. - FABS(mid[2] - kv * dz) / dz));
+                const long long j = (long long)((kv * g->nny + jv) * g->nnx + ivx);
+                const REAL v = -s * ds * dvdv;
+                long q;
+                const long have = *nm < cap ? *nm : cap;
+                for (q = 0; q < have; ++q)
+                    if (mj[q] == j) { mv[q] += v; break; }
+                if (q == have) {
+                    if (*nm < cap) { mj[*nm] = j; mv[*nm] = v; }
+                    ++*nm;
+                }
+            }
+}
+
+/* Grid3Drn::getRaypath(Tx, t0, Rx, m_data, RxNo, tt, threadNo), ttcr/Grid3Drn.h:1503-1800: the walk of getRaypath with the
+ * terms of M instead of the points.  Restated as it stands: prev_pt is overwritten with curr_pt BEFORE the segment's mid-
+ * point and length are formed (:1590-1597), so every step of the walk contributes -s^2 * 0 * w = a signed zero at the eight
+ * nodes around the step's END point, and only the last hop (or two) to the source carries weight; a receiver on a source
+ * point returns tt = 0 (not t0) and no entries.  Returns like fsm_raypath3d (3: capacity exceeded, *nm still counts). */
+int SFX(fsm_raypath3d_m)(const SFX(fsm_grid3d) * g, const REAL* sn, const REAL* T, int n_src, const REAL* src,
+                         const REAL* t0, const REAL rx[3], int iv, long max_steps, REAL* tt_out, long long* mj, REAL* mv, long cap,
+                         long* nm_out) {
+    REAL tt = 0.0, s1, s2;
+    long nm = 0;
+    *tt_out = tt;
+    *nm_out = 0;
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) return 0;
+    REAL prev[3] = {rx[0], rx[1], rx[2]}, cur[3] = {rx[0], rx[1], rx[2]}, gv[3], mid[3];
+    s1 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+    const REAL dx = g->dx;
+    const REAL maxDist = (REAL)sqrt(dx * dx + dx * dx + dx * dx);
+    int reached = 0;
+    long steps = 0;
+#define FSM_MID(A, B) do { mid[0] = (REAL)0.5 * ((A)[0] + (B)[0]); mid[1] = (REAL)0.5 * ((A)[1] + (B)[1]); mid[2] = (REAL)0.5 * ((A)[2] + (B)[2]); } while (0)
+    while (!reached) {
+        if (++steps > max_steps) { *nm_out = nm; return 2; }
+        SFX(grad3d)(g, T, cur[0], cur[1], cur[2], &gv[0], &gv[1], &gv[2]);
+        gv[0] *= (REAL)-1.0; gv[1] *= (REAL)-1.0; gv[2] *= (REAL)-1.0;
+        SFX(step_to_plane)(g, cur, gv);
+        if (cur[0] < g->xmin || cur[0] > g->xmax || cur[1] < g->ymin || cur[1] > g->ymax || cur[2] < g->zmin ||
+            cur[2] > g->zmax) { *nm_out = nm; return 1; }
+        s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+        tt += 0.5 * (s1 + s2) * SFX(dist3)(prev, cur);
+        s1 = s2;
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        FSM_MID(cur, prev);                                  /* = cur: prev was just overwritten */
+        SFX(m_terms3d)(g, sn, mid, SFX(dist3)(cur, prev), iv, mj, mv, cap, &nm);
+        for (int ns = 0; ns < n_src; ++ns) {
+            const REAL* tx = src + 3 * ns;
+            REAL dist = SFX(dist3)(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1]; gv[2] = tx[2] - cur[2];
+                SFX(step_to_plane)(g, cur, gv);
+                if (SFX(dist3)(cur, prev) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(prev, tx);
+                    FSM_MID(tx, prev);
+                    SFX(m_terms3d)(g, sn, mid, SFX(dist3)(tx, prev), iv, mj, mv, cap, &nm);
+                } else {
+                    s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+                    tt += 0.5 * (s1 + s2) * SFX(dist3)(prev, cur);
+                    s1 = s2;
+                    FSM_MID(cur, prev);
+                    SFX(m_terms3d)(g, sn, mid, SFX(dist3)(cur, prev), iv, mj, mv, cap, &nm);
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(cur, tx);
+                    FSM_MID(tx, cur);
+                    SFX(m_terms3d)(g, sn, mid, SFX(dist3)(tx, cur), iv, mj, mv, cap, &nm);
+                }
+                reached = 1;
+            }
+        }
+    }
+#undef FSM_MID
+    *tt_out = tt;
+    *nm_out = nm;
+    return nm > cap ? 3 : 0;
+}
+
 /* ------------------------------------------------------------------ 2D -- */
 /* 2D node index is z-fastest: n = i*(ncz+1)+j (ttcr/Grid2Drn.h:720). */
 

@@ -104,7 +104,7 @@ def _prep_pts(dt, pts, ncol):
 
 def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
             cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False,
-            return_rays=False):
+            return_rays=False, compute_m=False):
     """Restatement of Grid3Drnfs / Grid3Drcfs ::raytrace (tt_from_rp=False; weno selects the
     two-stage first-order + WENO3 driver).
 
@@ -178,6 +178,33 @@ def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=5
                 rays.append(ray)
             out["tt_rcv"] = vals
             out["rays"] = rays
+        elif compute_m:
+            # Grid3D::raytrace(Tx,t0,Rx,tt,m_data,threadNo) (ttcr/Grid3D.h:743-772): per receiver the (node, value) entries of
+            # the matrix M in the order the reference pushes them, and the traveltime of that overload
+            fm = getattr(L, "fsm_raypath3d_m_" + sfx)
+            vals = np.empty(r.shape[0], dtype=dt)
+            ms = []
+            cap = 64 * (ncx + ncy + ncz) + 256
+            for n, pnt in enumerate(r):
+                pp = np.ascontiguousarray(pnt, dtype=dt)
+                v = ct(0)
+                while True:
+                    mj = np.empty(cap, dtype=np.int64)
+                    mv = np.empty(cap, dtype=dt)
+                    nm = C.c_long(0)
+                    rc = fm(C.byref(g), _p(sn), _p(T), C.c_int(nsrc), _p(src), _p(t0), _p(pp), C.c_int(int(interp_vel)),
+                            C.c_long(1000000), C.byref(v), _p(mj), _p(mv), C.c_long(cap), C.byref(nm))
+                    if rc != 3:
+                        break
+                    cap *= 4
+                if rc == 1:
+                    raise RuntimeError("Error while computing raypaths: going outside grid")
+                if rc == 2:
+                    raise RuntimeError("raypath did not reach the source")
+                vals[n] = v.value
+                ms.append((mj[:nm.value].copy(), mv[:nm.value].copy()))
+            out["tt_rcv"] = vals
+            out["m"] = ms
         elif tt_from_rp:
             # Grid3D::raytrace with tt_from_rp (ttcr/Grid3D.h:493-496): traveltime integrated along the ray
             frp = getattr(L, "fsm_tt_from_raypath3d_" + sfx)
@@ -211,7 +238,7 @@ def cells_to_nodes3d(dtype, ncells, sc):
 
 def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
                 cell_slowness=False, translate=False, rcv=None, weno=False, tt_from_rp=False, interp_vel=False,
-                return_rays=False):
+                return_rays=False, compute_m=False):
     """The compiled, unmodified reference (build container only)."""
     dt = np.dtype(dtype)
     sfx, ct = _TYPES[dt][:2]
@@ -232,6 +259,12 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
             rbuf = np.empty((cap, 3), dtype=np.float64)
             roff = np.zeros(r.shape[0] + 1, dtype=np.int64)
             R.ref_set_rays(_p(rbuf), C.c_long(cap), _p(roff))
+        if compute_m:
+            mcap = 64 * cap
+            mjb = np.empty(mcap, dtype=np.int64)
+            mvb = np.empty(mcap, dtype=np.float64)
+            moff = np.zeros(r.shape[0] + 1, dtype=np.int64)
+            R.ref_set_m(_p(mjb), _p(mvb), C.c_long(mcap), _p(moff))
         try:
             rc = getattr(R, "ref_fsm3d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncy),
                                                 C.c_uint32(ncz), ct(dx), ct(origin[0]), ct(origin[1]), ct(origin[2]),
@@ -242,14 +275,21 @@ def ref_solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, max
         finally:
             if return_rays:
                 R.ref_set_rays(None, C.c_long(0), None)
+            if compute_m:
+                R.ref_set_m(None, None, C.c_long(0), None)
         if rc != 0:
             raise RuntimeError(R.ref_last_error().decode())
+        if compute_m and moff[-1] > mcap:
+            cap = int(moff[-1]) // 64 + 1
+            continue
         if not return_rays or roff[-1] <= cap:
             break
         cap = int(roff[-1])
     out = dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
     if return_rays:
         out["rays"] = [rbuf[roff[n]:roff[n + 1]].astype(dt) for n in range(r.shape[0])]
+    if compute_m:
+        out["m"] = [(mjb[moff[n]:moff[n + 1]].copy(), mvb[moff[n]:moff[n + 1]].astype(dt)) for n in range(r.shape[0])]
     return out
 
 

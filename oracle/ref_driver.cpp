@@ -49,6 +49,19 @@ extern "C" void ref_set_rays(double* buf, long cap_pts, long* off) {
     g_ray_cap = cap_pts;
     g_ray_off = off;
 }
+// when set, the next 3-D solve uses the overload with m_data, Grid3D::raytrace(Tx,t0,Rx,tt,m_data,threadNo) (ttcr/Grid3D.h:743-772
+// -> Grid3Drn::getRaypath(Tx,t0,Rx,m_data,RxNo,tt,threadNo), ttcr/Grid3Drn.h:1503-1800): the (j, v) entries of receiver n, in
+// the order the reference pushed them, occupy [off[n], off[n+1])
+static thread_local long long* g_m_j = nullptr;
+static thread_local double* g_m_v = nullptr;
+static thread_local long g_m_cap = 0;
+static thread_local long* g_m_off = nullptr;
+extern "C" void ref_set_m(long long* j, double* v, long cap, long* off) {
+    g_m_j = j;
+    g_m_v = v;
+    g_m_cap = cap;
+    g_m_off = off;
+}
 extern "C" void ref_set_save(const char* base, int all, int format) {
     g_save_base = base ? base : "";
     g_save_all = all;
@@ -78,6 +91,18 @@ static int run3d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
                 }
             }
             g_ray_off[n_rcv] = k;
+        } else if (g_m_j) {
+            std::vector<std::vector<sijv<T>>> m_data;
+            static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, m_data, 0);
+            long k = 0;
+            for (int n = 0; n < n_rcv; ++n) {
+                g_m_off[n] = k;
+                for (const auto& e : m_data[n]) {
+                    if (k < g_m_cap) { g_m_j[k] = (long long)e.j; g_m_v[k] = (double)e.v; }
+                    ++k;
+                }
+            }
+            g_m_off[n_rcv] = k;
         } else {
             static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, 0);
         }

@@ -1,0 +1,62 @@
+"""Golden vectors of the matrix M (compute_M): tests/golden/m_golden.npz, made with the COMPILED, UNMODIFIED reference
+(oracle/_ref, build container only) through its overload Grid3D::raytrace(Tx, t0, Rx, traveltimes, m_data, threadNo)
+(ttcr/Grid3D.h:743-772 -> Grid3Drn::getRaypath(..., m_data, ...), ttcr/Grid3Drn.h:1503-1800).
+
+  <case>/<dtype>/slowness, src, t0, rcv, meta = (ncx, ncy, ncz, dx, ox, oy, oz, translate, weno)      inputs
+  <case>/<dtype>/tt_rcv           traveltimes of that overload (0 for a receiver on the source)
+  <case>/<dtype>/m_off, m_j, m_v  per receiver n the entries [m_off[n], m_off[n+1]) in the order the reference pushed them
+
+usage: python tests/golden/make_m_golden.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from oracle import oracle as O
+
+
+def cases_m():
+    rng = np.random.default_rng(2024)
+    out = []
+    # smooth and rough node grids, cubic and not, translated origin, source on a node / off node, receivers on the source,
+    # next to the far faces (node indices one past the grid in the reference's weights) and in the interior
+    for name, nc, dx, org, tr, weno, rough, src in (
+            ("m_grad", (20, 20, 20), 1.0, (0.0, 0.0, 0.0), 0, 0, False, [3.3, 4.1, 5.7]),
+            ("m_rough", (18, 14, 11), 0.5, (1.0, -2.0, 0.0), 0, 0, True, [3.25, 1.0, 2.5]),
+            ("m_translate", (12, 16, 10), 2.0, (500000.0, 4000000.0, -1000.0), 1, 0, True, [500009.0, 4000011.5, -993.0]),
+            ("m_weno", (16, 16, 16), 1.0, (0.0, 0.0, 0.0), 0, 1, False, [8.0, 8.0, 8.0])):
+        nn = tuple(v + 1 for v in nc)
+        if rough:
+            s = rng.uniform(0.4, 1.0, nn[0] * nn[1] * nn[2])
+        else:
+            z = org[2] + np.arange(nn[2]) * dx
+            s = np.repeat(1.0 / (1.0 + 0.1 * (z - org[2])), nn[0] * nn[1])
+        lo = np.array(org); hi = lo + np.array(nc) * dx
+        rcv = rng.uniform(lo + 0.6 * dx, hi - 0.6 * dx, (7, 3))
+        rcv = np.vstack([rcv, [src], hi - 0.25 * dx, lo + np.array([0.5, 0.5, 0.5]) * dx])
+        out.append(dict(name=name, nc=nc, dx=dx, org=org, translate=tr, weno=weno, slowness=s, src=np.array([src]), t0=np.array([0.25]), rcv=rcv))
+    return out
+
+
+def main():
+    O.build(with_ref=True)
+    assert O.have_ref(), "the compiled reference is needed"
+    out = {}
+    for c in cases_m():
+        for dt in (np.float32, np.float64):
+            key = f"{c['name']}/{np.dtype(dt).name}"
+            r = O.ref_solve3d(dt, c["nc"], c["dx"], c["org"], c["slowness"], c["src"], t0=c["t0"], rcv=c["rcv"], weno=bool(c["weno"]),
+                              translate=bool(c["translate"]), compute_m=True)
+            out[key + "/tt_rcv"] = r["tt_rcv"]
+            out[key + "/m_off"] = np.cumsum([0] + [len(j) for j, _ in r["m"]]).astype(np.int64)
+            out[key + "/m_j"] = np.concatenate([j for j, _ in r["m"]]).astype(np.int64)
+            out[key + "/m_v"] = np.concatenate([v for _, v in r["m"]]).astype(dt)
+            print(key, "entries", out[key + "/m_j"].size, "nonzero", int(np.count_nonzero(out[key + "/m_v"])),
+                  "past the grid", int(np.sum(out[key + "/m_j"] >= np.prod([v + 1 for v in c["nc"]]))))
+        out[c["name"] + "/slowness"] = c["slowness"]
+        out[c["name"] + "/src"] = c["src"]; out[c["name"] + "/t0"] = c["t0"]; out[c["name"] + "/rcv"] = c["rcv"]
+        out[c["name"] + "/meta"] = np.array(list(c["nc"]) + [c["dx"]] + list(c["org"]) + [c["translate"], c["weno"]], dtype=np.float64)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "m_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

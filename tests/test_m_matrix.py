@@ -1,0 +1,131 @@
+"""The matrix M of `compute_M` (Grid3D::raytrace(..., m_data, threadNo), ttcr/Grid3D.h:743-772 -> Grid3Drn::getRaypath(...,
+m_data, ...), ttcr/Grid3Drn.h:1503-1800): the oracle's restatement against golden vectors made with the compiled reference
+(tests/golden/m_golden.npz + make_m_golden.py) and against the live reference (build container); the HIP path against the same
+vectors through the C ABI (-m gpu), entry for entry in the reference's push order, signed zeros included."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = ["m_grad", "m_rough", "m_translate", "m_weno"]
+
+
+@pytest.fixture(scope="module")
+def mg():
+    return np.load(os.path.join(HERE, "golden", "m_golden.npz"))
+
+
+def _meta(mg, name):
+    m = mg[name + "/meta"]
+    return dict(nc=tuple(int(v) for v in m[:3]), dx=float(m[3]), org=tuple(float(v) for v in m[4:7]), translate=bool(m[7]), weno=bool(m[8]))
+
+
+def _same_entries(j, v, gj, gv):
+    assert np.array_equal(j, gj)
+    assert np.array_equal(v, gv) and np.array_equal(np.signbit(v), np.signbit(gv))   # (-0.0 and +0.0 are different entries)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_oracle_m_matches_golden(oracle, mg, name, dt):
+    c = _meta(mg, name)
+    key = f"{name}/{np.dtype(dt).name}"
+    r = oracle.solve3d(dt, c["nc"], c["dx"], c["org"], mg[name + "/slowness"], mg[name + "/src"], t0=mg[name + "/t0"], rcv=mg[name + "/rcv"],
+                       weno=c["weno"], translate=c["translate"], compute_m=True)
+    np.testing.assert_array_equal(r["tt_rcv"], mg[key + "/tt_rcv"])
+    off = mg[key + "/m_off"]
+    assert len(r["m"]) == off.size - 1
+    for n, (j, v) in enumerate(r["m"]):
+        _same_entries(j, v, mg[key + "/m_j"][off[n]:off[n + 1]], mg[key + "/m_v"][off[n]:off[n + 1]])
+    # what the walk of that overload is: a receiver on the source has no entries and traveltime 0; of a ray's entries only
+    # those of the last hop(s) carry weight
+    on_src = int(np.nonzero(np.all(mg[name + "/rcv"] == mg[name + "/src"][0], axis=1))[0][0])
+    assert off[on_src + 1] == off[on_src] and r["tt_rcv"][on_src] == 0
+    for n in range(off.size - 1):
+        if n != on_src:
+            assert 1 <= np.count_nonzero(mg[key + "/m_v"][off[n]:off[n + 1]]) <= 24
+
+
+def test_oracle_m_matches_live_reference(oracle):
+    if not oracle.have_ref():
+        pytest.skip("the compiled reference is not present (GPU box)")
+    rng = np.random.default_rng(77)
+    for dt in (np.float32, np.float64):
+        for trial in range(6):
+            nc = tuple(int(v) for v in rng.integers(9, 17, 3))
+            dx = float(rng.choice([0.5, 1.0, 2.0]))
+            nn = tuple(v + 1 for v in nc)
+            z = np.arange(nn[2]) * dx
+            s = np.repeat(1.0 / (1.0 + 0.05 * z), nn[0] * nn[1]) * rng.uniform(0.9, 1.1, nn[0] * nn[1] * nn[2])
+            hi = np.array(nc) * dx
+            src = rng.uniform(1.5 * dx, hi - 1.5 * dx, (1, 3))
+            rcv = rng.uniform(0.7 * dx, hi - 0.7 * dx, (6, 3))
+            kw = dict(rcv=rcv, compute_m=True, weno=bool(trial % 2))
+            try:
+                a = oracle.solve3d(dt, nc, dx, (0, 0, 0), s, src, **kw)
+            except RuntimeError as e:   # a walk that leaves the grid: the reference throws as well
+                if "did not reach the source" in str(e):
+                    continue               # (a walk the reference would never finish: nothing to compare with)
+                assert "going outside grid" in str(e)
+                with pytest.raises(RuntimeError, match="going outside grid"):
+                    oracle.ref_solve3d(dt, nc, dx, (0, 0, 0), s, src, **kw)
+                continue
+            b = oracle.ref_solve3d(dt, nc, dx, (0, 0, 0), s, src, **kw)
+            np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
+            for (j1, v1), (j2, v2) in zip(a["m"], b["m"]):
+                _same_entries(j1, v1, j2, v2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hip_m_matches_golden(mg, name, dt):
+    import ttcr_amd
+    from ttcr_amd import _lib
+
+    c = _meta(mg, name)
+    key = f"{name}/{np.dtype(dt).name}"
+    nn = tuple(v + 1 for v in c["nc"])
+    axes = [c["org"][a] + np.arange(nn[a]) * c["dx"] for a in range(3)]
+    g = ttcr_amd.Grid3d(*axes, n_threads=2, cell_slowness=0, method="FSM", tt_from_rp=0, weno=int(c["weno"]), dtype=dt,
+                        translate_grid=c["translate"])
+    g.set_slowness(mg[name + "/slowness"].reshape(nn, order="F"))
+    src = np.column_stack([mg[name + "/t0"], mg[name + "/src"]])
+    rcv = mg[name + "/rcv"]
+    # raw entries through the C ABI, slot 1
+    L = _lib.load()
+    tx = np.ascontiguousarray(mg[name + "/src"], dtype=dt); t0 = np.ascontiguousarray(mg[name + "/t0"], dtype=dt)
+    rx = np.ascontiguousarray(rcv, dtype=dt); out = np.empty(rx.shape[0], dtype=dt)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(L.ttcr_fsm_raytrace_m(g._h, 1, 1, p(tx), p(t0), rx.shape[0], p(rx), p(out)))
+    np.testing.assert_array_equal(out, mg[key + "/tt_rcv"])
+    nrow, nnz = C.c_size_t(0), C.c_size_t(0)
+    _lib.check(L.ttcr_fsm_slot_m_size(g._h, 1, C.byref(nrow), C.byref(nnz)))
+    off = np.zeros(nrow.value + 1, dtype=np.int64); jj = np.empty(max(nnz.value, 1), dtype=np.int64); vv = np.empty(max(nnz.value, 1), dtype=dt)
+    _lib.check(L.ttcr_fsm_get_slot_m(g._h, 1, p(off), p(jj), p(vv)))
+    np.testing.assert_array_equal(off, mg[key + "/m_off"])
+    _same_entries(jj[:nnz.value], vv[:nnz.value], mg[key + "/m_j"], mg[key + "/m_v"])
+    # the Python layer: (tt, M) and (tt, rays, M) like ttcrpy -- one CSR matrix (receivers x nodes) per event, columns ascending
+    tt, M = g.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv, compute_M=True)
+    np.testing.assert_array_equal(tt, mg[key + "/tt_rcv"])
+    assert len(M) == 1 and M[0].shape == (rcv.shape[0], nn[0] * nn[1] * nn[2])
+    goff = mg[key + "/m_off"]
+    for n in range(rcv.shape[0]):
+        row = M[0].getrow(n)
+        gj, gv = mg[key + "/m_j"][goff[n]:goff[n + 1]], mg[key + "/m_v"][goff[n]:goff[n + 1]]
+        o = np.argsort(gj, kind="stable")
+        np.testing.assert_array_equal(row.indices, gj[o])
+        np.testing.assert_array_equal(row.data, gv[o].astype(np.float64))
+    tt2, rays, M2 = g.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv, compute_M=True, return_rays=True)
+    np.testing.assert_array_equal(tt2, tt)
+    assert (M2[0] != M[0]).nnz == 0 and len(rays) == rcv.shape[0]
+    for n in range(rcv.shape[0]):
+        np.testing.assert_array_equal(rays[n][0], rcv[n].astype(dt).astype(np.float64))
+    # refused where the reference's Python layer refuses, and where this backend does not follow it
+    gc = ttcr_amd.Grid3d(*axes, cell_slowness=1, method="FSM", dtype=dt)
+    with pytest.raises(NotImplementedError):
+        gc.raytrace(np.repeat(src, 2, axis=0), rcv[:2], compute_M=True)
+    with pytest.raises(NotImplementedError):
+        g.raytrace(np.repeat(src, 2, axis=0), rcv[:2], compute_L=True)

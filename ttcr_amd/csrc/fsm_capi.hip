@@ -92,6 +92,10 @@ class GridBase {
     virtual void raytrace_rays(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) = 0;
     virtual void slot_rays_size(int slot, size_t* n_rays, size_t* n_points) const = 0;
     virtual void get_slot_rays(int slot, long long* offsets, void* pts) const = 0;
+    // the same with the entries of the matrix M per receiver (m_data overloads), kept per slot like the rays
+    virtual void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) = 0;
+    virtual void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const = 0;
+    virtual void get_slot_m(int slot, long long* row_off, long long* j, void* v) const = 0;
     virtual void validate_points(int n_tx, const void* tx, int n_rx, const void* rx) = 0;   // throws like raytrace would
     // single-source calls that arrive together (ttcrpy's thread pool: nt host threads, one slot each) are solved together
     struct Request {
@@ -1383,8 +1387,8 @@ class GridT : public GridBase {
                 d_raydense.reserve((size_t)std::max<long long>(tot, 1) * nc);
                 HIP_CHECK(hipMemcpyAsync(d_rayoff.p, off.data(), sizeof(long long) * (m + 1), hipMemcpyHostToDevice, stream));
                 if (dim == 3)
-                    fsm_compact_rays<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p, translate ? ox : (T)0,
-                                                               translate ? oy : (T)0, translate ? oz : (T)0);
+                    fsm_compact_rays<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p, shift_rays() ? ox : (T)0,
+                                                               shift_rays() ? oy : (T)0, shift_rays() ? oz : (T)0);
                 else
                     fsm_compact_rays2<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p);
                 HIP_CHECK(hipGetLastError());
@@ -1398,8 +1402,8 @@ class GridT : public GridBase {
                     if (dim == 3) {
                         fsm_raypath3d<T, true><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * q, 1,
                                                                      d_out.p + q, d_rstat.p + q, max_steps, d_raylong.p, need, d_raynp.p + q);
-                        fsm_compact_rays<T><<<1, 128, 0, stream>>>(d_raylong.p, need, d_rayoff2.p, d_raydense.p, translate ? ox : (T)0,
-                                                                   translate ? oy : (T)0, translate ? oz : (T)0);
+                        fsm_compact_rays<T><<<1, 128, 0, stream>>>(d_raylong.p, need, d_rayoff2.p, d_raydense.p, shift_rays() ? ox : (T)0,
+                                                                   shift_rays() ? oy : (T)0, shift_rays() ? oz : (T)0);
                     } else {
                         fsm_raypath2d<T, true><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, cell_s, rg2, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * q,
                                                                      1, d_out.p + q, d_rstat.p + q, max_steps, d_raylong.p, need, d_raynp.p + q);
@@ -1431,6 +1435,121 @@ class GridT : public GridBase {
     long walk_step_limit = 1000000;   // steps after which a ray walk is declared endless (the oracle uses the same number)
     DevBuf<int> d_raynp;
     DevBuf<long long> d_rayoff;
+
+    bool rays_in_grid_coords = false;   // (raytrace_m: the rays stay in the coordinates of a translated grid)
+    bool shift_rays() const { return translate && !rays_in_grid_coords; }
+
+    // ---- matrix M (the raytrace overloads with m_data, ttcr/Grid3D.h:743-772 -> Grid3Drn::getRaypath(Tx, t0, Rx, m_data,
+    // RxNo, tt, threadNo), ttcr/Grid3Drn.h:1503-1800).  The walk of that overload visits exactly the points the r_data
+    // overload records (same gradient steps, same end game), so M is assembled on the host from the rays the device
+    // walked: per step point the reference adds -s^2 * ds * w at the eight nodes around the segment's mid-point, with
+    // prev_pt overwritten by curr_pt BEFORE mid-point and length are taken (:1590-1597): ds = 0, the mid-point is the
+    // step's end point and the eight entries are signed zeros; only the last hop (or two) to the source carries weight.
+    // Restated as it stands (weights without xmin, node indices that may lie one past the grid -- the Python layer
+    // drops those), entries merged by node in push order; a receiver on the source: no entries and tt = 0, not t0.
+    std::vector<std::vector<long long>> slot_m_off, slot_m_j;
+    std::vector<std::vector<T>> slot_m_v;
+    static T host_dist3(const T* a, const T* b) {
+        const T d2 = (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+        return (T)std::sqrt((double)d2);
+    }
+    struct MSeg { size_t row; T mid[3]; T ds; bool real; };   // real: needs the slowness at mid (the last hops)
+    void raytrace_m(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v) override {
+        check_slot(slot);
+        if (dim != 3) throw Unsupported("compute_M is implemented for 3-D grids only");
+        if (cell) throw Unsupported("compute_M not defined for grids with slowness defined for cells");
+        if (n_tx != 1) throw Unsupported("compute_M: sources of more than one point are not supported by the MI355X backend");
+        const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
+        rays_in_grid_coords = true;
+        try {
+            raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot, nullptr, true);
+        } catch (...) { rays_in_grid_coords = false; throw; }
+        rays_in_grid_coords = false;
+        T* tt_out = (T*)tt_out_v;
+        T tx[3] = {((const T*)tx_v)[0], ((const T*)tx_v)[1], ((const T*)tx_v)[2]};
+        if (translate) { tx[0] -= ox; tx[1] -= oy; tx[2] -= oz; }
+        const T maxDist = (T)std::sqrt((double)(dx * dx + dx * dx + dx * dx));
+        // segments of every ray, in the order the reference visits them
+        std::vector<MSeg> segs;
+        for (int r = 0; r < n_rx; ++r) {
+            const T* P = rays_pts.data() + 3 * (size_t)rays_off[r];
+            const long long np = rays_off[r + 1] - rays_off[r];
+            if (np == 1 && P[0] == tx[0] && P[1] == tx[1] && P[2] == tx[2]) { tt_out[r] = (T)0; continue; }   // Rx == Tx (:1516-1520)
+            if (np < 3) throw std::runtime_error("compute_M: unexpected ray of fewer than three points");
+            // end game: [.., c_m, Tx] or [.., c_m, x, Tx] (x: the plane crossed between the last step point and the source)
+            const bool via = np >= 4 && host_dist3(P + 3 * (np - 3), tx) < maxDist;
+            const long long m = via ? np - 3 : np - 2;   // step points P[1..m]
+            for (long long k = 1; k <= m; ++k) {
+                MSeg sg; sg.row = (size_t)r; sg.real = false; sg.ds = (T)0;
+                for (int c = 0; c < 3; ++c) sg.mid[c] = (T)0.5 * (P[3 * k + c] + P[3 * k + c]);
+                segs.push_back(sg);
+            }
+            auto hop = [&](const T* a, const T* b) {   // mid = 0.5 * (a + b), ds = a.getDistance(b)
+                MSeg sg; sg.row = (size_t)r; sg.real = true; sg.ds = host_dist3(a, b);
+                for (int c = 0; c < 3; ++c) sg.mid[c] = (T)0.5 * (a[c] + b[c]);
+                segs.push_back(sg);
+            };
+            const T* cm = P + 3 * m;
+            if (!via) hop(tx, cm);
+            else { hop(P + 3 * (m + 1), cm); hop(tx, P + 3 * (m + 1)); }
+        }
+        // slowness at the mid-points of the weighted hops: one device call (computeSlowness(mid_pt, true))
+        std::vector<T> mids, sl;
+        for (const MSeg& sg : segs) if (sg.real) { mids.push_back(sg.mid[0]); mids.push_back(sg.mid[1]); mids.push_back(sg.mid[2]); }
+        sl.resize(mids.size() / 3);
+        if (!sl.empty()) compute_slowness((int)sl.size(), mids.data(), true, sl.data());
+        if (slot_m_off.empty()) { slot_m_off.resize(n_slots); slot_m_j.resize(n_slots); slot_m_v.resize(n_slots); }
+        std::vector<long long>& mo = slot_m_off[slot]; std::vector<long long>& mj = slot_m_j[slot]; std::vector<T>& mv = slot_m_v[slot];
+        mo.assign((size_t)n_rx + 1, 0); mj.clear(); mv.clear();
+        const size_t nnx = ncx + 1, nny = ncy + 1;
+        size_t q = 0, isl = 0;
+        for (int r = 0; r < n_rx; ++r) {
+            const size_t row0 = mj.size();
+            for (; q < segs.size() && segs[q].row == (size_t)r; ++q) {
+                const MSeg& sg = segs[q];
+                T sq = (T)1;   // any finite positive value: times ds = 0 it is the same signed zero
+                if (sg.real) { sq = sl[isl++]; sq *= sq; }
+                const size_t ix = (size_t)((sg.mid[0] - xmin) / dx), iy = (size_t)((sg.mid[1] - ymin) / dx), iz = (size_t)((sg.mid[2] - zmin) / dx);
+                for (size_t ii = 0; ii < 2; ++ii)
+                    for (size_t jj = 0; jj < 2; ++jj)
+                        for (size_t kk = 0; kk < 2; ++kk) {
+                            const size_t iv = ix + ii, jv = iy + jj, kv = iz + kk;
+                            const T dvdv = (T)((1. - std::abs(sg.mid[0] - iv * dx) / dx) * (1. - std::abs(sg.mid[1] - jv * dx) / dx) *
+                                               (1. - std::abs(sg.mid[2] - kv * dx) / dx));
+                            const long long j = (long long)((kv * nny + jv) * nnx + iv);
+                            const T v = -sq * sg.ds * dvdv;
+                            size_t e = row0;
+                            for (; e < mj.size(); ++e)
+                                if (mj[e] == j) { mv[e] += v; break; }
+                            if (e == mj.size()) { mj.push_back(j); mv.push_back(v); }
+                        }
+            }
+            mo[r + 1] = (long long)mj.size();
+        }
+        // the rays of the call, for callers that want them as well (compute_M with return_rays): shifted back like any ray
+        if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
+        slot_rays_off[slot] = rays_off;
+        slot_rays_pts[slot] = rays_pts;
+        if (translate)
+            for (size_t k = 0; k + 2 < slot_rays_pts[slot].size(); k += 3) { slot_rays_pts[slot][k] += ox; slot_rays_pts[slot][k + 1] += oy; slot_rays_pts[slot][k + 2] += oz; }
+        rays_off.assign(1, 0);
+        rays_pts.clear();
+    }
+    void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const override {
+        check_slot(slot);
+        if (slot_m_off.empty() || slot_m_off[slot].empty()) { *n_rows = 0; *nnz = 0; return; }
+        *n_rows = slot_m_off[slot].size() - 1;
+        *nnz = slot_m_j[slot].size();
+    }
+    void get_slot_m(int slot, long long* row_off, long long* j, void* v) const override {
+        check_slot(slot);
+        if (slot_m_off.empty() || slot_m_off[slot].empty()) { row_off[0] = 0; return; }
+        std::memcpy(row_off, slot_m_off[slot].data(), slot_m_off[slot].size() * sizeof(long long));
+        if (!slot_m_j[slot].empty()) {
+            std::memcpy(j, slot_m_j[slot].data(), slot_m_j[slot].size() * sizeof(long long));
+            std::memcpy(v, slot_m_v[slot].data(), slot_m_v[slot].size() * sizeof(T));
+        }
+    }
 
     // rays of the last raytrace_rays call of every slot
     std::vector<std::vector<long long>> slot_rays_off;
@@ -1631,6 +1750,13 @@ class MultiGrid : public GridBase {
         g.raytrace_rays(l, n_tx, tx, t0, n_rx, rx, tt_out);
         timing = g.timing;
     }
+    void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) override {
+        int l; GridBase& g = of(slot, l);
+        g.raytrace_m(l, n_tx, tx, t0, n_rx, rx, tt_out);
+        timing = g.timing;
+    }
+    void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const override { int l; GridBase& g = of(slot, l); g.slot_m_size(l, n_rows, nnz); }
+    void get_slot_m(int slot, long long* row_off, long long* j, void* v) const override { int l; GridBase& g = of(slot, l); g.get_slot_m(l, row_off, j, v); }
     void slot_rays_size(int slot, size_t* n_rays, size_t* n_points) const override { int l; GridBase& g = of(slot, l); g.slot_rays_size(l, n_rays, n_points); }
     void get_slot_rays(int slot, long long* offsets, void* pts) const override { int l; GridBase& g = of(slot, l); g.get_slot_rays(l, offsets, pts); }
 
@@ -2084,6 +2210,19 @@ int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, cons
 int ttcr_fsm_raytrace_rays(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
                            void* tt_out) {
     return guarded_on(g, [&] { g->impl->raytrace_rays(slot, n_tx, tx, t0, n_rx, rx, tt_out); });
+}
+int ttcr_fsm_raytrace_m(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                        void* tt_out) {
+    return guarded_on(g, [&] { g->impl->raytrace_m(slot, n_tx, tx, t0, n_rx, rx, tt_out); });
+}
+int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz) {
+    return guarded_on(g, [&] {
+        if (!n_rows || !nnz) throw ValueError("null output pointer");
+        g->impl->slot_m_size(slot, n_rows, nnz);
+    });
+}
+int ttcr_fsm_get_slot_m(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* j, void* v) {
+    return guarded_on(g, [&] { g->impl->get_slot_m(slot, row_off, j, v); });
 }
 int ttcr_fsm_slot_rays_size(const ttcr_fsm_grid* g, int slot, size_t* n_rays, size_t* n_points) {
     return guarded_on(g, [&] {

@@ -13,7 +13,7 @@ and error behaviour) for the fast-sweeping path:
 weno=True (the reference's default: first-order sweeps, then third-order WENO sweeps) is
 supported, and so is tt_from_rp=True in 3-D (the 3-D default: traveltimes integrated along the
 ray traced back through the field).  What is not on the FSM hot path raises NotImplementedError
-(SPM/DSPM, compute_L/compute_M).  There is no CPU fallback.
+(SPM/DSPM, compute_L).  There is no CPU fallback.
 """
 import ctypes as C
 
@@ -539,12 +539,11 @@ class _Grid3d(_GridBase):
             raise NotImplementedError('compute_L defined only for grids with slowness defined for cells')
         if compute_L:
             raise NotImplementedError('compute_L defined for the FSM')
-        if compute_M:
-            raise NotImplementedError('compute_M is not built: the reference overload (ttcr/Grid3Drn.h:1503-1800) '
-                                      'yields zero weights for every interior ray segment (see DESIGN.md section 1)')
         vTx, vt0, vRx, iRx = self._split_sources(source, rcv, aggregate_src)
         if slowness is not None:
             self.set_slowness(slowness)
+        if compute_M:
+            return self._run_m(vTx, vt0, vRx, iRx, rcv.shape[0], return_rays)
         if not return_rays:
             return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
         # -> (tt, rays): the overloads with r_data; traveltimes are then integrated along the rays whatever
@@ -554,6 +553,54 @@ class _Grid3d(_GridBase):
             return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no, return_rays=True)
         finally:
             self.set_option("return_rays", 0)
+
+    def _run_m(self, vTx, vt0, vRx, iRx, n_rcv, return_rays):
+        """compute_M=True (rgrid.pyx:1040-1060, :1171-1199): per event the overload with m_data, then one scipy CSR matrix
+        (receivers of the event x nodes) per event, columns ascending, entries whose node index is not below the node count
+        dropped -- what the reference's Python layer builds.  Traveltimes are those of that overload."""
+        import scipy.sparse as sp
+
+        dt = self._dtype
+        tt = np.zeros((n_rcv,), dtype=dt)
+        rays = [[0.0] for _ in range(n_rcv)]
+        M = []
+        NN = self.get_number_of_nodes()
+        for n in range(len(vTx)):
+            slot = n % self._n_threads
+            tx = np.ascontiguousarray(vTx[n], dtype=dt)
+            t0 = np.ascontiguousarray(vt0[n], dtype=dt)
+            rx = np.ascontiguousarray(vRx[n], dtype=dt).reshape(-1, 3)
+            out = np.empty(rx.shape[0], dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_raytrace_m(self._h, slot, tx.shape[0], _ptr(tx), _ptr(t0), rx.shape[0], _ptr(rx), _ptr(out)))
+            tt[iRx[n]] = out
+            nrow, nnz = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(self._lib.ttcr_fsm_slot_m_size(self._h, slot, C.byref(nrow), C.byref(nnz)))
+            off = np.zeros(nrow.value + 1, dtype=np.int64)
+            jj = np.empty(max(nnz.value, 1), dtype=np.int64)
+            vv = np.empty(max(nnz.value, 1), dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_get_slot_m(self._h, slot, _ptr(off), _ptr(jj), _ptr(vv)))
+            indptr = np.zeros(rx.shape[0] + 1, dtype=np.int64)
+            ind, val = [], []
+            for i in range(rx.shape[0]):
+                j, v = jj[off[i]:off[i + 1]], vv[off[i]:off[i + 1]]
+                keep = j < NN
+                j, v = j[keep], v[keep]
+                o = np.argsort(j, kind='stable')
+                ind.append(j[o]); val.append(v[o].astype(np.float64))
+                indptr[i + 1] = indptr[i] + j.size
+            M.append(sp.csr_matrix((np.concatenate(val) if val else np.zeros(0), np.concatenate(ind) if ind else np.zeros(0, dtype=np.int64),
+                                    indptr), shape=(rx.shape[0], NN)))
+            if return_rays:
+                nr, npnt = C.c_size_t(0), C.c_size_t(0)
+                _lib.check(self._lib.ttcr_fsm_slot_rays_size(self._h, slot, C.byref(nr), C.byref(npnt)))
+                roff = np.zeros(nr.value + 1, dtype=np.int64)
+                pts = np.empty((max(npnt.value, 1), 3), dtype=dt)
+                _lib.check(self._lib.ttcr_fsm_get_slot_rays(self._h, slot, _ptr(roff), _ptr(pts)))
+                for k, row in enumerate(iRx[n]):
+                    rays[row] = np.array(pts[roff[k]:roff[k + 1]], dtype=np.float64)
+        if return_rays:
+            return tt, rays, M
+        return tt, M
 
 
 def _builder3d(cls, filename, n_threads=1, method='FSM', tt_from_rp=1, interp_vel=0, eps=1.e-5, maxit=50, weno=1,
