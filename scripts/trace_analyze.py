@@ -32,3 +32,10 @@ T = np.linspace(0, end.max(), 41)
 act = [(int(np.sum((beg <= t) & (end > t))), int(np.sum((ent <= t) & (beg > t)))) for t in T]
 print("time(us): running / resident-but-waiting-for-previous-sweep")
 print("  ".join(f"{t:.0f}:{r}/{w}" for t, (r, w) in zip(T, act)))
+# slot time by kind of unit (SKIP kernels): units that evaluated no chunk at all only relay progress
+res = end - ent
+none = (nch == 0) | (nch == 0xffff)
+some = ~none
+print(f"slot time: all units {res.sum()/1e3:.1f} ms | units without an evaluated chunk: {none.sum()} units, {res[none].sum()/1e3:.1f} ms "
+      f"(median {np.median(res[none]) if none.any() else 0:.1f} us, 90 % {np.percentile(res[none], 90) if none.any() else 0:.1f} us) | "
+      f"units with chunks: {some.sum()} units, {res[some].sum()/1e3:.1f} ms, {nch[some].sum()} chunks = {res[some].sum()/max(nch[some].sum(),1):.2f} us of residence per evaluated chunk")
