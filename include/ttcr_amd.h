@@ -226,7 +226,8 @@ int ttcr_fsm_get_slot_rays(const ttcr_fsm_grid* g, int slot, long long* offsets,
  * segment's mid-point and length (:1590-1597), so every step of the walk contributes signed zeros at the eight nodes around
  * the step's end point and only the last hop (or two) to the source carries weight; its weights drop xmin and its node
  * indices may lie one node past the grid (the Python layer drops those).  Bit-identical to the compiled reference
- * (tests/golden, tests/test_parity_gpu.py).  3-D node grids, sources of ONE point (TTCR_ERR_UNSUPPORTED otherwise).
+ * (tests/golden/m_golden.npz, tests/test_m_matrix.py).  3-D node grids (TTCR_ERR_UNSUPPORTED otherwise, like the Python layer);
+ * a source may have several points as long as only one of them lies within a cell diagonal of the end of a ray.
  * ttcr_fsm_slot_m_size: rows (= receivers) and entries of the last call on `slot`; ttcr_fsm_get_slot_m: row_off[n_rows+1],
  * j[nnz] node indices, v[nnz] values of the grid dtype.  The rays of the same call are available through
  * ttcr_fsm_slot_rays_size / ttcr_fsm_get_slot_rays (the overload with r_data AND m_data, ttcr/Grid3D.h:646-680). */

@@ -23,7 +23,9 @@ def cases_m():
             ("m_grad", (20, 20, 20), 1.0, (0.0, 0.0, 0.0), 0, 0, False, [3.3, 4.1, 5.7]),
             ("m_rough", (18, 14, 11), 0.5, (1.0, -2.0, 0.0), 0, 0, True, [3.25, 1.0, 2.5]),
             ("m_translate", (12, 16, 10), 2.0, (500000.0, 4000000.0, -1000.0), 1, 0, True, [500009.0, 4000011.5, -993.0]),
-            ("m_weno", (16, 16, 16), 1.0, (0.0, 0.0, 0.0), 0, 1, False, [8.0, 8.0, 8.0])):
+            ("m_weno", (16, 16, 16), 1.0, (0.0, 0.0, 0.0), 0, 1, False, [8.0, 8.0, 8.0]),
+            # a source of two points with their own origin times (aggregate_src): every ray ends at the point it reaches first
+            ("m_two_points", (20, 16, 14), 1.0, (0.0, 0.0, 0.0), 0, 0, True, [[3.3, 4.1, 5.7], [16.2, 11.4, 8.9]])):
         nn = tuple(v + 1 for v in nc)
         if rough:
             s = rng.uniform(0.4, 1.0, nn[0] * nn[1] * nn[2])
@@ -32,8 +34,9 @@ def cases_m():
             s = np.repeat(1.0 / (1.0 + 0.1 * (z - org[2])), nn[0] * nn[1])
         lo = np.array(org); hi = lo + np.array(nc) * dx
         rcv = rng.uniform(lo + 0.6 * dx, hi - 0.6 * dx, (7, 3))
-        rcv = np.vstack([rcv, [src], hi - 0.25 * dx, lo + np.array([0.5, 0.5, 0.5]) * dx])
-        out.append(dict(name=name, nc=nc, dx=dx, org=org, translate=tr, weno=weno, slowness=s, src=np.array([src]), t0=np.array([0.25]), rcv=rcv))
+        srcs = np.atleast_2d(np.array(src, dtype=float))
+        rcv = np.vstack([rcv, srcs[:1], hi - 0.25 * dx, lo + np.array([0.5, 0.5, 0.5]) * dx])
+        out.append(dict(name=name, nc=nc, dx=dx, org=org, translate=tr, weno=weno, slowness=s, src=srcs, t0=np.array([0.25, 0.4][:srcs.shape[0]]), rcv=rcv))
     return out
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = ["m_grad", "m_rough", "m_translate", "m_weno"]
+CASES = ["m_grad", "m_rough", "m_translate", "m_weno", "m_two_points"]
 
 
 @pytest.fixture(scope="module")
@@ -99,7 +99,7 @@ def test_hip_m_matches_golden(mg, name, dt):
     tx = np.ascontiguousarray(mg[name + "/src"], dtype=dt); t0 = np.ascontiguousarray(mg[name + "/t0"], dtype=dt)
     rx = np.ascontiguousarray(rcv, dtype=dt); out = np.empty(rx.shape[0], dtype=dt)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    _lib.check(L.ttcr_fsm_raytrace_m(g._h, 1, 1, p(tx), p(t0), rx.shape[0], p(rx), p(out)))
+    _lib.check(L.ttcr_fsm_raytrace_m(g._h, 1, tx.shape[0], p(tx), p(t0), rx.shape[0], p(rx), p(out)))
     np.testing.assert_array_equal(out, mg[key + "/tt_rcv"])
     nrow, nnz = C.c_size_t(0), C.c_size_t(0)
     _lib.check(L.ttcr_fsm_slot_m_size(g._h, 1, C.byref(nrow), C.byref(nnz)))
@@ -108,7 +108,9 @@ def test_hip_m_matches_golden(mg, name, dt):
     np.testing.assert_array_equal(off, mg[key + "/m_off"])
     _same_entries(jj[:nnz.value], vv[:nnz.value], mg[key + "/m_j"], mg[key + "/m_v"])
     # the Python layer: (tt, M) and (tt, rays, M) like ttcrpy -- one CSR matrix (receivers x nodes) per event, columns ascending
-    tt, M = g.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv, compute_M=True)
+    multi = src.shape[0] > 1   # a source of several points: the rows are the points (aggregate_src), every receiver belongs to it
+    srows = src if multi else np.repeat(src, rcv.shape[0], axis=0)
+    tt, M = g.raytrace(srows, rcv, compute_M=True, aggregate_src=multi)
     np.testing.assert_array_equal(tt, mg[key + "/tt_rcv"])
     assert len(M) == 1 and M[0].shape == (rcv.shape[0], nn[0] * nn[1] * nn[2])
     goff = mg[key + "/m_off"]
@@ -118,7 +120,7 @@ def test_hip_m_matches_golden(mg, name, dt):
         o = np.argsort(gj, kind="stable")
         np.testing.assert_array_equal(row.indices, gj[o])
         np.testing.assert_array_equal(row.data, gv[o].astype(np.float64))
-    tt2, rays, M2 = g.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv, compute_M=True, return_rays=True)
+    tt2, rays, M2 = g.raytrace(srows, rcv, compute_M=True, return_rays=True, aggregate_src=multi)
     np.testing.assert_array_equal(tt2, tt)
     assert (M2[0] != M[0]).nnz == 0 and len(rays) == rcv.shape[0]
     for n in range(rcv.shape[0]):
@@ -126,6 +128,6 @@ def test_hip_m_matches_golden(mg, name, dt):
     # refused where the reference's Python layer refuses, and where this backend does not follow it
     gc = ttcr_amd.Grid3d(*axes, cell_slowness=1, method="FSM", dtype=dt)
     with pytest.raises(NotImplementedError):
-        gc.raytrace(np.repeat(src, 2, axis=0), rcv[:2], compute_M=True)
+        gc.raytrace(np.repeat(src[:1], 2, axis=0), rcv[:2], compute_M=True)
     with pytest.raises(NotImplementedError):
-        g.raytrace(np.repeat(src, 2, axis=0), rcv[:2], compute_L=True)
+        g.raytrace(np.repeat(src[:1], 2, axis=0), rcv[:2], compute_L=True)

@@ -1458,7 +1458,7 @@ class GridT : public GridBase {
         check_slot(slot);
         if (dim != 3) throw Unsupported("compute_M is implemented for 3-D grids only");
         if (cell) throw Unsupported("compute_M not defined for grids with slowness defined for cells");
-        if (n_tx != 1) throw Unsupported("compute_M: sources of more than one point are not supported by the MI355X backend");
+        if (n_tx < 1) throw ValueError("every source needs at least one point");
         const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
         rays_in_grid_coords = true;
         try {
@@ -1466,19 +1466,31 @@ class GridT : public GridBase {
         } catch (...) { rays_in_grid_coords = false; throw; }
         rays_in_grid_coords = false;
         T* tt_out = (T*)tt_out_v;
-        T tx[3] = {((const T*)tx_v)[0], ((const T*)tx_v)[1], ((const T*)tx_v)[2]};
-        if (translate) { tx[0] -= ox; tx[1] -= oy; tx[2] -= oz; }
+        std::vector<T> txs((const T*)tx_v, (const T*)tx_v + 3 * (size_t)n_tx);
+        if (translate)
+            for (int q = 0; q < n_tx; ++q) { txs[3 * q] -= ox; txs[3 * q + 1] -= oy; txs[3 * q + 2] -= oz; }
         const T maxDist = (T)std::sqrt((double)(dx * dx + dx * dx + dx * dx));
         // segments of every ray, in the order the reference visits them
         std::vector<MSeg> segs;
         for (int r = 0; r < n_rx; ++r) {
             const T* P = rays_pts.data() + 3 * (size_t)rays_off[r];
             const long long np = rays_off[r + 1] - rays_off[r];
-            if (np == 1 && P[0] == tx[0] && P[1] == tx[1] && P[2] == tx[2]) { tt_out[r] = (T)0; continue; }   // Rx == Tx (:1516-1520)
+            bool on_src = false;
+            for (int q = 0; q < n_tx; ++q) on_src = on_src || (P[0] == txs[3 * q] && P[1] == txs[3 * q + 1] && P[2] == txs[3 * q + 2]);
+            if (np == 1 && on_src) { tt_out[r] = (T)0; continue; }   // Rx == Tx (:1516-1520): no entries, and 0 -- not t0
             if (np < 3) throw std::runtime_error("compute_M: unexpected ray of fewer than three points");
-            // end game: [.., c_m, Tx] or [.., c_m, x, Tx] (x: the plane crossed between the last step point and the source)
-            const bool via = np >= 4 && host_dist3(P + 3 * (np - 3), tx) < maxDist;
-            const long long m = via ? np - 3 : np - 2;   // step points P[1..m]
+            // The walk stops at the FIRST step point that is closer than a cell diagonal to a source point: the step points are
+            // P[1..m], the end game follows -- [.., c_m, Tx] or [.., c_m, x, Tx] (x: the plane crossed between c_m and Tx).
+            long long m = -1;
+            int ns = -1, near = 0;
+            for (long long k = 1; k < np && m < 0; ++k)
+                for (int q = 0; q < n_tx; ++q)
+                    if (host_dist3(P + 3 * k, txs.data() + 3 * q) < maxDist) { if (m < 0) { m = k; ns = q; } ++near; }
+            if (m < 0 || np - m < 2 || np - m > 3) throw std::runtime_error("compute_M: the end of a ray does not have the expected shape");
+            if (near > 1)   // (the reference then runs its end game once per such point, on a point the first run has moved)
+                throw Unsupported("compute_M: two points of a source within a cell diagonal of the end of a ray are not supported");
+            const T* tx = txs.data() + 3 * ns;
+            const bool via = np - m == 3;
             for (long long k = 1; k <= m; ++k) {
                 MSeg sg; sg.row = (size_t)r; sg.real = false; sg.ds = (T)0;
                 for (int c = 0; c < 3; ++c) sg.mid[c] = (T)0.5 * (P[3 * k + c] + P[3 * k + c]);
