@@ -129,6 +129,59 @@ int main(void) {
         }
     CHECK(ends_ok, "rays in receiver-row order, receiver -> source");
     CHECK(ttcr_fsm_set_option(g, "return_rays", 0.0) == TTCR_OK, "return_rays off");
+
+    /* the r_data overload a worker thread calls: traveltimes along the ray + the rays of THIS slot */
+    const float ry[6] = {10.0f, 5.0f, 5.5f, 4.4f, 0.3f, 1.9f};
+    float rtt2[2];
+    CHECK(ttcr_fsm_raytrace_rays(g, 0, 1, tx, t0, 2, ry, rtt2) == TTCR_OK, "raytrace_rays slot 0");
+    printf("ttrays %a %a\n", rtt2[0], rtt2[1]);
+    size_t sr = 0, sp = 0;
+    CHECK(ttcr_fsm_slot_rays_size(g, 0, &sr, &sp) == TTCR_OK && sr == 2 && sp >= 4, "slot_rays_size");
+    long long soff[3];
+    float* spts = (float*)malloc(3 * sp * sizeof(float));
+    CHECK(ttcr_fsm_get_slot_rays(g, 0, soff, spts) == TTCR_OK && soff[0] == 0 && (size_t)soff[2] == sp, "get_slot_rays");
+    CHECK(memcmp(spts, ry, 3 * sizeof(float)) == 0 && memcmp(spts + 3 * (soff[1] - 1), tx, 3 * sizeof(float)) == 0,
+          "slot ray 0 runs receiver -> source");
+    printf("rays_npts %lld %lld\n", soff[1], soff[2] - soff[1]);
+    /* the m_data overload (compute_M) on the other slot; the rays of slot 0 stay what they were */
+    float mtt2[2];
+    CHECK(ttcr_fsm_raytrace_m(g, 1, 1, tx, t0, 2, ry, mtt2) == TTCR_OK, "raytrace_m slot 1");
+    printf("ttm %a %a\n", mtt2[0], mtt2[1]);
+    size_t mrows = 0, mnnz = 0;
+    CHECK(ttcr_fsm_slot_m_size(g, 1, &mrows, &mnnz) == TTCR_OK && mrows == 2 && mnnz >= 16, "slot_m_size");
+    long long mro[3];
+    long long* mj = (long long*)malloc(mnnz * sizeof(long long));
+    float* mv = (float*)malloc(mnnz * sizeof(float));
+    CHECK(ttcr_fsm_get_slot_m(g, 1, mro, mj, mv) == TTCR_OK && mro[0] == 0 && (size_t)mro[2] == mnnz, "get_slot_m");
+    double msum = 0;
+    long long jsum = 0;
+    for (size_t n = 0; n < mnnz; ++n) { msum += mv[n]; jsum += mj[n]; }
+    printf("m_shape %lld %lld\n", mro[1], mro[2] - mro[1]);
+    printf("m_sums %a %lld\n", msum, jsum);
+    size_t sr2 = 0, sp2 = 0;
+    CHECK(ttcr_fsm_slot_rays_size(g, 0, &sr2, &sp2) == TTCR_OK && sr2 == sr && sp2 == sp, "rays of slot 0 untouched by slot 1");
+    CHECK(ttcr_fsm_raytrace_m(g, 2, 1, tx, t0, 2, ry, mtt2) == TTCR_ERR_VALUE, "raytrace_m slot out of range -> TTCR_ERR_VALUE");
+    double ch[50], chw[50];
+    CHECK(ttcr_fsm_get_changes(g, 1, ch, 50, chw, 50) == TTCR_OK && ch[0] > 0 && ch[niter - 1] >= 0 && chw[0] == 0, "get_changes");
+    printf("change3d %a %a\n", ch[0], ch[niter - 1]);
+    CHECK(ttcr_fsm_n_devices(g) == 1, "n_devices of a plain grid");
+    free(spts); free(mj); free(mv);
+    ttcr_fsm_destroy(g);
+
+    /* ------------------------------------------------------------------ one handle over several replicas */
+    g = NULL;
+    const int devs[2] = {0, 0};   /* the same ordinal twice: two replicas on the one GPU of the test box */
+    CHECK(ttcr_fsm3d_create_multi(&g, TTCR_F32, 0, ncx, ncy, ncz, 0.5, 1.0, -2.0, 0.0, 1e-5, 50, 0, 4, 0, devs, 2) == TTCR_OK,
+          "create3d_multi");
+    CHECK(ttcr_fsm_n_devices(g) == 2 && ttcr_fsm_n_slots(g) == 4, "n_devices / n_slots of the multi handle");
+    CHECK(ttcr_fsm_set_slowness(g, s, nn) == TTCR_OK, "set_slowness reaches every replica");
+    float dmtt[6];
+    CHECK(ttcr_fsm_raytrace_multi(g, 3, tx_off, mtx, mt0, rx_off, mrx, dmtt) == TTCR_OK, "raytrace_multi over two replicas");
+    CHECK(memcmp(dmtt, mtt, sizeof(mtt)) == 0, "two replicas == one device, bit for bit");
+    CHECK(ttcr_fsm_raytrace(g, 3, 1, tx, t0, 3, rx, tt) == TTCR_OK && memcmp(tt, ti, sizeof(ti)) == 0, "slot 3 lives on replica 1");
+    ttcr_fsm_grid* g2 = NULL;
+    CHECK(ttcr_fsm3d_create_multi(&g2, TTCR_F32, 0, ncx, ncy, ncz, 0.5, 1.0, -2.0, 0.0, 1e-5, 50, 0, 4, 0, devs, 0) == TTCR_ERR_VALUE && !g2,
+          "empty device list -> TTCR_ERR_VALUE");
     ttcr_fsm_destroy(g);
 
     /* ------------------------------------------------------------------ 3-D cell slowness + bad arguments */

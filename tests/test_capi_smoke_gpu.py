@@ -60,8 +60,12 @@ def test_capi_smoke_runs_and_matches_the_oracle(oracle):
     vals = {}
     for line in out.splitlines():
         k, *rest = line.split()
-        if k in ("tt3d", "ttmulti", "ttcells", "tt2d", "field3d_sum", "field3d_probe", "niter3d"):
-            vals[k] = [float.fromhex(v) if k != "niter3d" else int(v) for v in rest]
+        if k in ("tt3d", "ttmulti", "ttcells", "tt2d", "field3d_sum", "field3d_probe", "ttrays", "ttm", "change3d"):
+            vals[k] = [float.fromhex(v) for v in rest]
+        elif k in ("niter3d", "rays_npts", "m_shape"):
+            vals[k] = [int(v) for v in rest]
+        elif k == "m_sums":
+            vals[k] = [float.fromhex(rest[0]), int(rest[1])]
     # 3-D node grid, fp32
     nc, dx, org = (18, 14, 11), 0.5, (1.0, -2.0, 0.0)
     nn = 19 * 15 * 12
@@ -79,6 +83,20 @@ def test_capi_smoke_runs_and_matches_the_oracle(oracle):
     want = np.concatenate([oracle.solve3d(np.float32, nc, dx, org, s, mtx[n:n + 1], t0=mt0[n:n + 1],
                                           rcv=mrx[off[n]:off[n + 1]])["tt_rcv"] for n in range(3)])
     np.testing.assert_array_equal(np.array(vals["ttmulti"], dtype=np.float32), want)
+    # the r_data and m_data overloads (rays per slot, matrix M per slot)
+    ry = rx[1:]
+    orr = oracle.solve3d(np.float32, nc, dx, org, s, [[3.3, 1.1, 2.7]], t0=[0.25], rcv=ry, return_rays=True)
+    np.testing.assert_array_equal(np.array(vals["ttrays"], dtype=np.float32), orr["tt_rcv"])
+    assert vals["rays_npts"] == [len(r) for r in orr["rays"]]
+    om = oracle.solve3d(np.float32, nc, dx, org, s, [[3.3, 1.1, 2.7]], t0=[0.25], rcv=ry, compute_m=True)
+    np.testing.assert_array_equal(np.array(vals["ttm"], dtype=np.float32), om["tt_rcv"])
+    assert vals["m_shape"] == [len(j) for j, _ in om["m"]]
+    assert vals["m_sums"][1] == int(sum(int(np.sum(j)) for j, _ in om["m"]))
+    assert vals["m_sums"][0] == float(sum(np.sum(v.astype(np.float64)) for _, v in om["m"]))
+    # the stopping rule's quantity: fp64 sum of the decreases vs the reference's sequential fp32 sum
+    # (iteration 1 lowers every node from the initial "infinity": huge in both)
+    assert vals["change3d"][0] > 1e30 and o["change"][0] > 1e30
+    np.testing.assert_allclose(vals["change3d"][1], o["change"][-1], rtol=1e-3)
     # 3-D cell grid, fp64
     sc = slow(1000 + np.arange(6 * 5 * 4)).astype(np.float64)
     oc = oracle.solve3d(np.float64, (6, 5, 4), 1.0, (0, 0, 0), sc, [[2.5, 2.5, 1.0]], rcv=[[0, 0, 0], [6, 5, 4]], cell_slowness=True)
