@@ -291,6 +291,11 @@ class GridT : public GridBase {
         max_batch = n_slots;
         device = dev;
         HIP_CHECK(hipSetDevice(device));
+        {
+            int cus = 0;
+            HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            persist_wgs = 8 * std::max(cus, 1);
+        }
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
@@ -372,6 +377,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_PRE_MIN")) pre_min = std::atoi(e);                     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_SKIP_UNITS")) skip_units_min = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_WGS")) persist_wgs = std::atoi(e);              // tuning only
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
@@ -517,7 +523,10 @@ class GridT : public GridBase {
         pa.n_sw_groups = n_groups();
         pa.n_sw_sweeps = sw_sweeps;
 
-        const dim3 block(C::PJ * C::PK), grid((unsigned)n_patches * batch);
+        // workgroups take units until the tickets run out: no more of them than can be resident (8 per CU is more than any
+        // instantiation fits; the surplus finds the ticket counter exhausted).  TTCR_FSM_WGS=0: one workgroup per unit.
+        const size_t wg_cap = persist_wgs > 0 ? (size_t)persist_wgs : ~(size_t)0;
+        const dim3 block(C::PJ * C::PK), grid((unsigned)std::min<size_t>((size_t)n_patches * batch, wg_cap));
         const int ndir = DIM == 3 ? 8 : 4;
         if (mode == 2) {
             // whole iteration in one launch: tickets direction-major, sweeps overlap at their ends
@@ -527,7 +536,7 @@ class GridT : public GridBase {
             a.rf = a.rj = a.rk = a.rev = 0;
             a.s_sheared = nullptr;
             pa.timeout_ticks = 1000000000ull;  // 10 s: a unit may wait for most of the previous sweep
-            const dim3 gridx((unsigned)n_patches * batch * ndir);
+            const dim3 gridx((unsigned)std::min<size_t>((size_t)n_patches * batch * ndir, wg_cap));
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
             HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
@@ -865,6 +874,7 @@ class GridT : public GridBase {
     // (1.03x ... 1.19x from 1 to 64 sources on 1024^2 ... 8192^2 nodes, although the SKIP kernels do not follow the
     // previous sweep up the columns).  TTCR_FSM_SKIP_UNITS: work units per sweep from which the first-order 3-D sweeps skip.
     int skip_units_min = 2048;
+    int persist_wgs = 2048;   // workgroups of a sweep launch (each takes units until none is left): 8 per CU; 0: one per unit
     int skip_default(int entries) const {
         if (dim != 3) return 1;
         if (stage == 1) return 1;

@@ -123,7 +123,10 @@ __device__ __forceinline__ float update3(float ax, float ay, float az, float s, 
         r = __builtin_fma(r, 2.0, (3.0 * dfh) * dfh);
         const float s12 = a1 + a2;
         const float s123 = s12 + a3;
-        const float t3 = (float)((1. / 3.) * ((double)s123 + sqrt_disc(r)));
+        // (no zero fix-up of the root: wherever t3 is taken the 2-D value lies above a3, i.e. fh^2 > u^2 + v^2 in the
+        // notation below, and r = 3 fh^2 - (u-v)^2 - u^2 - v^2 > (u+v)^2 >= 0 then; r == 0 needs u = v = 0, where
+        // r = 3 fh^2.  A lane with r <= 0 gets NaN and takes t1 or t2, as it would with sqrt(r).)
+        const float t3 = (float)((1. / 3.) * ((double)s123 + sqrt_disc_pos(r)));
         // Is the 2-D quadratic t2 needed at all?  The reference takes the 3-D value iff t1 > a2 and
         // t2 > a3.  With u = a3-a1, v = a3-a2:  t2* > a3  <=>  fh^2 > u^2 + v^2 (exact arithmetic),
         // and t2* - a3 >= (fh^2-u^2-v^2)/(3.42 fh).  The computed t2 differs from t2* by less than
@@ -139,7 +142,8 @@ __device__ __forceinline__ float update3(float ax, float ay, float az, float s, 
             const float df = a1 - a2;
             const float df2 = df * df;
             const double disc2 = __builtin_fma(dfh * dfh, 2.0, -(double)df2);
-            const float t2 = (float)(0.5 * ((double)s12 + sqrt_disc(disc2)));
+            // (disc2 == 0 needs |a1-a2| = sqrt(2) fh, where t1 <= a2 and t2 is dropped: no zero fix-up either)
+            const float t2 = (float)(0.5 * ((double)s12 + sqrt_disc_pos(disc2)));
             t = t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
         } else {
             t = t1 > a2 ? t3 : t1;
@@ -763,8 +767,9 @@ __device__ __forceinline__ void st_sc1(Pack<double, 2>* p, Pack<double, 2> x) {
 // PRE = true: lane 0 samples the upwind progress counters one chunk ahead (see the wait at the top of the
 // chunk loop).  Pays off with several units in flight per patch position (64 sources: +3.8 %) and for the one-wave
 // 2-D patches (a single 4096^2 solve: +24 %); a lone 3-D source is 4 % better off without.
-template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE = false>
-__global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeof(T) == 4) ? 3 : FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
+// One work unit: the body of fsm_sweep_persistent below.  Returns false when the tickets of the launch have run out.
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE>
+__device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     using P = Pack<T, NS>;
     constexpr int NT = PJ * PK;
     constexpr int RJ = PJ + 2 * H;
@@ -782,7 +787,7 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
     const SweepArgs<T>& a = pa.s;
 
     __shared__ P Tt[NROWS * RS];
-    __shared__ int s_ticket;
+    __shared__ int s_ticket, s_abort;
     __shared__ int s_anychg;
     // scheduler state of the SKIP kernels (thread 0 only, apart from s_slab's set-up and s_next / s_act)
     constexpr int SLABW = SKIP ? FSM_SLAB_WORDS : 1;
@@ -795,18 +800,35 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
     __shared__ unsigned s_mywv[2];
     // per-unit constants and the little state of the scheduler live in LDS, not in registers: they are touched once per
     // chunk by one lane, and the level march has no register to spare (a resident wave per SIMD is at stake)
-    enum { U_THR, U_RSJLO, U_RSKLO, U_RSNJ, U_RSNK, U_LCF, U_UPLCF0, U_UPLCF1, U_HIST, U_EVER, U_UCHG, U_PENDV, U_N };
+    enum { U_THR, U_RSJLO, U_RSKLO, U_RSNJ, U_RSNK, U_LCF, U_UPLCF0, U_UPLCF1, U_HIST, U_EVER, U_UCHG, U_PENDV, U_LCHG, U_N };
     __shared__ int s_u[U_N];
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (see the loop in fsm_sweep_persistent)
     // debug phase timers (FSM_ENABLE_PROF builds): thread 0 sums per phase in registers, one flush per unit
     unsigned long long prof_t = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
     unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned pchunks = 0;
+    unsigned long long twait = 0;   // FSM_ENABLE_PROF == 2 (unit trace only, up to 2^20 units): ticks thread 0 spent polling
+    constexpr int FSM_TRACE_UNITS = FSM_ENABLE_PROF == 2 ? (1 << 20) : 65536;
     const unsigned long long trace_t0 = prof_t;
     unsigned long long* prec = nullptr;   // set once the ticket is known
+    __shared__ unsigned long long s_pacc[FSM_ENABLE_PROF == 2 ? 8 : 1];   // trace-only builds: the phase sums live in LDS
+    if constexpr (FSM_ENABLE_PROF == 2) {                                  // (no register of the march is spent on them)
+        if (tid == 0) {
+            for (int q = 0; q < 6; ++q) s_pacc[q] = 0;
+            s_pacc[6] = prof_t;
+        }
+    }
 #define FSM_PMARK(slot_)                                                          \
-    if (FSM_ENABLE_PROF && a.prof && tid == 0) {                                  \
+    if constexpr (FSM_ENABLE_PROF == 2) {                                         \
+        if (a.prof && tid == 0) {                                                 \
+            const unsigned long long now_ = wall_clock64();                       \
+            s_pacc[slot_] += now_ - s_pacc[6];                                    \
+            s_pacc[6] = now_;                                                     \
+        }                                                                         \
+    }                                                                             \
+    if (FSM_ENABLE_PROF == 1 && a.prof && tid == 0) {                             \
         const unsigned long long now_ = wall_clock64();                           \
         pacc[slot_] += now_ - prof_t;                                             \
         prof_t = now_;                                                            \
@@ -836,14 +858,17 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
         if (ia >= ntj || ib >= ntk) return nullptr;
         return pa.sync + 2 + ((size_t)pd * pa.batch + z_) * pa.n_patches + ((tka + ib) * npj + tja + ia);
     };
+    __syncthreads();   // (the workgroup comes here once per unit: every read of the previous unit's shared state is over)
     if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
+    if (tid == 1) s_abort = __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight together)
     __syncthreads();
+    if (s_abort) return false;   // a unit timed out: the solve fails on the host, nobody takes another unit
     const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
     // XS: `order` lists the units (direction, patch) of the whole iteration in ticket order -- any order in which a
     // unit comes after its upwind patches and after the patches of the previous sweep it has to see finished
     const int oidx = ticket / pa.batch, z = ticket - oidx * pa.batch;
-    if (oidx >= (XS ? pa.n_patches * pa.ndir : pa.n_patches)) return;
-    if (FSM_ENABLE_PROF && a.prof && ticket < 8192) prec = a.prof + 8 + 4 * 65536 + (size_t)ticket * 400;
+    if (oidx >= (XS ? pa.n_patches * pa.ndir : pa.n_patches)) return false;
+    if (FSM_ENABLE_PROF == 1 && a.prof && ticket < 8192) prec = a.prof + 8 + 4 * 65536 + (size_t)ticket * 400;
     const uint32_t tile = pa.order[oidx];
     const int dir = XS ? (int)(tile >> 28) : pa.dir;
     const int TJ = XS ? (int)(tile & 0x3fffu) : (int)(tile & 0xffffu), TK = XS ? (int)((tile >> 14) & 0x3fffu) : (int)(tile >> 16);
@@ -871,7 +896,7 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
     const int grp = a.slots[z];   // slot (NS == 1) or slot group (NS == 2)
     if (grp < 0) {  // converged source(s): nothing to do, but never leave a waiter hanging
         if (tid == 0) __hip_atomic_store(my_prog, SKIP ? FSM_FIN : 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+        return true;
     }
     // SKIP: when the previous sweep (of this source group) has finished every patch and changed no node, this sweep cannot
     // change one either (by induction along its own order every node sees the neighbour values of its last visit): the unit
@@ -888,13 +913,13 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
                 if (tid == 0) {
                     __hip_atomic_store(my_prog, FSM_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicAdd(pa.sw + (size_t)sigma0 * pa.n_sw_groups + grp, 1ull);
-                    if (FSM_ENABLE_PROF && a.prof && ticket < 65536) {
+                    if (FSM_ENABLE_PROF && a.prof && ticket < FSM_TRACE_UNITS) {
                         unsigned long long* tr = a.prof + 8 + 4 * (size_t)ticket;
-                        tr[0] = trace_t0; tr[1] = trace_t0; tr[2] = wall_clock64();
+                        tr[0] = trace_t0; tr[1] = FSM_ENABLE_PROF == 2 ? 0ull : trace_t0; tr[2] = wall_clock64();
                         tr[3] = (unsigned long long)TJ | ((unsigned long long)TK << 16) | ((unsigned long long)dir << 32) | ((unsigned long long)z << 40) | (0xffffull << 48);
                     }
                 }
-                return;
+                return true;
             }
         }
     }
@@ -1217,7 +1242,7 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
             const int lsj = Ls - PJ, lsk = Ls - PK, mu = TJ + TK - 1;
             s_u[U_UPLCF0] = lsj - (((lsj - mu) % C + C) % C);
             s_u[U_UPLCF1] = lsk - (((lsk - mu) % C + C) % C);
-            s_u[U_HIST] = 0; s_u[U_EVER] = 0; s_u[U_UCHG] = 0; s_u[U_PENDV] = 0;
+            s_u[U_HIST] = 0; s_u[U_EVER] = 0; s_u[U_UCHG] = 0; s_u[U_PENDV] = 0; s_u[U_LCHG] = 0;
         }
         __syncthreads();
         {
@@ -1299,7 +1324,10 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
         int spins = 0;
         for (;;) {
             const int v = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >= want) return v;
+            if (v >= want) {
+                if (FSM_ENABLE_PROF == 2 && spins) twait += wall_clock64() - t0;
+                return v;
+            }
             if (spins == 0) t0 = wall_clock64();
             if ((++spins & 63) == 0) {
                 if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; return v; }
@@ -1318,8 +1346,21 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
             if (tid == 0) {
                 int L = Lc, act = 1, h = s_u[U_HIST];
                 const int lcf = s_u[U_LCF];
+                // the common case in a region that is being worked on: the chunk before this one was evaluated and changed a
+                // node.  Its bricks went into the slab mask, and the F range of this chunk (widened by H) overlaps the range of
+                // that one: slab_any() below would find them -- the chunk is dirty, only the upwind progress has to be there.
+                const bool follow = s_u[U_LCHG] != 0 && L <= Le;
+                s_u[U_LCHG] = 0;
                 for (;;) {
                     if (L > Le) { act = 0; break; }
+                    if (follow) {
+                        const int need8 = (L + C - 1) << 8;
+                        bool ok = true;
+                        if (up_j && pre_j < need8) pre_j = poll_until(up_j, need8, ok);
+                        if (up_k && ok && pre_k < need8) pre_k = poll_until(up_k, need8, ok);
+                        if (!ok) act = 0;
+                        break;
+                    }
                     const int need = L + C - 1, need8 = need << 8;
                     int vj = FSM_FIN, vk = FSM_FIN;
                     bool ok = true;
@@ -1623,6 +1664,7 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
                             }
                     }
                     s_u[U_UCHG] = 1;
+                    s_u[U_LCHG] = 1;
                 }
                 const int h2 = ((s_u[U_HIST] << 2) | (chg_flags >> 1)) & 0xff, ev2 = s_u[U_EVER] | (chg_flags >> 1);
                 s_u[U_HIST] = h2;
@@ -1674,15 +1716,23 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
     }
 
     if (FSM_ENABLE_PROF && a.prof && tid == 0) {
+        if constexpr (FSM_ENABLE_PROF == 2) {
+            for (int q = 0; q < 6; ++q) atomicAdd(a.prof + q, s_pacc[q]);
+            atomicAdd(a.prof + 6, 1ull);
+            atomicAdd(a.prof + 7, (unsigned long long)pchunks);
+        }
+        if (FSM_ENABLE_PROF == 1) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) atomicAdd(a.prof + q, pacc[q]);
-        atomicAdd(a.prof + 6, 1ull);
-        atomicAdd(a.prof + 7, (unsigned long long)pchunks);
+            for (int q = 0; q < 6; ++q) atomicAdd(a.prof + q, pacc[q]);
+            atomicAdd(a.prof + 6, 1ull);
+            atomicAdd(a.prof + 7, (unsigned long long)pchunks);
+        }
         // per-unit trace (last iteration wins): entry, first chunk, exit on the 100 MHz clock; patch and direction
         // (trace buffer: 65536 unit entries of 4 words, then 80 chunk records of 5 stamps for each of the first 8192 units)
-        if (ticket < 65536) {
+        if (ticket < FSM_TRACE_UNITS) {
             unsigned long long* tr = a.prof + 8 + 4 * (size_t)ticket;
-            tr[0] = trace_t0; tr[1] = trace_t1; tr[2] = wall_clock64();
+            // (trace-only builds: the second word holds first chunk - entry in its low half, the polling ticks in its high half)
+            tr[0] = trace_t0; tr[1] = FSM_ENABLE_PROF == 2 ? ((trace_t1 - trace_t0) & 0xffffffffull) | (twait << 32) : trace_t1; tr[2] = wall_clock64();
             tr[3] = (unsigned long long)TJ | ((unsigned long long)TK << 16) | ((unsigned long long)dir << 32) | ((unsigned long long)z << 40) |
                     ((unsigned long long)pchunks << 48);
         }
@@ -1698,6 +1748,26 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
         for (int off = 32; off > 0; off >>= 1) accd += __shfl_down(accd, off, 64);
         if ((tid & 63) == 0 && accd != 0.0) atomicAdd(a.change + grp * NS + l, accd);
         if ((tid & 63) == 0 && nevals && ((lm >> l) & 1)) atomicAdd(pa.evals + grp * NS + l, nevals);
+    }
+    return true;
+}
+
+// The sweep kernel: a workgroup takes work units (tickets) until none is left.  Units used to be one workgroup each; the
+// dispatcher then had to place a new workgroup whenever one retired -- in launch order, round-robin over the XCDs -- and
+// with units of very different length (exact skipping: 10 us to 700 us) 10-18 % of the workgroup slots stood empty
+// (unit trace, profiles/r03/unit_trace.txt).  Any ticket order that is a valid order for fresh workgroups is one for
+// resident ones: a workgroup only waits for units with lower tickets, and those are running or done.
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE = false>
+__global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeof(T) == 4) ? 3 : FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
+    // Nothing is to be carried from one unit to the next: the arguments are read again from the kernel argument segment
+    // through a pointer the compiler cannot see through (it would otherwise hoist everything that depends on them out of the
+    // loop and keep it in registers -- the march has none to spare), and so is the thread index inside the unit.
+    (void)pa;
+    for (;;) {
+        auto kp = __builtin_amdgcn_kernarg_segment_ptr();   // (constant address space)
+        asm volatile("" : "+s"(kp));
+        // (cast to a generic pointer in sight of the compiler: it still knows the loads are scalar loads of constant memory)
+        if (!fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE>(*(const PersistArgs<T>*)kp)) break;
     }
 }
 
