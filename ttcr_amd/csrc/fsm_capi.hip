@@ -523,9 +523,10 @@ class GridT : public GridBase {
         pa.n_sw_groups = n_groups();
         pa.n_sw_sweeps = sw_sweeps;
 
-        // workgroups take units until the tickets run out: no more of them than can be resident (8 per CU is more than any
-        // instantiation fits; the surplus finds the ticket counter exhausted).  TTCR_FSM_WGS=0: one workgroup per unit.
-        const size_t wg_cap = persist_wgs > 0 ? (size_t)persist_wgs : ~(size_t)0;
+        // first-order 3-D kernels: workgroups take units until the tickets run out -- no more of them than can be resident
+        // (8 per CU is more than any instantiation fits; the surplus finds the ticket counter exhausted).  The others (and
+        // TTCR_FSM_WGS=0, tuning): one workgroup per unit.
+        const size_t wg_cap = (fsm_looped(DIM == 3, H) && persist_wgs > 0) ? (size_t)persist_wgs : ~(size_t)0;
         const dim3 block(C::PJ * C::PK), grid((unsigned)std::min<size_t>((size_t)n_patches * batch, wg_cap));
         const int ndir = DIM == 3 ? 8 : 4;
         if (mode == 2) {

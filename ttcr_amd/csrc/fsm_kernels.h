@@ -767,9 +767,13 @@ __device__ __forceinline__ void st_sc1(Pack<double, 2>* p, Pack<double, 2> x) {
 // PRE = true: lane 0 samples the upwind progress counters one chunk ahead (see the wait at the top of the
 // chunk loop).  Pays off with several units in flight per patch position (64 sources: +3.8 %) and for the one-wave
 // 2-D patches (a single 4096^2 solve: +24 %); a lone 3-D source is 4 % better off without.
+// Which instantiations keep their workgroups for more than one unit: the first-order 3-D kernels (see fsm_sweep_persistent).
+__host__ __device__ constexpr bool fsm_looped(bool is3d, int h) { return is3d && h == 1; }
+
 // One work unit: the body of fsm_sweep_persistent below.  Returns false when the tickets of the launch have run out.
 template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE>
 __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
+    constexpr bool LOOPED = fsm_looped(IS3D, H);   // the workgroup comes back for another unit (see fsm_sweep_persistent)
     using P = Pack<T, NS>;
     constexpr int NT = PJ * PK;
     constexpr int RJ = PJ + 2 * H;
@@ -804,7 +808,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     __shared__ int s_u[U_N];
 
     int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));   // (see the loop in fsm_sweep_persistent)
+    if constexpr (LOOPED) asm volatile("" : "+v"(tid));   // (see the loop in fsm_sweep_persistent)
     // debug phase timers (FSM_ENABLE_PROF builds): thread 0 sums per phase in registers, one flush per unit
     unsigned long long prof_t = (FSM_ENABLE_PROF && a.prof) ? wall_clock64() : 0ull;
     unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
@@ -858,11 +862,11 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         if (ia >= ntj || ib >= ntk) return nullptr;
         return pa.sync + 2 + ((size_t)pd * pa.batch + z_) * pa.n_patches + ((tka + ib) * npj + tja + ia);
     };
-    __syncthreads();   // (the workgroup comes here once per unit: every read of the previous unit's shared state is over)
+    if constexpr (LOOPED) __syncthreads();   // (the workgroup comes here once per unit: every read of the previous unit's shared state is over)
     if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
-    if (tid == 1) s_abort = __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight together)
+    if (LOOPED && tid == 1) s_abort = __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight together)
     __syncthreads();
-    if (s_abort) return false;   // a unit timed out: the solve fails on the host, nobody takes another unit
+    if (LOOPED && s_abort) return false;   // a unit timed out: the solve fails on the host, nobody takes another unit
     const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
     // XS: `order` lists the units (direction, patch) of the whole iteration in ticket order -- any order in which a
     // unit comes after its upwind patches and after the patches of the previous sweep it has to see finished
@@ -1752,22 +1756,28 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     return true;
 }
 
-// The sweep kernel: a workgroup takes work units (tickets) until none is left.  Units used to be one workgroup each; the
-// dispatcher then had to place a new workgroup whenever one retired -- in launch order, round-robin over the XCDs -- and
-// with units of very different length (exact skipping: 10 us to 700 us) 10-18 % of the workgroup slots stood empty
-// (unit trace, profiles/r03/unit_trace.txt).  Any ticket order that is a valid order for fresh workgroups is one for
-// resident ones: a workgroup only waits for units with lower tickets, and those are running or done.
+// The sweep kernel.  First-order 3-D instantiations: a workgroup takes work units (tickets) until none is left.  Units used
+// to be one workgroup each; the dispatcher then had to place a new workgroup whenever one retired -- in launch order,
+// round-robin over the XCDs -- and with units of very different length (exact skipping: 10 us to 700 us) 10-18 % of the
+// workgroup slots stood empty (unit trace, profiles/r03/unit_trace.txt).  Any ticket order that is a valid order for fresh
+// workgroups is one for resident ones: a workgroup only waits for units with lower tickets, and those are running or done.
+// The WENO stage and the 2-D kernels keep one workgroup per unit: their units are long and alike, and the loop costs them
+// registers (WENO, one 256^3 source: 365 -> 406 ms looped; 2-D 4096^2 x 64: 17.6 -> 18.2 ms).
 template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE = false>
 __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeof(T) == 4) ? 3 : FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
-    // Nothing is to be carried from one unit to the next: the arguments are read again from the kernel argument segment
-    // through a pointer the compiler cannot see through (it would otherwise hoist everything that depends on them out of the
-    // loop and keep it in registers -- the march has none to spare), and so is the thread index inside the unit.
-    (void)pa;
-    for (;;) {
-        auto kp = __builtin_amdgcn_kernarg_segment_ptr();   // (constant address space)
-        asm volatile("" : "+s"(kp));
-        // (cast to a generic pointer in sight of the compiler: it still knows the loads are scalar loads of constant memory)
-        if (!fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE>(*(const PersistArgs<T>*)kp)) break;
+    if constexpr (fsm_looped(IS3D, H)) {
+        // Nothing is to be carried from one unit to the next: the arguments are read again from the kernel argument segment
+        // through a pointer the compiler cannot see through (it would otherwise hoist everything that depends on them out of
+        // the loop and keep it in registers -- the march has none to spare), and so is the thread index inside the unit.
+        (void)pa;
+        for (;;) {
+            auto kp = __builtin_amdgcn_kernarg_segment_ptr();   // (constant address space)
+            asm volatile("" : "+s"(kp));
+            // (cast to a generic pointer in sight of the compiler: it still knows the loads are scalar loads of constant memory)
+            if (!fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE>(*(const PersistArgs<T>*)kp)) break;
+        }
+    } else {
+        fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE>(pa);
     }
 }
 
