@@ -184,6 +184,11 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                     0: tri/bilinear interpolation (getTraveltime).  Default 0.
  *   "interp_vel"   1: the ray integration interpolates velocity instead of slowness (`intVel`
  *                     constructor argument / processVel, ttcr/Grid3Drn.h:2451-2676).  Default 0.
+ *   "pair_sources" 1 (default): the sources of a ttcr_fsm_raytrace_multi batch are paired by distance before they share
+ *                     the sweep kernel two by two (first-order 3-D grids): the field of the source the block distribution
+ *                     gives to thread t may then LIVE in another slot's storage, every entry point that takes a slot
+ *                     looks it up, and a caller sees what it would see without (same fields, iteration counts, receivers
+ *                     under the same thread numbers).  0: every source in the storage of its own thread number.
  *   "return_rays"  1: the raytrace calls follow the overloads with r_data (Grid3D::raytrace(Tx,t0,Rx,tt,
  *                     r_data,threadNo), ttcr/Grid3D.h:546-586): receiver traveltimes AND raypaths come from
  *                     Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) (ttcr/Grid3Drn.h:1339-1500); the rays

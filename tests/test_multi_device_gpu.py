@@ -113,3 +113,36 @@ def test_multi_device_2d_and_env(monkeypatch):
     monkeypatch.setenv("TTCR_AMD_DEVICES", "0,x")
     with pytest.raises(ValueError):
         ttcr_amd.Grid2d(x, z, n_threads=3, cell_slowness=0, method="FSM", dtype=np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", [1, 0])
+def test_paired_by_distance_sources_are_found_under_their_thread_numbers(oracle, pair):
+    """The batch driver pairs the sources of a call by distance (first-order 3-D grids): whatever slot storage a source ends
+    up in, its field, iteration count and change history are found under the thread number the block distribution gives it."""
+    import ttcr_amd
+    n = 33
+    x = np.arange(n) * 0.5
+    rng = np.random.default_rng(5)
+    s = rng.uniform(0.4, 1.0, (n, n, n)).astype(np.float32)
+    S = 7   # odd: one source stays without a partner
+    src = np.column_stack([np.zeros(S), rng.uniform(1.0, 15.0, (S, 3))])
+    src[3, 1:] = src[0, 1:] + 0.3   # 0 and 3 are each other's nearest neighbours: they share a pair when pairing is on
+    rcv = rng.uniform(0.5, 15.5, (S, 3))
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=S, cell_slowness=0, method='FSM', tt_from_rp=0, weno=0, dtype=np.float32)
+    g.set_slowness(s)
+    g.set_option('pair_sources', pair)
+    tt = g.raytrace(src, rcv)
+    for k in range(S):
+        o = oracle.solve3d(np.float32, (n - 1,) * 3, 0.5, (0, 0, 0), np.asfortranarray(s).ravel(order='F'), src[k:k + 1, 1:], rcv=rcv[k:k + 1])
+        np.testing.assert_array_equal(g.get_grid_traveltimes(k).ravel(order='F'), o['tt'])
+        assert g.get_niter(k) == o['niter']
+        assert tt[k] == o['tt_rcv'][0]
+    # a single-source call on a thread number afterwards lands in that thread's storage, wherever it is now
+    tt1 = g.raytrace(src[2:3], rcv[2:3], thread_no=5)
+    o = oracle.solve3d(np.float32, (n - 1,) * 3, 0.5, (0, 0, 0), np.asfortranarray(s).ravel(order='F'), src[2:3, 1:], rcv=rcv[2:3])
+    np.testing.assert_array_equal(g.get_grid_traveltimes(5).ravel(order='F'), o['tt'])
+    assert tt1[0] == o['tt_rcv'][0]
+    # ... and the other threads still hold what they held
+    o4 = oracle.solve3d(np.float32, (n - 1,) * 3, 0.5, (0, 0, 0), np.asfortranarray(s).ravel(order='F'), src[4:5, 1:])
+    np.testing.assert_array_equal(g.get_grid_traveltimes(4).ravel(order='F'), o4['tt'])

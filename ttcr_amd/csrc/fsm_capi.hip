@@ -124,11 +124,20 @@ class GridBase {
     int dim = 3, dtype = 0, n_slots = 1, device = 0;
     size_t n_nodes = 0, n_cells = 0;
     std::vector<int> niter, niterw;
+    // Where the field of (logical) slot s lives: phys[s].  A slot is what the caller's thread number names; the batch driver
+    // may give the sources of a call to other physical slots than the block distribution names (it pairs sources that lie
+    // close to each other, see raytrace_multi) and records here where each one went.  Always a permutation; everything
+    // inside the grid (solve_batch, the per-slot device arrays, niter, change_hist) is indexed by PHYSICAL slot, every entry
+    // point that takes a slot translates.
+    std::vector<int> phys;
+    int P(int slot) const { return phys.empty() ? slot : phys[slot]; }
+    int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
     // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
     // order stage then WENO stage
     std::vector<std::vector<double>> change_hist, change_histw;
     virtual void get_changes(int slot, double* first, int n_first, double* wen, int n_weno) const {
         if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
+        slot = P(slot);
         for (int q = 0; q < n_first; ++q) first[q] = (!change_hist.empty() && q < (int)change_hist[slot].size()) ? change_hist[slot][q] : 0.0;
         for (int q = 0; q < n_weno; ++q) wen[q] = (!change_histw.empty() && q < (int)change_histw[slot].size()) ? change_histw[slot][q] : 0.0;
     }
@@ -154,12 +163,13 @@ class GridBase {
         else if (k == "tt_from_rp") ttrp = value != 0;
         else if (k == "interp_vel") interp_vel = value != 0;
         else if (k == "return_rays") return_rays = value != 0;
+        else if (k == "pair_sources") pair_by_distance = value != 0;
         else throw ValueError("unknown option '" + k + "'");
     }
     virtual void get_niter(int slot, int* it, int* itw) const {
         if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
-        if (it) *it = niter[slot];
-        if (itw) *itw = niterw[slot];
+        if (it) *it = niter[P(slot)];
+        if (itw) *itw = niterw[P(slot)];
     }
 };
 
@@ -288,6 +298,8 @@ class GridT : public GridBase {
         n_slots = nslots;
         niter.assign(n_slots, 0);
         niterw.assign(n_slots, 0);
+        phys.resize(n_slots);
+        for (int q = 0; q < n_slots; ++q) phys[q] = q;
         max_batch = n_slots;
         device = dev;
         HIP_CHECK(hipSetDevice(device));
@@ -685,6 +697,7 @@ class GridT : public GridBase {
     void get_tt(int slot, void* out, size_t n) override {
         HIP_CHECK(hipSetDevice(device));
         check_slot(slot);
+        slot = P(slot);
         if (n != n_nodes) throw ValueError("traveltime buffer has wrong size");
         if (NS == 1) {
             HIP_CHECK(hipMemcpyAsync(out, tt_ptr(slot), n * sizeof(T), hipMemcpyDeviceToHost, stream));
@@ -703,6 +716,7 @@ class GridT : public GridBase {
     void* tt_device(int slot) override {
         HIP_CHECK(hipSetDevice(device));
         check_slot(slot);
+        slot = P(slot);
         if (NS == 1) return tt_ptr(slot);
         d_gather.reserve(n_nodes);
         const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
@@ -714,7 +728,7 @@ class GridT : public GridBase {
     void* tt_device_view(int slot, size_t* stride) override {
         check_slot(slot);
         if (stride) *stride = (size_t)NS;
-        return tt_ptr(slot);
+        return tt_ptr(P(slot));
     }
 
     void check_slot(int slot) const {
@@ -1153,7 +1167,7 @@ class GridT : public GridBase {
         if (translate)
             for (int m = 0; m < n; ++m) { p[3 * m] -= ox; p[3 * m + 1] -= oy; p[3 * m + 2] -= oz; }
         check_pts(p.data(), n);
-        interp_grid_coords(slot, n, p.data(), (T*)out);
+        interp_grid_coords(P(slot), n, p.data(), (T*)out);
     }
 
     // Grid3Drn::computeSlowness(pt, isTranslated) (ttcr/Grid3Drn.h:2451-2676), Grid2Drn::computeSlowness (ttcr/Grid2Drn.h:262-330)
@@ -1620,6 +1634,52 @@ class GridT : public GridBase {
         check_pts(rx.data(), n_rx);
     }
 
+    // Source pairs (NS == 2) share the control flow of the sweep kernel: with exact skipping a chunk is evaluated when EITHER
+    // source of the pair needs it, so two sources that lie close to each other -- whose fronts reach the same regions in the
+    // same sweeps -- cost fewer evaluations than two that do not (64 random sources on 512^3 nodes: 40.5 % -> 33.9 % of the
+    // node updates evaluated, 204 -> 175 ms of sweeps).  The results do not depend on who shares a pair with whom.  Within
+    // the batch (logical slots sl[b], sources sr[b]) the physical slots are handed out again: greedy nearest-neighbour pairs
+    // (first source point) go to the slot pairs the batch owns completely, the rest to its other slots; `phys` records it.
+    void pair_sources(const std::vector<int>& sl, const std::vector<int>& sr, const int* tx_off, const T* tx) {
+        const int nb = (int)sl.size();
+        if (NS != 2 || !pair_by_distance || nb < 3) return;
+        const int nc = ncoord();
+        std::vector<int> ps(nb);
+        for (int b = 0; b < nb; ++b) ps[b] = P(sl[b]);
+        std::sort(ps.begin(), ps.end());
+        std::vector<int> pair_slots, single_slots;   // physical slots of complete pairs (2g, 2g+1 both in the batch), the others
+        for (int b = 0; b < nb;) {
+            if (b + 1 < nb && (ps[b] & 1) == 0 && ps[b + 1] == ps[b] + 1) { pair_slots.push_back(ps[b]); pair_slots.push_back(ps[b + 1]); b += 2; }
+            else { single_slots.push_back(ps[b]); b += 1; }
+        }
+        if (pair_slots.empty()) return;
+        auto dist2 = [&](int a, int b) {
+            double d = 0;
+            for (int c = 0; c < nc; ++c) { const double v = (double)tx[(size_t)nc * tx_off[sr[a]] + c] - (double)tx[(size_t)nc * tx_off[sr[b]] + c]; d += v * v; }
+            return d;
+        };
+        std::vector<char> used(nb, 0);
+        std::vector<int> order;   // batch entries: pairs first, then what is left
+        order.reserve(nb);
+        int n_left = nb;
+        for (size_t k = 0; k + 1 < pair_slots.size(); k += 2) {
+            int a = 0;
+            while (used[a]) ++a;
+            used[a] = 1;
+            int best = -1;
+            double bd = 0;
+            for (int b = 0; b < nb; ++b)
+                if (!used[b]) { const double d = dist2(a, b); if (best < 0 || d < bd) { best = b; bd = d; } }
+            used[best] = 1;
+            order.push_back(a); order.push_back(best);
+            n_left -= 2;
+        }
+        for (int b = 0; b < nb && n_left > 0; ++b) if (!used[b]) { order.push_back(b); --n_left; }
+        std::vector<int> target(pair_slots);
+        target.insert(target.end(), single_slots.begin(), single_slots.end());
+        for (int k = 0; k < nb; ++k) phys[sl[order[k]]] = target[k];
+    }
+
     void raytrace_multi(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off,
                         const void* rx_v, void* tt_out_v, int forced_slot, const int* explicit_slots = nullptr,
                         bool force_rays = false) override {
@@ -1673,6 +1733,17 @@ class GridT : public GridBase {
             for (size_t c0 = 0; c0 < slots.size(); c0 += mb) {
                 const size_t c1 = std::min(slots.size(), c0 + mb);
                 std::vector<int> sl(slots.begin() + c0, slots.begin() + c1), sr(srcs.begin() + c0, srcs.begin() + c1);
+                // logical -> physical slots; the sources of a block-distributed batch are first paired by distance
+                if (forced_slot < 0 && !explicit_slots) pair_sources(sl, sr, tx_off, tx.data());
+                for (int& q : sl) q = P(q);
+                {   // (the batch driver takes its entries in ascending slot order)
+                    std::vector<int> idx(sl.size());
+                    for (size_t q = 0; q < idx.size(); ++q) idx[q] = (int)q;
+                    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return sl[a] < sl[b]; });
+                    std::vector<int> sl2(sl.size()), sr2(sr.size());
+                    for (size_t q = 0; q < idx.size(); ++q) { sl2[q] = sl[idx[q]]; sr2[q] = sr[idx[q]]; }
+                    sl.swap(sl2); sr.swap(sr2);
+                }
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
                 if (!(ttrp || return_rays)) {
                     interp_batch(sl, sr, rx_off, rx.data(), tt_out);
