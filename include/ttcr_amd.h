@@ -137,8 +137,9 @@ int ttcr_fsm_get_tt(ttcr_fsm_grid* g, int slot, void* out, size_t n);
  *   destruction of the grid.
  * ttcr_fsm_get_tt_device_view: zero copy.  *d_ptr addresses node 0 of the slot's field where it lies and *stride is
  *   the distance between consecutive nodes in ELEMENTS of the grid dtype -- 1, or 2 for the interleaved layout
- *   T[slot/2][node][2]: always take it from the call; valid until the next raytrace call on that slot.  Both stay
- *   owned by the grid. */
+ *   T[p/2][node][2], p = the storage the slot's field occupies (p = slot with option "pair_sources" = 0; otherwise a
+ *   multi-source call may have given the sources of its batch to each other's storage): always take pointer and stride
+ *   from the call; valid until the next raytrace call that solves a source for that slot.  Both stay owned by the grid. */
 int ttcr_fsm_get_tt_device(ttcr_fsm_grid* g, int slot, void** d_ptr);
 int ttcr_fsm_get_tt_device_view(ttcr_fsm_grid* g, int slot, void** d_ptr, size_t* stride);
 

@@ -630,9 +630,13 @@ def test_hip_device_views_of_a_field():
     sink = ttcr_amd.Grid3d(x, x, x, cell_slowness=0, method="FSM", dtype=np.float32)                 # nn values
     sink2 = ttcr_amd.Grid3d(np.arange(2 * n) * 0.5, x, x, cell_slowness=0, method="FSM", dtype=np.float32)   # 2 nn values
     # (one slot; three slots of a first-order grid: interleaved pairs; three slots with weno=1: one field per slot)
-    for nthr, weno, want_stride in ((1, 0, 1), (3, 0, 2), (3, 1, 1)):
+    # (pair: the sources of a call paired by distance -- a slot's field may lie in another slot's storage -- or not)
+    for nthr, weno, want_stride, pair in ((1, 0, 1, 1), (3, 0, 2, 1), (3, 0, 2, 0), (3, 1, 1, 1)):
         g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=weno, dtype=np.float32)
+        g.set_option("pair_sources", pair)
         srcs = rng.uniform(0.5, 9.0, (nthr, 3))
+        if pair and nthr == 3:
+            srcs[2] = srcs[0] + 0.2   # sources 0 and 2 end up in one pair
         g.raytrace(srcs, np.zeros((nthr, 3)), slowness=s)
         fields = [g._flat_tt(k) for k in range(nthr)]
         for slot in range(nthr):
@@ -643,7 +647,16 @@ def test_hip_device_views_of_a_field():
             if stride == 1:
                 sink.set_slowness_device(ptr, nn)                           # the view IS the contiguous field
                 np.testing.assert_array_equal(sink.get_slowness().flatten("F"), fields[slot])
-        if want_stride == 2:
+        if want_stride == 2 and pair:
+            p0, _ = g.tt_device_view(0)
+            p1, _ = g.tt_device_view(1)
+            p2, _ = g.tt_device_view(2)
+            assert abs(p2 - p0) == 4 and abs(p1 - min(p0, p2)) == 2 * nn * 4   # 0 and 2 interleaved, 1 in the next group
+            sink2.set_slowness_device(min(p0, p2), 2 * nn)
+            both = sink2.get_slowness().flatten("F").reshape(nn, 2)
+            np.testing.assert_array_equal(both[:, 0 if p0 < p2 else 1], fields[0])
+            np.testing.assert_array_equal(both[:, 1 if p0 < p2 else 0], fields[2])
+        if want_stride == 2 and not pair:
             p0, _ = g.tt_device_view(0)
             p1, _ = g.tt_device_view(1)
             p2, _ = g.tt_device_view(2)

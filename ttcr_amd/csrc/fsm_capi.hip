@@ -1734,7 +1734,9 @@ class GridT : public GridBase {
                 const size_t c1 = std::min(slots.size(), c0 + mb);
                 std::vector<int> sl(slots.begin() + c0, slots.begin() + c1), sr(srcs.begin() + c0, srcs.begin() + c1);
                 // logical -> physical slots; the sources of a block-distributed batch are first paired by distance
-                if (forced_slot < 0 && !explicit_slots) pair_sources(sl, sr, tx_off, tx.data());
+                // (also when the caller names the slots -- the replicas of a multi-device grid, single-source calls of several host
+                // threads that went to the device together: the permutation stays among the slots of the batch)
+                if (forced_slot < 0) pair_sources(sl, sr, tx_off, tx.data());
                 for (int& q : sl) q = P(q);
                 {   // (the batch driver takes its entries in ascending slot order)
                     std::vector<int> idx(sl.size());
