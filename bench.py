@@ -94,7 +94,8 @@ def cpu_baseline(n=256, n_src=3):
 
 
 KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,SKIP,1,2,true,true> (one launch per sweep-iteration; SKIP: template flag of "
-                "the build with the exact-skipping scheduler, the default from two slot groups on)",
+                "the build with the exact-skipping scheduler, the default from two slot groups on; two sources per workgroup, the "
+                "sources of a call paired by distance; workgroups draw work units from a ticket counter until none is left)",
            "1": "fsm_sweep_persistent<float,16,16,8,true,SKIP,1,2,false,false> (one launch per directional sweep)",
            "0": "fsm_sweep_tile<float,16,16,16,true> (one launch per tile wavefront)"}
 PROFILE_DIRS = ("r03", "r02")
