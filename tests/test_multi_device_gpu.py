@@ -146,3 +146,15 @@ def test_paired_by_distance_sources_are_found_under_their_thread_numbers(oracle,
     # ... and the other threads still hold what they held
     o4 = oracle.solve3d(np.float32, (n - 1,) * 3, 0.5, (0, 0, 0), np.asfortranarray(s).ravel(order='F'), src[4:5, 1:])
     np.testing.assert_array_equal(g.get_grid_traveltimes(4).ravel(order='F'), o4['tt'])
+
+
+def test_slot_map_fuzz_short():
+    """scripts/fuzz_pairing.py for a few seconds: random grids, slot and source counts (several rounds), max_batch, single-source
+    calls on thread numbers in between -- pairing by distance on against off"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pairing.py"), "8", "17"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz_pairing:" in r.stdout and " 0 random" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
