@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-source", action="store_true", help="skip the 1-source leg of the N=1 run")
     ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="key=value handed to ttcr_fsm_set_option (tuning / bisecting)")
+    ap.add_argument("--per-step", action="store_true", help="print launches / evaluated updates of every timed step to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to "
                     "exercise the multi-rank path on a single-GPU box)")
     args = ap.parse_args()
@@ -229,6 +231,9 @@ def main():
                            dtype=np.float32, device=local_rank)
     if args.max_batch > 0:
         grid.set_option("max_batch", args.max_batch)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        grid.set_option(k_, float(v_))
 
     # slowness: generated on rank 0 in HBM, broadcast over RCCL/xGMI, handed over as a device pointer
     s_dev = torch.empty(n * n * n, dtype=torch.float32, device=dev)
@@ -283,15 +288,23 @@ def main():
     launches = 0
     node_iters = 0
     evaluated = 0
+    step_launches, step_niter = [], []
     for _ in range(args.steps):
         tt, tm = step()
         sweep_ms += tm["sweep_ms"]
         launches += tm["kernel_launches"]
         node_iters += tm["node_updates"] // 8
         evaluated += tm["evaluated_updates"]
+        step_launches.append(int(tm["kernel_launches"]))
+        step_niter.append(tuple(grid.get_niter(i) for i in range(S)))   # (a few microseconds: host-side counters)
+        if args.per_step:
+            sys.stderr.write(f"step {len(step_launches) - 1}: launches {step_launches[-1]} evaluated {tm['evaluated_updates'] / n ** 3:.3f} N "
+                             f"sweep_ms {tm['sweep_ms']:.2f} niter {sorted(set(step_niter[-1]))}\n")
     fence()
     el = time.perf_counter() - t0
-    iters_per_src = [grid.get_niter(i) for i in range(S)]
+    iters_per_src = list(step_niter[-1])
+    # every timed step solves the same sources on the same model: launch count and iteration counts must not move
+    odd_steps = [k for k in range(args.steps) if step_launches[k] != step_launches[0] or step_niter[k] != step_niter[0]]
 
     stats = torch.tensor([el, sweep_ms, float(node_iters), float(launches)], dtype=torch.float64, device=cdev)
     per_rank = [(S, el)]
@@ -342,6 +355,8 @@ def main():
                        "sources_per_rank": [p[0] for p in per_rank],
                        "sources_per_s_per_rank": [round(p[0] * args.steps / p[1], 3) for p in per_rank],
                        "sweep_iterations_per_source": sorted(set(iters_per_src)),
+                       "launches_per_step": sorted(set(step_launches)),
+                       "steps_that_differ_from_the_first": odd_steps,
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, all_gather of receiver traveltimes)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -395,6 +410,12 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if odd_steps:
+        for k in odd_steps[:8]:
+            w = [i for i in range(S) if step_niter[k][i] != step_niter[0][i]]
+            sys.stderr.write(f"rank {rank}: step {k}: {step_launches[k]} launches (step 0: {step_launches[0]}), niter differs in slots "
+                             f"{w}: {[step_niter[k][i] for i in w]} vs {[step_niter[0][i] for i in w]}\n")
+        raise SystemExit(f"bench.py: {len(odd_steps)} of {args.steps} timed steps differ from the first in launch or iteration count")
 
 
 if __name__ == "__main__":

@@ -156,7 +156,7 @@ class GridBase {
     virtual void apply_option(const std::string& k, double value) {
         if (k == "fixed_iters") fixed_iters = (int)value;
         else if (k == "max_batch") max_batch = (int)value;
-        else if (k == "use_graph") use_graph = value != 0;
+        else if (k == "use_graph") use_graph = (int)value;
         else if (k == "combine_window_us") combine_window_us = (int)value;
         else if (k == "mode") mode = (int)value;
         else if (k == "skip") skip = (int)value;
@@ -242,13 +242,16 @@ class GridT : public GridBase {
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
     DevBuf<int> d_stamp;       // dirty-brick stamps [n_slots][nbf*nbj*nbk]
-    DevBuf<unsigned> d_cmap;   // SKIP kernels: per-chunk edge-change flags of every unit of a launch [dir][entry][patch][2][cmap_words]
+    DevBuf<unsigned long long> d_cmap;   // SKIP kernels: per-chunk edge-change flags of every unit of a launch [dir][entry][patch][2][cmap_words]
     int cmap_words = 1;
     DevBuf<unsigned long long> d_sw;   // SKIP kernels: per (global sweep, slot group) units finished | units that changed a node
     int sw_sweeps = 0;
     DevBuf<int> d_iter;        // current iteration index (read by the captured kernels)
     DevBuf<unsigned long long> d_evals;  // [n_slots] node updates actually evaluated
-    int* h_iter = nullptr;     // pinned
+    int* h_iter = nullptr;     // pinned: [0] iteration index, [1] launch epoch
+    unsigned launch_epoch = 1;  // number of the next sweep launch of this grid (0: never -- what zeroed memory reads as)
+    bool sync_clean = true;     // the last solve ended normally (else the synchronisation words are wiped before the next one)
+    size_t sync_words = 0;
     unsigned long long* h_evals = nullptr;  // pinned
     int nbf = 0, nbj = 0, nbk = 0;
     size_t n_bricks = 0;
@@ -336,7 +339,7 @@ class GridT : public GridBase {
         HIP_CHECK(hipHostMalloc((void**)&h_slots, sizeof(int) * n_slots));
         HIP_CHECK(hipHostMalloc((void**)&h_abort, sizeof(int)));
         *h_abort = 0;
-        HIP_CHECK(hipHostMalloc((void**)&h_iter, sizeof(int)));
+        HIP_CHECK(hipHostMalloc((void**)&h_iter, 2 * sizeof(int)));
         HIP_CHECK(hipHostMalloc((void**)&h_evals, sizeof(unsigned long long) * n_slots));
         HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_groups() * NS * sizeof(T), stream));
 
@@ -374,11 +377,12 @@ class GridT : public GridBase {
             const int max_chunks = (geom.NF + 2 * (PJ + PK)) / 4 + 4;
             cmap_words = max_chunks / 32 + 1;
             d_cmap.reserve((size_t)n_patches * n_slots * (dim == 3 ? 8 : 4) * 2 * cmap_words);
+            HIP_CHECK(hipMemset(d_cmap.p, 0, (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4) * 2 * cmap_words * sizeof(unsigned long long)));
             // whole-sweep tallies: one entry per sweep of a solve (both stages); solves with more sweeps simply stop using them
             sw_sweeps = (dim == 3 ? 8 : 4) * (2 * std::min(nitermax, 256) + 2);
             d_sw.reserve((size_t)sw_sweeps * n_groups());
         }
-        d_iter.reserve(1);
+        d_iter.reserve(2);
         d_evals.reserve(n_slots);
         if (dim == 2)   // the row-parallel sweep45 kernel keeps four rows in (dynamic) LDS
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fsm_sweep45_rows<T>),
@@ -405,7 +409,11 @@ class GridT : public GridBase {
         n_patches = (int)order.size();
         d_order.reserve(order.size());
         HIP_CHECK(hipMemcpy(d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        d_sync.reserve(2 + (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4));
+        // four ticket counters, the abort word, then one progress word per (direction, slot, patch).  The kernels tag every
+        // word with the launch epoch: nothing is reset between the launches of a solve (fsm_kernels.h, "launch epoch")
+        sync_words = 8 + (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4);
+        d_sync.reserve(sync_words);
+        HIP_CHECK(hipMemset(d_sync.p, 0, sync_words * sizeof(int)));
         if (geom.npj >= (1 << 14) || geom.npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
         for (int st = 0; st < 2; ++st)
             for (int tm = 0; tm < 2; ++tm) {
@@ -531,7 +539,7 @@ class GridT : public GridBase {
         pa.skip = skip_now(batch) ? (std::getenv("TTCR_FSM_SKIP_ALL_DIRTY") ? 2 : 1) : 0;
         pa.cmap = d_cmap.p;
         pa.cw = cmap_words;
-        pa.sw = d_sw.p;
+        pa.sw = std::getenv("TTCR_FSM_NO_SW") ? nullptr : d_sw.p;   // (tuning / bisecting: no whole-sweep shortcut)
         pa.n_sw_groups = n_groups();
         pa.n_sw_sweeps = sw_sweeps;
 
@@ -551,9 +559,6 @@ class GridT : public GridBase {
             pa.timeout_ticks = 1000000000ull;  // 10 s: a unit may wait for most of the previous sweep
             const dim3 gridx((unsigned)std::min<size_t>((size_t)n_patches * batch * ndir, wg_cap));
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
-            HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
-            HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch * ndir, stream));
-            if (skip_now(batch)) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * ndir * 2 * cmap_words, stream));
             const bool pre = DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0;   // counters sampled one chunk ahead (template PRE)
             if (skip_now(batch) && pre)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
@@ -582,10 +587,8 @@ class GridT : public GridBase {
             }
             a.s_sheared = d_ssh.p + (size_t)fam * ssh_stride;
             pa.dir = d;
-            // ticket + progress counters back to zero (the abort word [1] is sticky within an iteration)
-            HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sizeof(int), stream));
-            HIP_CHECK(hipMemsetAsync(d_sync.p + 2, 0, sizeof(int) * (size_t)n_patches * batch, stream));
-            if (skip_now(batch)) HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, sizeof(unsigned) * (size_t)n_patches * batch * 2 * cmap_words, stream));
+            // (no reset of tickets, progress words or change maps: launch epoch pa.iter_ptr[1] + d; the abort word is sticky
+            // within an iteration)
             if (skip_now(batch))
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, false><<<grid, block, 0, stream>>>(pa);
             else
@@ -953,7 +956,7 @@ class GridT : public GridBase {
 
     void run_iteration(int batch) {
         const int ndir = dim == 3 ? 8 : 4;
-        if (use_graph) {
+        if (use_graph >= 2 || (use_graph == 1 && !persistent_now())) {
             hipGraph_t& graph = graphs[stage];
             hipGraphExec_t& graph_exec = graph_execs[stage];
             const int key = mode * 2 + (skip_now(batch) ? 1 : 0);
@@ -1053,7 +1056,17 @@ class GridT : public GridBase {
         // the change reset (:104-136).  A source that converges leaves the batch (slot -1).
         const int maxit = fixed_iters > 0 ? fixed_iters : nitermax;
         const int ndir = dim == 3 ? 8 : 4;
-        if (persistent_now() || weno) HIP_CHECK(hipMemsetAsync(d_sync.p, 0, 2 * sizeof(int), stream));
+        if (!sync_clean || launch_epoch > 0xfffff000u) {   // a solve that did not end normally (or 2^32 launches): start over
+            HIP_CHECK(hipMemsetAsync(d_sync.p, 0, sync_words * sizeof(int), stream));
+            HIP_CHECK(hipMemsetAsync(d_cmap.p, 0, (size_t)n_patches * n_slots * ndir * 2 * cmap_words * sizeof(unsigned long long), stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            launch_epoch = 1;
+        }
+        sync_clean = false;
+        // progress words: wiped once per solve (an ordinary stream operation, like the fills above); between the launches of
+        // the solve the 2-bit epoch field tells this launch's values from the previous launch's
+        if (persistent_now() || weno) HIP_CHECK(hipMemsetAsync(d_sync.p + 8, 0, (sync_words - 8) * sizeof(int), stream));
+        if (persistent_now() || weno) HIP_CHECK(hipMemsetAsync(d_sync.p + 4, 0, sizeof(int), stream));
         HIP_CHECK(hipMemsetAsync(d_evals.p, 0, sizeof(unsigned long long) * n_slots, stream));
         HIP_CHECK(hipMemsetAsync(d_sw.p, 0, sizeof(unsigned long long) * (size_t)sw_sweeps * n_groups(), stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
@@ -1083,14 +1096,16 @@ class GridT : public GridBase {
                 HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemcpyAsync(d_lmask.p, h_lmask, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
-                *h_iter = it_total;
-                HIP_CHECK(hipMemcpyAsync(d_iter.p, h_iter, sizeof(int), hipMemcpyHostToDevice, stream));
+                h_iter[0] = it_total;
+                h_iter[1] = (int)launch_epoch;   // epoch of this iteration's (first) sweep launch
+                launch_epoch += (persistent_now() && mode == 2) ? 1u : (unsigned)ndir;
+                HIP_CHECK(hipMemcpyAsync(d_iter.p, h_iter, 2 * sizeof(int), hipMemcpyHostToDevice, stream));
                 run_iteration(n_entries);
                 HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
-                if (persistent_now()) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+                if (persistent_now()) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 4, sizeof(int), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
                 if (persistent_now() && *h_abort) {
-                    HIP_CHECK(hipMemsetAsync(d_sync.p + 1, 0, sizeof(int), stream));
+                    HIP_CHECK(hipMemsetAsync(d_sync.p + 4, 0, sizeof(int), stream));
                     stage = 0;
                     throw DeviceError("persistent sweep kernel: a patch timed out waiting for its upwind neighbour");
                 }
@@ -1125,6 +1140,7 @@ class GridT : public GridBase {
         }
         const bool was_persistent = mode >= 1 || weno;
         stage = 0;
+        sync_clean = true;
         HIP_CHECK(hipEventRecord(ev1, stream));
         HIP_CHECK(hipEventSynchronize(ev1));
         if (d_prof.p) {

@@ -523,18 +523,19 @@ struct PersistArgs {
     SweepArgs<T> s;           // w, tiles unused
     const uint32_t* order;    // ticket order.  One launch per sweep: patches (TJ | TK<<16) by anti-diagonal m = TJ+TK;
                               // whole-iteration launch (XS): units (TJ | TK<<14 | dir<<28) of all directions
-    int* sync;                // [0]: ticket counter, [1]: abort flag, [2 + z*n_patches + patch]: progress
+    int* sync;                // [0..3]: ticket counters (launch seq & 3), [4]: abort flag, from [8] on the progress words
+                              // ((1 + seq % 3) << 30 | value) per (direction,) batch entry and patch
     int n_patches, batch;
     unsigned long long timeout_ticks;  // 100 MHz wall-clock ticks
     // dirty-brick tracking (exact skipping of chunks that cannot change anything)
     int* stamp;               // [n_slots][nbf*nbj*nbk] global sweep number of the last change in a brick, -1: never
-    const int* iter_ptr;      // device word: index of the current iteration
+    const int* iter_ptr;      // device words: [0] index of the current iteration, [1] launch epoch of its (first) sweep launch
     unsigned long long* evals;  // [n_slots] node updates actually evaluated
     int nbf, nbj, nbk;        // bricks of FSM_BRICK^3 nodes (natural coordinates)
     int dir, ndir;            // direction index within the iteration, directions per iteration
     int skip;                 // 0: evaluate every chunk
     // exact skipping (SKIP kernels), see "scheduler" in fsm_sweep_persistent
-    unsigned* cmap;           // [unit][2][cw] per-chunk change flags of a unit's J-edge / K-edge columns (zeroed per launch)
+    unsigned long long* cmap; // [unit][2][cw] per-chunk change flags of a unit's J-edge / K-edge columns: (launch epoch << 32) | 32 flag bits
     int cw;                   // words per edge and unit
     unsigned long long* sw;   // [global sweep number][n_sw_groups]: units finished (low 32) | units that changed a node (high 32);
                               // zeroed per solve; nullptr: no whole-sweep shortcut
@@ -693,7 +694,7 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
 #endif
 // SKIP kernels publish progress as (levels << 8) | change flags of the last four chunks (two bits each: J-edge, K-edge columns);
 // a finished unit publishes FSM_FIN | (ever changed its J edge) | (ever changed its K edge) << 1
-#define FSM_FIN 0x7ffffff0
+#define FSM_FIN 0x3ffffff0
 #ifndef FSM_SKIP_ABL
 #define FSM_SKIP_ABL 0   // tuning builds: leave parts of the skip bookkeeping out (wrong results unless every brick is dirty)
 #endif
@@ -789,6 +790,34 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     constexpr int NUPI = (NUP + RPI - 1) / RPI;  // passes over the upwind halo columns
     static_assert(NT % C == 0 && (IS3D || PK == 1) && C <= FSM_BRICK && (H == 1 || H == 2), "tile shape");
     const SweepArgs<T>& a = pa.s;
+    // Launch epoch.  Nothing the kernel synchronises on is reset between the launches of a solve: every word carries the number
+    // of the launch that wrote it, and a word of another launch reads as "nothing published" -- what a word held before (the
+    // final values of the previous launch) can never be taken for this launch's progress, whatever the order in which a
+    // reset would have become visible.  (Round 4: under the HIP runtime that PyTorch bundles, replays of a hipGraph with
+    // memset nodes in front of the kernel node let the kernel work with the words of the previous launch once the process
+    // had called hipDeviceSynchronize() -- profiles/r04/niter_root_cause.txt.)
+    //   * progress words: 32 bits, (e2 << 30) | value with e2 = 1 + seq % 3 -- every word of a launch is rewritten by the
+    //     next one (each unit publishes a final value), so within a solve a stale word is exactly one launch old; the host
+    //     wipes them once per solve with an ordinary stream memset (zero reads as epoch 0: never);
+    //   * change maps: 64 bits, (seq << 32) | 32 flag bits -- a unit only writes the words it sets a bit in, the rest
+    //     may be of any age;
+    //   * ticket counters: four, launch seq draws from counter seq & 3 and whoever draws ticket 0 zeroes counter (seq + 2) & 3.
+    // One launch per directional sweep: one seq per sweep.
+    const unsigned epoch = (unsigned)pa.iter_ptr[1] + (XS ? 0u : (unsigned)pa.dir);
+    const int e2 = (int)(epoch % 3u) + 1;
+    auto dec_prog = [&](int raw_) -> int { return (int)((unsigned)raw_ >> 30) == e2 ? (raw_ & 0x3fffffff) : 0; };
+    auto ld_raw = [&](const int* p_) -> int { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld_prog = [&](const int* p_) -> int { return dec_prog(ld_raw(p_)); };
+    auto st_prog = [&](int* p_, int v_) {
+        __hip_atomic_store(p_, (int)(((unsigned)e2 << 30) | (unsigned)v_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto ld_cmap = [&](const unsigned long long* p_) -> unsigned {
+        const unsigned long long v_ = __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned)(v_ >> 32) == epoch ? (unsigned)v_ : 0u;
+    };
+    auto st_cmap = [&](unsigned long long* p_, unsigned v_) {
+        __hip_atomic_store(p_, ((unsigned long long)epoch << 32) | v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
 
     __shared__ P Tt[NROWS * RS];
     __shared__ int s_ticket, s_abort;
@@ -860,11 +889,16 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         const int tka = IS3D ? ka2 / PK : 0, ntk = IS3D ? kb2 / PK - tka + 1 : 1;
         const int ia = lane & 3, ib = lane >> 2;
         if (ia >= ntj || ib >= ntk) return nullptr;
-        return pa.sync + 2 + ((size_t)pd * pa.batch + z_) * pa.n_patches + ((tka + ib) * npj + tja + ia);
+        return pa.sync + 8 + ((size_t)pd * pa.batch + z_) * pa.n_patches + ((tka + ib) * npj + tja + ia);
     };
     if constexpr (LOOPED) __syncthreads();   // (the workgroup comes here once per unit: every read of the previous unit's shared state is over)
-    if (tid == 0) s_ticket = atomicAdd(pa.sync, 1);
-    if (LOOPED && tid == 1) s_abort = __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight together)
+    if (tid == 0) {
+        const int t_ = atomicAdd(pa.sync + (epoch & 3u), 1);
+        // (the counter the launch after the next one draws from: no launch is using it now)
+        if (t_ == 0) __hip_atomic_store(pa.sync + ((epoch + 2u) & 3u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ticket = t_;
+    }
+    if (LOOPED && tid == 1) s_abort = __hip_atomic_load(pa.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (in flight together)
     __syncthreads();
     if (LOOPED && s_abort) return false;   // a unit timed out: the solve fails on the host, nobody takes another unit
     const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
@@ -876,7 +910,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     const uint32_t tile = pa.order[oidx];
     const int dir = XS ? (int)(tile >> 28) : pa.dir;
     const int TJ = XS ? (int)(tile & 0x3fffu) : (int)(tile & 0xffffu), TK = XS ? (int)((tile >> 14) & 0x3fffu) : (int)(tile >> 16);
-    int* prog = pa.sync + 2 + ((size_t)(XS ? dir : 0) * pa.batch + z) * pa.n_patches;
+    int* prog = pa.sync + 8 + ((size_t)(XS ? dir : 0) * pa.batch + z) * pa.n_patches;
     int* my_prog = prog + (TK * npj + TJ);
     // sweep direction: 3-D bits (F, J, K); 2-D order (+x+z, -x+z, -x-z, +x-z) with J = x, F = z
     int rf, rj, rk, rev;
@@ -899,7 +933,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     }
     const int grp = a.slots[z];   // slot (NS == 1) or slot group (NS == 2)
     if (grp < 0) {  // converged source(s): nothing to do, but never leave a waiter hanging
-        if (tid == 0) __hip_atomic_store(my_prog, SKIP ? FSM_FIN : 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) st_prog(my_prog, SKIP ? FSM_FIN : 0x3fffffff);
         return true;
     }
     // SKIP: when the previous sweep (of this source group) has finished every patch and changed no node, this sweep cannot
@@ -915,7 +949,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             __syncthreads();
             if (s_act) {
                 if (tid == 0) {
-                    __hip_atomic_store(my_prog, FSM_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    st_prog(my_prog, FSM_FIN);
                     atomicAdd(pa.sw + (size_t)sigma0 * pa.n_sw_groups + grp, 1ull);
                     if (FSM_ENABLE_PROF && a.prof && ticket < FSM_TRACE_UNITS) {
                         unsigned long long* tr = a.prof + 8 + 4 * (size_t)ticket;
@@ -957,7 +991,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         if (tid - 1 < ntj) {
             const int q = tja + tid - 1;
             const int qmax = (q * PJ + PJ < NJ ? q * PJ + PJ : NJ) - 1;
-            chase_ptr = pa.sync + 2 + ((size_t)(dir - 1) * pa.batch + z) * pa.n_patches + q;
+            chase_ptr = pa.sync + 8 + ((size_t)(dir - 1) * pa.batch + z) * pa.n_patches + q;
             chase_add = qmax + 3 * H + C + 1;
         }
     }
@@ -973,13 +1007,13 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             unsigned long long t0 = 0;
             int spins = 0;
             for (;;) {
-                if (!ok) ok = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+                if (!ok) ok = ld_prog(wp) >= need;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                 if (spins == 0) t0 = wall_clock64();
                 if ((++spins & 63) == 0) {
-                    if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (__hip_atomic_load(pa.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                     if (wall_clock64() - t0 > pa.timeout_ticks) {
-                        if (tid == 0) __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (tid == 0) __hip_atomic_store(pa.sync + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
@@ -1178,6 +1212,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     int pending = 0;            // progress value of the previous chunk, published once its stores have drained
     int n_done = 0;             // chunks of this unit evaluated so far
     int pre_j = -1, pre_k = -1; // upwind progress counters as sampled during the previous chunk (first lane of every wave)
+    int smp_j = 0, smp_k = 0;   // ... the sampled words as loaded (epoch field and all)
     P uvn[NUPI];                // upwind halo columns fetched one chunk ahead ...
     int uvn_for = -(1 << 30);   // ... for the chunk that starts at this level
     // Chunks that may hold frozen nodes of source l: the patch overlaps the bounding box of the frozen nodes in
@@ -1204,11 +1239,11 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             if (pp) {
                 const unsigned long long t0 = wall_clock64();
                 int spins = 0;
-                while (__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (SKIP ? FSM_FIN : 0x3fffffff)) {
+                while (ld_prog(pp) < (SKIP ? FSM_FIN : 0x3fffffff)) {
                     if ((++spins & 63) == 0) {
-                        if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        if (__hip_atomic_load(pa.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                         if (wall_clock64() - t0 > pa.timeout_ticks) {
-                            __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(pa.sync + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                     }
@@ -1272,7 +1307,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     // (DESIGN.md section 4a): the scheduler steps over it and publishes the progress, a run of such chunks costs one pass
     // of a scalar loop, and the workgroup only synchronises where a chunk has to be evaluated.
     // change map of unit (patch index pidx) of this launch, edge e
-    auto cmap_of = [&](int pidx, int e) -> unsigned* {
+    auto cmap_of = [&](int pidx, int e) -> unsigned long long* {
         return pa.cmap + ((((size_t)(XS ? dir : 0) * pa.batch + z) * pa.n_patches + (size_t)pidx) * 2 + e) * pa.cw;
     };
     // any brick of the slab mask set within the natural F range [flo, fhi]
@@ -1312,8 +1347,8 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
                 if (s_cwi[e] != w || s_cwl[e] < nd) {
                     // (the word is read after the progress value that makes its bits final was seen)
                     s_cwl[e] = v >= FSM_FIN ? 0x7fffffff : (v >> 8);
-                    const unsigned* um = cmap_of(e == 0 ? TK * npj + TJ - 1 : (TK - 1) * npj + TJ, e);
-                    s_cwv[e] = __hip_atomic_load(um + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long* um = cmap_of(e == 0 ? TK * npj + TJ - 1 : (TK - 1) * npj + TJ, e);
+                    s_cwv[e] = ld_cmap(um + w);
                     s_cwi[e] = w;
                 }
                 bit = (s_cwv[e] >> (ciu & 31)) & 1u;
@@ -1327,16 +1362,16 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         unsigned long long t0 = 0;
         int spins = 0;
         for (;;) {
-            const int v = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int v = ld_prog(ptr);
             if (v >= want) {
                 if (FSM_ENABLE_PROF == 2 && spins) twait += wall_clock64() - t0;
                 return v;
             }
             if (spins == 0) t0 = wall_clock64();
             if ((++spins & 63) == 0) {
-                if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; return v; }
+                if (__hip_atomic_load(pa.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; return v; }
                 if (wall_clock64() - t0 > pa.timeout_ticks) {
-                    __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pa.sync + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = false;
                     return v;
                 }
@@ -1345,6 +1380,11 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         }
     };
     for (; Lc <= Le; Lc += C) {
+        if constexpr (PRE) {   // samples taken during the previous chunk (progress only grows: never below what is known already)
+            // (taken after anything the scheduler polled in that chunk, so they are the newest values this lane has seen)
+            pre_j = dec_prog(smp_j);
+            pre_k = dec_prog(smp_k);
+        }
         if constexpr (SKIP) {
             FSM_PMARK(0)
             if (tid == 0) {
@@ -1377,7 +1417,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
                         bool any = false;
                         for (int w = 0; w < ((pa.nbf + 31) >> 5); ++w) any |= s_slab[w] != 0u;
                         if (!any) {
-                            __hip_atomic_store(my_prog, FSM_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            st_prog(my_prog, FSM_FIN);
                             L = Le + 1;
                             act = 0;
                             break;
@@ -1395,7 +1435,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
                     if (L > Le && s_u[U_UCHG]) {
                         s_u[U_PENDV] = FSM_FIN | s_u[U_EVER];   // (goes out after the unit's stamps, below the loop)
                     } else {
-                        __hip_atomic_store(my_prog, L > Le ? (FSM_FIN | s_u[U_EVER]) : ((L << 8) | h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        st_prog(my_prog, L > Le ? (FSM_FIN | s_u[U_EVER]) : ((L << 8) | h));
                     }
                 }
                 s_u[U_HIST] = h;
@@ -1411,7 +1451,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             if (act == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) __hip_atomic_store(my_prog, s_u[U_PENDV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) st_prog(my_prog, s_u[U_PENDV]);
                 pending = 0;
                 Lc -= C;   // (the loop header adds it back: the scheduler runs again from the same chunk)
                 continue;
@@ -1435,14 +1475,14 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             unsigned long long t0 = 0;   // the clock is only read once a poll has failed (the common case: none does)
             int spins = 0;
             for (;;) {
-                const int vj = up_j ? __hip_atomic_load(up_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-                const int vk = up_k ? __hip_atomic_load(up_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                const int vj = up_j ? ld_prog(up_j) : need;
+                const int vk = up_k ? ld_prog(up_k) : need;
                 if (vj >= need && vk >= need) break;
                 if (spins == 0) t0 = wall_clock64();
                 if ((++spins & 63) == 0) {
-                    if (__hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (__hip_atomic_load(pa.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                     if (wall_clock64() - t0 > pa.timeout_ticks) {
-                        __hip_atomic_store(pa.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pa.sync + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
@@ -1506,7 +1546,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             if (ulrow[it] >= 0) Tt[ulrow[it]] = uv[it];
         if (H == 2 && xlrow >= 0) Tt[xlrow] = xv;
         __syncthreads();
-        if (tid == 0 && pending) __hip_atomic_store(my_prog, SKIP ? s_u[U_PENDV] : pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && pending) st_prog(my_prog, SKIP ? s_u[U_PENDV] : pending);
         pending = 0;
         // sample the upwind counters for the NEXT chunk now: the loads complete during the march (counters only
         // grow, an old sample is a safe lower bound)
@@ -1528,11 +1568,12 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             }
         }
         if (PRE && (tid & 63) == 0 && Lc + C <= Le) {
-            if (up_j) pre_j = __hip_atomic_load(up_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (up_k) pre_k = __hip_atomic_load(up_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (raw words: they are decoded at the top of the next chunk, when the loads have long landed)
+            if (up_j) smp_j = ld_raw(up_j);
+            if (up_k) smp_k = ld_raw(up_k);
         }
         if (PRE && CHASE_OK && chase_ptr && Lc + C <= Le)   // lanes 1..3 of a chasing unit: their patch of the previous sweep
-            pre_j = __hip_atomic_load(chase_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            smp_j = ld_raw(chase_ptr);
 
         bool near_src[NS];
 #pragma unroll
@@ -1664,7 +1705,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
                         for (int e2 = 0; e2 < 2; ++e2)
                             if (chg_flags & (2 << e2)) {
                                 s_mywv[e2] |= 1u << (ci & 31);
-                                __hip_atomic_store(cmap_of(TK * npj + TJ, e2) + w, s_mywv[e2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                st_cmap(cmap_of(TK * npj + TJ, e2) + w, s_mywv[e2]);
                             }
                     }
                     s_u[U_UCHG] = 1;
@@ -1685,7 +1726,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             // exactly these levels): publish at once instead of at the next staging barrier
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(my_prog, SKIP ? s_u[U_PENDV] : pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) st_prog(my_prog, SKIP ? s_u[U_PENDV] : pending);
             pending = 0;
         }
         ++n_done;
@@ -1711,7 +1752,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     if (pending) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(my_prog, SKIP ? s_u[U_PENDV] : pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) st_prog(my_prog, SKIP ? s_u[U_PENDV] : pending);
     }
     if constexpr (SKIP) {   // this sweep's tally for the whole-sweep shortcut of the next one
         const int sigma0 = pa.ndir * pa.iter_ptr[0] + dir;
