@@ -16,7 +16,7 @@ tot=collections.defaultdict(collections.Counter); n=collections.defaultdict(coll
 for f in glob.glob("$RAW/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r.get("Kernel_Name","?")
-        if "fsm_sweep_persistent" in k: tot[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k][r["Counter_Name"]]+=1
+        if "fsm_sweep" in k: tot[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k][r["Counter_Name"]]+=1
 for k,v in tot.items():
     print(k, "dispatches", max(n[k].values()))
     for c, x in sorted(v.items()): print("   %-24s %.6g" % (c, x))

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libttcr_amd.so")
 SOURCES = ["fsm_capi.hip"]
-DEPS = ["fsm_capi.hip", "fsm_kernels.h", "fsm_march_levels.inc", os.path.join("..", "..", "include", "ttcr_amd.h")]
+DEPS = ["fsm_capi.hip", "fsm_kernels.h", "fsm_wave_kernels.h", "fsm_march_levels.inc", os.path.join("..", "..", "include", "ttcr_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result"]
 

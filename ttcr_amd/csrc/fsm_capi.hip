@@ -23,6 +23,7 @@
 
 #include "../../include/ttcr_amd.h"
 #include "fsm_kernels.h"
+#include "fsm_wave_kernels.h"
 
 #ifndef FSM_CHUNK3
 #define FSM_CHUNK3 8
@@ -57,17 +58,22 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    void reserve(size_t m) {
+    size_t guard = 0;   // elements allocated in front of p and behind p + n (readable, never meaningful)
+    void reserve(size_t m, size_t guard_ = 0) {
         if (m <= n) return;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-        HIP_CHECK(hipMalloc((void**)&p, m * sizeof(T)));
+        release();
+        char* raw = nullptr;
+        HIP_CHECK(hipMalloc((void**)&raw, (m + 2 * guard_) * sizeof(T)));
+        guard = guard_;
+        p = (T*)raw + guard;
         n = m;
     }
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+    void release() {
+        if (p) (void)hipFree((void*)(p - guard));
+        p = nullptr;
+        n = 0;
     }
+    ~DevBuf() { release(); }
 };
 
 struct Timing {
@@ -132,6 +138,7 @@ class GridBase {
     std::vector<int> phys;
     int P(int slot) const { return phys.empty() ? slot : phys[slot]; }
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
+    virtual void set_wave(int) {}   // option "wave" (GridT)
     // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
     // order stage then WENO stage
     std::vector<std::vector<double>> change_hist, change_histw;
@@ -164,6 +171,7 @@ class GridBase {
         else if (k == "interp_vel") interp_vel = value != 0;
         else if (k == "return_rays") return_rays = value != 0;
         else if (k == "pair_sources") pair_by_distance = value != 0;
+        else if (k == "wave") set_wave((int)value);
         else throw ValueError("unknown option '" + k + "'");
     }
     virtual void get_niter(int slot, int* it, int* itw) const {
@@ -239,6 +247,12 @@ class GridT : public GridBase {
     DevBuf<uint32_t> d_order;  // persistent kernel: patches in ticket order (anti-diagonal major)
     DevBuf<uint32_t> d_order_xs[2][2];  // whole-iteration launch, [stage: first order / WENO][0: sweep by sweep, 1: by expected start time]
     DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
+    // one-wavefront units (fsm_wave_kernels.h): first-order 3-D sweeps of fp32 grids that keep one field per slot
+    int wave = -1;             // option "wave" / TTCR_FSM_WAVE: 1 on (where the kernel applies), 0 / -1 off (default: it is slower, profiles/r04/wave_kernel.txt)
+    int wave_pkr = 2, wave_c = 8;   // columns per lane (patch = 16 x 4 pkr columns) and levels per chunk
+    int wave_wgs = 0;          // wavefronts of a launch (each takes units until none is left); 0: 3 per SIMD
+    int wave_npk = 0, wave_patches = 0, wave_built_pkr = 0, wave_built_c = 0;
+    DevBuf<uint32_t> d_order_wave[2];   // ticket order: [0] sweep by sweep, [1] by expected start time
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
     DevBuf<int> d_stamp;       // dirty-brick stamps [n_slots][nbf*nbj*nbk]
@@ -314,7 +328,7 @@ class GridT : public GridBase {
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
-        d_s.reserve(n_nodes);
+        d_s.reserve(n_nodes, 64);   // (guard elements: the 16-byte accesses of fsm_wave_kernels.h overhang a row by up to three)
         // source pairs (fields interleaved, marched together) for the first-order 3-D solver only.  The one-wave 2-D
         // patches issue in order, a second source doubles the instructions of a level and buys nothing (4096^2:
         // 16 sources 28.0 -> 20.8 ms, 64 sources 35.8 -> 28.9 ms, 256 sources 112 -> 87 ms unpaired); the WENO stage
@@ -322,7 +336,7 @@ class GridT : public GridBase {
         // 1208 -> 973 ms, 16 sources 1740 -> 1672 ms, 64 sources 5986 -> 6221 ms).  profiles/r02/pairing.txt
         NS = (n_slots >= 2 && dim == 3 && !weno) ? 2 : 1;
         if (const char* e = std::getenv("TTCR_FSM_PAIR")) NS = (std::atoi(e) != 0 && n_slots >= 2) ? 2 : 1;
-        d_tt.reserve(n_nodes * (size_t)n_groups() * NS);
+        d_tt.reserve(n_nodes * (size_t)n_groups() * NS, 64);
         mask_words = (n_nodes + 31) / 32;
         d_mask.reserve(mask_words * (size_t)n_slots);
         d_bbox.reserve(6 * (size_t)n_slots);
@@ -397,6 +411,9 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_WAVE")) wave = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_WAVE_SHAPE")) { if (std::sscanf(e, "%dx%d", &wave_pkr, &wave_c) != 2) throw ValueError("TTCR_FSM_WAVE_SHAPE=<columns per lane>x<levels per chunk>"); }
+        if (const char* e = std::getenv("TTCR_FSM_WAVE_WGS")) wave_wgs = std::atoi(e);   // tuning only
     }
 
     // persistent kernel: ticket order = anti-diagonal m = TJ+TK major (a topological order of the
@@ -412,6 +429,8 @@ class GridT : public GridBase {
         // four ticket counters, the abort word, then one progress word per (direction, slot, patch).  The kernels tag every
         // word with the launch epoch: nothing is reset between the launches of a solve (fsm_kernels.h, "launch epoch")
         sync_words = 8 + (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4);
+        if (dim == 3)   // (the one-wavefront units of fsm_wave_kernels.h use finer patches: 16 x 4 columns at the least)
+            sync_words = std::max(sync_words, 8 + (size_t)((geom.NJ + 15) / 16) * ((geom.NK + 3) / 4) * n_slots * 8);
         d_sync.reserve(sync_words);
         HIP_CHECK(hipMemset(d_sync.p, 0, sync_words * sizeof(int)));
         if (geom.npj >= (1 << 14) || geom.npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
@@ -433,9 +452,13 @@ class GridT : public GridBase {
     // next sweep, whose first corner is long free, cannot enter.  In start-time order the resident units are the ones
     // that can run next, of whichever sweep.
     std::vector<uint32_t> xs_order(const std::vector<uint32_t>& diag_order, bool by_time, int H) const {
-        const int ndir = dim == 3 ? 8 : 4, npj = geom.npj;
         const int PJ = dim == 3 ? TileCfg<T, 3>::PJ : TileCfg<T, 2>::PJ, PK = dim == 3 ? TileCfg<T, 3>::PK : 1;
         const int C = dim == 3 ? ChunkCfg<T, 3>::C : ChunkCfg<T, 2>::C;
+        return xs_order_for(diag_order, by_time, H, PJ, PK, C, geom.npj, n_patches);
+    }
+    std::vector<uint32_t> xs_order_for(const std::vector<uint32_t>& diag_order, bool by_time, int H, int PJ, int PK, int C, int npj,
+                                       int n_patches) const {
+        const int ndir = dim == 3 ? 8 : 4;
         std::vector<uint32_t> out;
         out.reserve((size_t)n_patches * ndir);
         if (!by_time) {
@@ -944,7 +967,71 @@ class GridT : public GridBase {
         if (dim == 2 && rotated && !weno && dx == dz) launch_sweep45(batch);
     }
 
+    // ---- one-wavefront units (fsm_wave_kernels.h) ----------------------------------------------------------
+    void set_wave(int v) override { wave = v; }
+    // where they apply: first-order sweeps of a 3-D fp32 grid with one field per slot (a lone slot, grids with weno = 1, or
+    // TTCR_FSM_PAIR=0), whole-iteration launches, byte offsets of a field in 32 bits
+    bool wave_now() const {
+        if (sizeof(T) != 4 || dim != 3 || stage != 0 || NS != 1 || mode != 2 || wave <= 0) return false;   // (opt-in: see the measurements at fsm_wave_kernels.h)
+        if (skip > 0) return false;                                  // (exact skipping asked for: the kernels that have it)
+        if ((unsigned long long)n_nodes * 4ull > 0xfff00000ull) return false;
+        return true;
+    }
+    void build_wave_lists() {
+        if (wave_built_pkr == wave_pkr && wave_built_c == wave_c) return;
+        const int PJ = 16, PK = 4 * wave_pkr, npj = (geom.NJ + PJ - 1) / PJ;
+        wave_npk = (geom.NK + PK - 1) / PK;
+        wave_patches = npj * wave_npk;
+        if (npj >= (1 << 14) || wave_npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
+        if (8 + (size_t)wave_patches * n_slots * 8 > sync_words) throw std::logic_error("progress words of the wave kernel do not fit");
+        std::vector<uint32_t> order;
+        for (int m = 0; m <= npj + wave_npk - 2; ++m)
+            for (int TK = std::max(0, m - npj + 1); TK <= std::min(m, wave_npk - 1); ++TK) order.push_back((uint32_t)(m - TK) | ((uint32_t)TK << 16));
+        for (int tm = 0; tm < 2; ++tm) {
+            const std::vector<uint32_t> xs = xs_order_for(order, tm != 0, 1, PJ, PK, wave_c, npj, wave_patches);
+            d_order_wave[tm].reserve(xs.size());
+            HIP_CHECK(hipMemcpy(d_order_wave[tm].p, xs.data(), xs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        wave_built_pkr = wave_pkr;
+        wave_built_c = wave_c;
+    }
+    void launch_sweeps_wave(int batch) {
+        if constexpr (sizeof(T) == 4) {
+            build_wave_lists();
+            WaveArgs wa;
+            wa.tt = (float*)d_tt.p;
+            wa.s = (const float*)d_s.p;
+            wa.frozen = d_mask.p;
+            wa.bbox = d_bbox.p;
+            wa.change = d_change.p;
+            wa.slots = d_slots.p;
+            wa.evals = d_evals.p;
+            wa.order = d_order_wave[batch < time_order_below ? 1 : 0].p;
+            wa.sync = d_sync.p;
+            wa.iter_ptr = d_iter.p;
+            wa.NF = geom.NF; wa.NJ = geom.NJ; wa.NK = geom.NK;
+            wa.npj = (geom.NJ + 15) / 16;
+            wa.npk = wave_npk;
+            wa.n_patches = wave_patches;
+            wa.batch = batch;
+            wa.n_nodes = (uint32_t)n_nodes;
+            wa.mask_words = (uint32_t)mask_words;
+            wa.dx = (float)dx;
+            wa.timeout_ticks = 1000000000ull;   // 10 s: a unit may wait for most of the previous sweep
+            int cus = 0;
+            HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            const size_t cap = wave_wgs > 0 ? (size_t)wave_wgs : (size_t)std::max(cus, 1) * 12;
+            const dim3 grid((unsigned)std::min<size_t>((size_t)wave_patches * batch * 8, cap)), block(64);
+            if (wave_pkr == 2 && wave_c == 8) fsm_sweep_wave<2, 8><<<grid, block, 0, stream>>>(wa);
+            else if (wave_pkr == 1 && wave_c == 8) fsm_sweep_wave<1, 8><<<grid, block, 0, stream>>>(wa);
+            else if (wave_pkr == 4 && wave_c == 8) fsm_sweep_wave<4, 8><<<grid, block, 0, stream>>>(wa);
+            else throw ValueError("TTCR_FSM_WAVE_SHAPE: no such instantiation (1x8, 2x8, 4x8)");
+            HIP_CHECK(hipGetLastError());
+        }
+    }
+
     void issue_sweeps_axis(int batch) {
+        if (wave_now()) { launch_sweeps_wave(batch); return; }
         if (stage == 1) {
             if (dim == 3) launch_sweeps_persistent<3, 2>(batch); else launch_sweeps_persistent<2, 2>(batch);
         } else if (mode >= 1) {
