@@ -93,12 +93,7 @@ def cpu_baseline(n=256, n_src=3):
     return out
 
 
-KERNELS = {"2": "fsm_sweep_persistent<float,16,16,8,true,SKIP,1,2,true,true> (one launch per sweep-iteration; SKIP: template flag of "
-                "the build with the exact-skipping scheduler, the default from two slot groups on; two sources per workgroup, the "
-                "sources of a call paired by distance; workgroups draw work units from a ticket counter until none is left)",
-           "1": "fsm_sweep_persistent<float,16,16,8,true,SKIP,1,2,false,false> (one launch per directional sweep)",
-           "0": "fsm_sweep_tile<float,16,16,16,true> (one launch per tile wavefront)"}
-PROFILE_DIRS = ("r03", "r02")
+PROFILE_DIRS = ("r04", "r03", "r02")
 
 
 def profiled_traffic(n, n_src_rank0, world):
@@ -174,6 +169,101 @@ def single_source_leg(n, dx, x, s_dev, local_rank, reps=5):
             "Mnodes_per_s_per_sweep_iteration": round(n ** 3 / per_it / 1e3, 1), "sweep_iterations": its // reps,
             "ms_per_solve_wall": round(wall / reps * 1e3, 3), "solves": reps,
             "note": "1 source (first of the set) on the same grid, same process; HIP events on the library's stream"}
+
+
+def small_batch_leg(n, dx, x, s_dev, local_rank, n_src, reps, ms64_per_step):
+    """What ONE GPU of an 8-GPU node runs when the 64 sources of the workload are sharded (Grid3D::raytrace's block distribution,
+    ttcr/Grid3D.h:451-465, 810-853): n_src sources on the same grid, same process.  Whole steps (wall clock) and sweep launches."""
+    import cases
+    import ttcr_amd
+
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=n_src, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32, device=local_rank)
+    g.set_slowness_device(s_dev.data_ptr(), s_dev.numel())
+    src = cases.mt_sources(64)[:n_src]
+    rcv = cases.rcv_lattice3d()
+    sr, rr = np.repeat(src, rcv.shape[0], axis=0), np.tile(rcv, (n_src, 1))
+    g.raytrace(sr, rr)
+    ms, ev, its, launches = 0.0, 0, 0, 0
+    t = time.perf_counter()
+    for _ in range(reps):
+        g.raytrace(sr, rr)
+        tm = g.timing()
+        ms += tm["sweep_ms"]; ev += tm["evaluated_updates"]; its += tm["node_updates"] // 8; launches += tm["kernel_launches"]
+    wall = (time.perf_counter() - t) / reps * 1e3
+    achieved = BYTES_PER_NODE_ITER / 8.0 * ev / (ms * 1e-3) / 1e9
+    out = {"sources": n_src, "ms_per_step_wall": round(wall, 3), "ms_of_sweep_launches_per_step": round(ms / reps, 3),
+           "Mnodes_per_s_per_sweep_iteration": round(its / (wall * reps * 1e-3) / 1e6, 1),
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "evaluated_fraction": round(ev / max(its * 8, 1), 4),
+           "sweep_iterations": sorted({g.get_niter(i) for i in range(n_src)}), "kernel": g.last_kernel(), "steps": reps}
+    if ms64_per_step:
+        out["projected_strong_scaling_efficiency_8_gpus"] = round(ms64_per_step / (8.0 * wall), 3)
+        out["note"] = ("projection from one GPU: t(64 sources) / (8 x t(8 sources)), whole steps -- what the strong-scaling run of the "
+                       "workload would show on 8 GPUs if nothing else were lost; not a measurement of 8 GPUs")
+    return out, g
+
+
+def heterogeneous_leg(g, n, reps=2):
+    """The same 8-source grid on a model where every sweep-iteration does real work: uniform random slowness in [0.25, 1] per 16^3
+    block (seed 5), run to convergence -- what exact skipping is worth when iterations 2 ... do not come for free."""
+    import cases
+    import torch
+
+    rng = np.random.default_rng(5)
+    nb = (n + 15) // 16
+    b = torch.from_numpy(rng.uniform(0.25, 1.0, (nb, nb, nb)).astype(np.float32)).cuda()
+    s = b.repeat_interleave(16, 0).repeat_interleave(16, 1).repeat_interleave(16, 2)[:n, :n, :n]
+    s = s.permute(2, 1, 0).contiguous().reshape(-1)   # (nx, ny, nz) C order -> x fastest
+    torch.cuda.synchronize()
+    g.set_slowness_device(s.data_ptr(), s.numel())
+    n_src = g.n_threads
+    src = cases.mt_sources(64)[:n_src]
+    rcv = cases.rcv_lattice3d()
+    sr, rr = np.repeat(src, rcv.shape[0], axis=0), np.tile(rcv, (n_src, 1))
+    g.raytrace(sr, rr)
+    ms, ev, its = 0.0, 0, 0
+    t = time.perf_counter()
+    for _ in range(reps):
+        g.raytrace(sr, rr)
+        tm = g.timing()
+        ms += tm["sweep_ms"]; ev += tm["evaluated_updates"]; its += tm["node_updates"] // 8
+    wall = (time.perf_counter() - t) / reps * 1e3
+    achieved = BYTES_PER_NODE_ITER / 8.0 * ev / (ms * 1e-3) / 1e9
+    return {"model": "uniform random slowness in [0.25, 1] per 16^3 block (numpy default_rng(5))", "sources": n_src,
+            "ms_per_step_wall": round(wall, 3), "ms_of_sweep_launches_per_step": round(ms / reps, 3),
+            "Mnodes_per_s_per_sweep_iteration": round(its / (wall * reps * 1e-3) / 1e6, 1),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "evaluated_fraction": round(ev / max(its * 8, 1), 4),
+            "sweep_iterations": sorted({g.get_niter(i) for i in range(n_src)}), "kernel": g.last_kernel(), "steps": reps}
+
+
+def weno_leg(local_rank, n=256):
+    """The two-stage solver (weno=True, the ttcrpy default: first-order sweeps, then third-order WENO sweeps,
+    ttcr/Grid3Drnfs.h:104-136) on the n^3 gradient model, 1 and 8 sources."""
+    import cases
+    import ttcr_amd
+
+    dx = 20.0 / (n - 1)
+    x = np.arange(n, dtype=np.float64) * dx
+    s = np.ascontiguousarray(np.broadcast_to(gradient_slowness_f32(n, dx), (n, n, n)))
+    out = {}
+    for n_src in (1, 8):
+        g = ttcr_amd.Grid3d(x, x, x, n_threads=n_src, cell_slowness=0, method="FSM", tt_from_rp=0, weno=1, dtype=np.float32, device=local_rank)
+        g.set_slowness(s)
+        src = cases.mt_sources(64)[:n_src]
+        rcv = cases.rcv_lattice3d()
+        sr, rr = np.repeat(src, rcv.shape[0], axis=0), np.tile(rcv, (n_src, 1))
+        g.raytrace(sr, rr)
+        t = time.perf_counter()
+        g.raytrace(sr, rr)
+        wall = (time.perf_counter() - t) * 1e3
+        tm = g.timing()
+        its = tm["node_updates"] // 8
+        out[f"sources_{n_src}"] = {"ms_per_solve_wall": round(wall, 2), "ms_of_sweep_launches": round(tm["sweep_ms"], 2),
+                                   "sweep_iterations_first_order": sorted({g.get_niter(i) for i in range(n_src)}),
+                                   "sweep_iterations_weno": sorted({g.get_niterw(i) for i in range(n_src)}),
+                                   "Mnodes_per_s_per_sweep_iteration": round(its / (wall * 1e-3) / 1e6, 1), "kernel_of_the_last_stage": g.last_kernel()}
+        del g
+    out["grid"] = f"{n}^3 nodes, gradient model, fp32, weno=True, tt_from_rp=False"
+    return out
 
 
 def main():
@@ -289,8 +379,12 @@ def main():
     node_iters = 0
     evaluated = 0
     step_launches, step_niter = [], []
+    host_ms = 0.0
     for _ in range(args.steps):
+        tw = time.perf_counter()
         tt, tm = step()
+        tw = (time.perf_counter() - tw) * 1e3
+        host_ms += tw - tm["sweep_ms"]
         sweep_ms += tm["sweep_ms"]
         launches += tm["kernel_launches"]
         node_iters += tm["node_updates"] // 8
@@ -299,9 +393,10 @@ def main():
         step_niter.append(tuple(grid.get_niter(i) for i in range(S)))   # (a few microseconds: host-side counters)
         if args.per_step:
             sys.stderr.write(f"step {len(step_launches) - 1}: launches {step_launches[-1]} evaluated {tm['evaluated_updates'] / n ** 3:.3f} N "
-                             f"sweep_ms {tm['sweep_ms']:.2f} niter {sorted(set(step_niter[-1]))}\n")
+                             f"sweep_ms {tm['sweep_ms']:.2f} wall_ms {tw:.2f} lib_total_ms {tm['total_ms']:.2f} niter {sorted(set(step_niter[-1]))}\n")
     fence()
     el = time.perf_counter() - t0
+    kernel_name = grid.last_kernel()
     iters_per_src = list(step_niter[-1])
     # every timed step solves the same sources on the same model: launch count and iteration counts must not move
     odd_steps = [k for k in range(args.steps) if step_launches[k] != step_launches[0] or step_niter[k] != step_niter[0]]
@@ -323,6 +418,17 @@ def main():
     else:
         el_max, sweep_ms_max, node_iters_all = el, sweep_ms, float(node_iters)
 
+    # which device every rank ran on (uuid where torch exposes it): the first multi-GPU run is self-verifying
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        mine_id = f"rank {rank}: cuda:{local_rank} {pr.name} uuid {getattr(pr, 'uuid', 'n/a')}"
+    except Exception as e:
+        mine_id = f"rank {rank}: cuda:{local_rank} ({e})"
+    if world > 1:
+        dev_ids = [None] * world
+        dist.all_gather_object(dev_ids, mine_id)
+    else:
+        dev_ids = [mine_id]
     if rank == 0:
         assert np.all(np.isfinite(tt)) and float(tt.max()) < 1e3, "non-physical traveltimes"
         value = node_iters_all / el_max / 1e6
@@ -342,6 +448,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(el_max / args.steps * 1e3, 3),
+            "ms_per_step_outside_sweep_launches": round(host_ms / args.steps, 3),
             "higher_is_better": True,
             "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
@@ -357,13 +464,16 @@ def main():
                        "sweep_iterations_per_source": sorted(set(iters_per_src)),
                        "launches_per_step": sorted(set(step_launches)),
                        "steps_that_differ_from_the_first": odd_steps,
-                       "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, all_gather of receiver traveltimes)"},
+                       "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, all_gather of receiver traveltimes)",
+                       "collective_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
+                       "devices": dev_ids},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_reads": traffic_rd, "traffic_writes": traffic_wr,
                          "frac_real_traffic": (round(traffic * launches / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                         "frac_real_traffic_note": ("PMC bytes of the committed profile (another box, same kernel sources) over THIS run's launch time" if traffic else None),
                          "frac_contract_all_updates": round(nominal / HBM_PEAK_GBS, 4),
-                         "kernel": KERNELS.get(os.environ.get("TTCR_FSM_MODE", "2"), "?"),
+                         "kernel": kernel_name + " (as reported by the library: ttcr_fsm_last_kernel; 8th parameter = sources marched per workgroup, 6th = exact skipping)",
                          "algorithmic_bytes_per_node_per_sweep_iteration": BYTES_PER_NODE_ITER,
                          "evaluated_fraction": round(evaluated / max(node_iters * 8, 1), 4),
                          "nominal_GBs_all_updates": round(nominal, 1),
@@ -404,6 +514,18 @@ def main():
             except Exception as e:
                 sys.stderr.write("evaluate-all leg failed: %s\n" % e)
             out["single_source"] = single_source_leg(n, dx, x, s_dev, local_rank)
+            # the small-batch regime (one GPU's share of the workload on an 8-GPU node), a model without free iterations, the WENO stage
+            for name, fn in (("eight_sources", None), ("heterogeneous", None), ("weno", None)):
+                try:
+                    if name == "eight_sources":
+                        out[name], g8 = small_batch_leg(n, dx, x, s_dev, local_rank, 8, 3, el_max / args.steps * 1e3 if n_total == 64 else None)
+                    elif name == "heterogeneous":
+                        out[name] = heterogeneous_leg(g8, n)
+                        del g8
+                    else:
+                        out[name] = weno_leg(local_rank)
+                except Exception as e:   # (reported, never fatal)
+                    out[name] = {"error": str(e)[:300]}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

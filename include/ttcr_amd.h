@@ -257,6 +257,9 @@ typedef struct {
     int n_sources;
 } ttcr_fsm_timing;
 int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out);
+/* Name of the sweep-kernel instantiation the last solve launched (first-order stage of the last batch; no reference
+ * equivalent: bench.py reports it beside the roofline figures).  Written into buf (n bytes, NUL terminated). */
+int ttcr_fsm_last_kernel(const ttcr_fsm_grid* g, char* buf, size_t n);
 
 #ifdef __cplusplus
 }

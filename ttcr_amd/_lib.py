@@ -53,6 +53,7 @@ SYMBOLS = {
     "ttcr_fsm_n_cells": (C.c_size_t, [_P]),
     "ttcr_fsm_set_option": (_I, [_P, C.c_char_p, _D]),
     "ttcr_fsm_last_timing": (_I, [_P, C.POINTER(Timing)]),
+    "ttcr_fsm_last_kernel": (_I, [_P, C.c_char_p, C.c_size_t]),
     "ttcr_fsm_rays_size": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ttcr_fsm_get_rays": (_I, [_P, _P, _P]),
     "ttcr_fsm_raytrace_rays": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),

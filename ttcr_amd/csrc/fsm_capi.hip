@@ -159,6 +159,8 @@ class GridBase {
     int mode = 2;  // 2: persistent kernel, one launch per sweep-iteration, sweeps overlap (default);
                    // 1: persistent kernel, one launch per sweep; 0: one launch per tile wavefront
     Timing timing;
+    std::string last_kernel;   // instantiation of the sweep kernel the last solve launched (ttcr_fsm_last_kernel)
+    virtual std::string kernel_name() const { return last_kernel; }
     // ttcr_fsm_set_option (a multi-device grid forwards it to its replicas)
     virtual void apply_option(const std::string& k, double value) {
         if (k == "fixed_iters") fixed_iters = (int)value;
@@ -572,6 +574,13 @@ class GridT : public GridBase {
         const size_t wg_cap = (fsm_looped(DIM == 3, H) && persist_wgs > 0) ? (size_t)persist_wgs : ~(size_t)0;
         const dim3 block(C::PJ * C::PK), grid((unsigned)std::min<size_t>((size_t)n_patches * batch, wg_cap));
         const int ndir = DIM == 3 ? 8 : 4;
+        {
+            const bool pre_ = mode == 2 && (DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0);
+            char nm[160];
+            std::snprintf(nm, sizeof nm, "fsm_sweep_persistent<%s,%d,%d,%d,%s,%s,%d,%d,%s,%s>", sizeof(T) == 4 ? "float" : "double", C::PJ, C::PK, CH,
+                          DIM == 3 ? "true" : "false", skip_now(batch) ? "true" : "false", H, NSV, mode == 2 ? "true" : "false", pre_ ? "true" : "false");
+            last_kernel = nm;
+        }
         if (mode == 2) {
             // whole iteration in one launch: tickets direction-major, sweeps overlap at their ends
             pa.ssh = d_ssh.p;
@@ -895,6 +904,7 @@ class GridT : public GridBase {
                 fsm_sweep_tile<T, C::PJ, C::PK, C::BL, DIM == 3><<<grid, block, 0, stream>>>(a);
             }
         }
+        last_kernel = std::string("fsm_sweep_tile<") + (sizeof(T) == 4 ? "float" : "double") + "," + std::to_string(C::PJ) + "," + std::to_string(C::PK) + "," + std::to_string(C::BL) + "," + (DIM == 3 ? "true" : "false") + ">";
         HIP_CHECK(hipGetLastError());
     }
 
@@ -1022,6 +1032,7 @@ class GridT : public GridBase {
             HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
             const size_t cap = wave_wgs > 0 ? (size_t)wave_wgs : (size_t)std::max(cus, 1) * 12;
             const dim3 grid((unsigned)std::min<size_t>((size_t)wave_patches * batch * 8, cap)), block(64);
+            last_kernel = "fsm_sweep_wave<" + std::to_string(wave_pkr) + "," + std::to_string(wave_c) + ">";
             if (wave_pkr == 2 && wave_c == 8) fsm_sweep_wave<2, 8><<<grid, block, 0, stream>>>(wa);
             else if (wave_pkr == 1 && wave_c == 8) fsm_sweep_wave<1, 8><<<grid, block, 0, stream>>>(wa);
             else if (wave_pkr == 4 && wave_c == 8) fsm_sweep_wave<4, 8><<<grid, block, 0, stream>>>(wa);
@@ -1072,9 +1083,19 @@ class GridT : public GridBase {
     }
 
     // One batch: sources src_ids[b] solved concurrently, source b in slot slot_ids[b].
+    // TTCR_FSM_HOST_PROF=1: wall clock of the host-side phases of a call (stderr), tuning only
+    bool host_prof = std::getenv("TTCR_FSM_HOST_PROF") != nullptr;
+    std::chrono::steady_clock::time_point hp_t = std::chrono::steady_clock::now();
+    void hp_mark(const char* what) {
+        if (!host_prof) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[host] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - hp_t).count());
+        hp_t = now;
+    }
     void solve_batch(const std::vector<int>& slot_ids, const std::vector<int>& src_ids, const int* tx_off,
                      const T* tx, const T* t0) {
         const int nb = (int)slot_ids.size();
+        hp_mark("(before solve_batch)");
         const int nc = ncoord();
         const long long node_updates_before = timing.node_updates;
         // reinit + initFSM (ttcr/Grid3Drnfs.h:92-100)
@@ -1136,7 +1157,9 @@ class GridT : public GridBase {
             change_histw[slot].clear();
         }
         HIP_CHECK(hipGetLastError());
+        hp_mark("reinit + initFSM issued");
         HIP_CHECK(hipStreamSynchronize(stream));  // pts vector goes out of scope below; also surfaces errors early
+        hp_mark("reinit + initFSM done");
 
         // driver loop of Grid3Drnfs::raytrace, per source: first-order sweeps until the L1 change
         // drops below eps*N (ttcr/Grid3Drnfs.h:137-153); with weno3 a second loop of WENO sweeps with
@@ -1191,6 +1214,7 @@ class GridT : public GridBase {
                 HIP_CHECK(hipMemcpyAsync(h_change, d_change.p, sizeof(double) * n_slots, hipMemcpyDeviceToHost, stream));
                 if (persistent_now()) HIP_CHECK(hipMemcpyAsync(h_abort, d_sync.p + 4, sizeof(int), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
+                hp_mark("sweep-iteration");
                 if (persistent_now() && *h_abort) {
                     HIP_CHECK(hipMemsetAsync(d_sync.p + 4, 0, sizeof(int), stream));
                     stage = 0;
@@ -1250,6 +1274,7 @@ class GridT : public GridBase {
                              h[4], h[0] * 0.01 / nb_, h[1] * 0.01 / nb_, h[2] * 0.01 / nb_, h[3] * 0.01 / nb_);
             }
         }
+        hp_mark("after the iterations");
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.sweep_ms += ms;
@@ -1787,6 +1812,7 @@ class GridT : public GridBase {
                         const void* rx_v, void* tt_out_v, int forced_slot, const int* explicit_slots = nullptr,
                         bool force_rays = false) override {
         HIP_CHECK(hipSetDevice(device));
+        if (host_prof) { hp_t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[host] ---- raytrace_multi\n"); }
         const int return_rays = (this->return_rays.load() || force_rays) ? 1 : 0;   // (shadows the option for this call)
         const auto wall0 = std::chrono::steady_clock::now();
         timing = Timing();
@@ -1850,8 +1876,10 @@ class GridT : public GridBase {
                     sl.swap(sl2); sr.swap(sr2);
                 }
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
+                hp_mark("solve_batch tail");
                 if (!(ttrp || return_rays)) {
                     interp_batch(sl, sr, rx_off, rx.data(), tt_out);
+                    hp_mark("receivers");
                     continue;
                 }
                 if (!return_rays) {
@@ -1936,6 +1964,7 @@ class MultiGrid : public GridBase {
     void interp(int slot, int n, const void* pts, void* out) override { int l; GridBase& g = of(slot, l); g.interp(l, n, pts, out); }
     void compute_slowness(int n, const void* pts, bool translated, void* out) override { rep[0]->compute_slowness(n, pts, translated, out); }
     void get_niter(int slot, int* it, int* itw) const override { int l; GridBase& g = of(slot, l); g.get_niter(l, it, itw); }
+    std::string kernel_name() const override { return rep[0]->kernel_name(); }
     void get_changes(int slot, double* first, int n_first, double* wen, int n_weno) const override {
         int l; GridBase& g = of(slot, l); g.get_changes(l, first, n_first, wen, n_weno);
     }
@@ -2493,6 +2522,14 @@ int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out) {
         out->evaluated_updates = t.evaluated_updates;
         out->iterations = t.iterations;
         out->n_sources = t.n_sources;
+    });
+}
+
+int ttcr_fsm_last_kernel(const ttcr_fsm_grid* g, char* buf, size_t n) {
+    return guarded_on(g, [&] {
+        if (!buf || n == 0) throw ValueError("ttcr_fsm_last_kernel: no buffer");
+        const std::string k = g->impl->kernel_name();
+        std::snprintf(buf, n, "%s", k.c_str());
     });
 }
 

@@ -153,6 +153,12 @@ class _GridBase:
         _lib.check(self._lib.ttcr_fsm_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
+    def last_kernel(self):
+        """Instantiation of the sweep kernel the last solve launched (string)."""
+        buf = C.create_string_buffer(256)
+        _lib.check(self._lib.ttcr_fsm_last_kernel(self._h, buf, 256))
+        return buf.value.decode()
+
     def _flat_tt(self, thread_no):
         if thread_no >= self._n_threads:
             raise ValueError('Thread number is larger than number of threads')
