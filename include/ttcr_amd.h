@@ -242,9 +242,24 @@ int ttcr_fsm_raytrace_m(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, co
 int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz);
 int ttcr_fsm_get_slot_m(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* j, void* v);
 
-/* NOT provided (reference overload without an entry point here): raytrace with l_data (ray projection matrix L) -- ttcrpy
- * itself raises "compute_L not implemented for FSM" (src/ttcrpy/rgrid.pyx:916-917).  A binding must refuse it (the adapters in
- * integration/ throw, ttcr_amd/rgrid.py raises NotImplementedError). */
+/* Replaces: Grid2D::raytrace(Tx, t0, Rx, traveltimes, l_data, threadNo) (ttcr/Grid2D.h:616-640) and the overload with r_data
+ * AND l_data (:583-614) -> Grid2Drn::getRaypath(Tx, t0, Rx, [r_data,] l_data, tt, threadNo) (ttcr/Grid2Drn.h:1852-2190): what
+ * `compute_L=True` of the Python layer reaches for 2-D grids with cell slowness (src/ttcrpy/rgrid.pyx:3889-3893, :4060-4143).
+ * One call solves the source in `slot`, walks every receiver's ray on the device and keeps, per receiver, the (cell index,
+ * segment length) entries of the ray-projection matrix L, sorted by cell with the reference's comparator (CompareSiv_i,
+ * ttcr/ttcr_t.h:417-422).  Restated AS IT STANDS: this walk gives up where the plain raypath walk retries along a face
+ * ("going outside grid"); when the last two segments of a ray lie in one cell the reference pushes the entry of the first
+ * AND an entry holding the sum, and the overload without r_data prices the last hop with that sum.  Traveltimes are those
+ * of the overload (with_rays selects which).  Bit-identical to the compiled reference (tests/golden/l_golden.npz,
+ * tests/test_l_matrix.py).  2-D grids with cell slowness only (TTCR_ERR_UNSUPPORTED otherwise: in 3-D ttcrpy itself raises
+ * "compute_L defined for the FSM", rgrid.pyx:916-917; node grids: rgrid.pyx:3889-3890).
+ * ttcr_fsm_slot_l_size: rows (= receivers) and entries of the last call on `slot`; ttcr_fsm_get_slot_l: row_off[n_rows+1],
+ * cell[nnz] cell indices (x-major, z fastest, like Grid2Drn::getCellNo), v[nnz] lengths of the grid dtype.  With with_rays != 0
+ * the rays of the call are available through ttcr_fsm_slot_rays_size / ttcr_fsm_get_slot_rays (two coordinates per point). */
+int ttcr_fsm_raytrace_l(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx,
+                        const void* rx, void* tt_out, int with_rays);
+int ttcr_fsm_slot_l_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz);
+int ttcr_fsm_get_slot_l(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* cell, void* v);
 
 typedef struct {
     double sweep_ms;        /* HIP-event time of all sweep launches of the last raytrace call   */

@@ -117,11 +117,41 @@ class Grid2Drnfs_amd : public Grid2D<T1, T2, S> {
             k += Rx[n]->size();
         }
     }
-    // L / M: not available for FSM (rgrid.pyx raises before it gets here; DESIGN.md for M)
-    void raytrace(const std::vector<S>&, const std::vector<T1>&, const std::vector<S>&, std::vector<T1>&, std::vector<std::vector<S>>&,
-                  std::vector<std::vector<siv<T1>>>&, const size_t = 0) const override { no_LM("l_data"); }
-    void raytrace(const std::vector<S>&, const std::vector<T1>&, const std::vector<S>&, std::vector<T1>&,
-                  std::vector<std::vector<siv<T1>>>&, const size_t = 0) const override { no_LM("l_data"); }
+    // L (ray-projection matrix of a cell grid): Grid2D::raytrace(Tx, t0, Rx, tt, [r_data,] l_data, threadNo), ttcr/Grid2D.h:583-640
+    void raytrace(const std::vector<S>& Tx, const std::vector<T1>& t0, const std::vector<S>& Rx, std::vector<T1>& traveltimes,
+                  std::vector<std::vector<S>>& r_data, std::vector<std::vector<siv<T1>>>& l_data, const size_t threadNo = 0) const override {
+        run_l(Tx, t0, Rx, traveltimes, &r_data, l_data, threadNo);
+    }
+    void raytrace(const std::vector<S>& Tx, const std::vector<T1>& t0, const std::vector<S>& Rx, std::vector<T1>& traveltimes,
+                  std::vector<std::vector<siv<T1>>>& l_data, const size_t threadNo = 0) const override {
+        run_l(Tx, t0, Rx, traveltimes, nullptr, l_data, threadNo);
+    }
+    void run_l(const std::vector<S>& Tx, const std::vector<T1>& t0, const std::vector<S>& Rx, std::vector<T1>& traveltimes,
+               std::vector<std::vector<S>>* r_data, std::vector<std::vector<siv<T1>>>& l_data, const size_t threadNo) const {
+        if (t0.size() != Tx.size()) throw std::runtime_error("Error: Tx and t0 of different sizes.");
+        traveltimes.resize(Rx.size());
+        std::vector<T1> tt(Rx.size() ? Rx.size() : 1);
+        chk(ttcr_fsm_raytrace_l(h, (int)threadNo, (int)Tx.size(), Tx.data(), t0.data(), (int)Rx.size(), Rx.data(), tt.data(), r_data ? 1 : 0));
+        last_slot.store((int)threadNo);
+        std::copy(tt.begin(), tt.begin() + Rx.size(), traveltimes.begin());
+        size_t nrow = 0, nnz = 0;
+        chk(ttcr_fsm_slot_l_size(h, (int)threadNo, &nrow, &nnz));
+        std::vector<long long> off(nrow + 1), cellno(nnz ? nnz : 1);
+        std::vector<T1> v(nnz ? nnz : 1);
+        chk(ttcr_fsm_get_slot_l(h, (int)threadNo, off.data(), cellno.data(), v.data()));
+        l_data.assign(Rx.size(), std::vector<siv<T1>>());
+        for (size_t n = 0; n < nrow; ++n)
+            for (long long e = off[n]; e < off[n + 1]; ++e) l_data[n].push_back(siv<T1>((size_t)cellno[e], v[e]));
+        if (r_data) {
+            size_t nr = 0, np = 0;
+            chk(ttcr_fsm_slot_rays_size(h, (int)threadNo, &nr, &np));
+            std::vector<long long> roff(nr + 1);
+            std::vector<S> pts(np ? np : 1);
+            chk(ttcr_fsm_get_slot_rays(h, (int)threadNo, roff.data(), pts.data()));
+            r_data->assign(Rx.size(), std::vector<S>());
+            for (size_t n = 0; n < nr; ++n) (*r_data)[n].assign(pts.begin() + roff[n], pts.begin() + roff[n + 1]);
+        }
+    }
 
     void raytrace_batch(const std::vector<std::vector<S>>& Tx, const std::vector<std::vector<T1>>& t0,
                         const std::vector<std::vector<S>>& Rx, std::vector<std::vector<T1>>& traveltimes,

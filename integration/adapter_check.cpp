@@ -240,6 +240,31 @@ int main() {
         std::vector<S> out = {{10.5f, 1.0f}};
         CHECK(what_of([&] { g->raytrace(Tx, t0, out, tt, 0); }) == "Error: Point (10.5, 1) outside grid.", "2-D point outside throws the reference's message");
     }
+    {   // ------------------------------------------------ 2-D cell grid: the overloads with l_data (compute_L) through Grid2D*
+        using S = sxz<float>;
+        std::unique_ptr<Grid2D<float, uint32_t, S>> g(new Grid2Drnfs_amd<float, uint32_t, S>(true, 20, 12, 0.5f, 0.5f, 0.0f, 0.0f, 1e-5f, 50,
+                                                                                              false, false, false, 2));
+        std::vector<float> s(20 * 12);
+        for (size_t n = 0; n < s.size(); ++n) s[n] = slow(7000u + (unsigned)n);
+        g->setSlowness(s);
+        std::vector<S> Tx = {{3.3f, 1.1f}}, Rx = {{0.4f, 0.3f}, {9.0f, 5.0f}, {3.3f, 1.1f}};
+        std::vector<float> t0 = {0.0f}, tt, tt2;
+        std::vector<std::vector<siv<float>>> l_data, l2;
+        std::vector<std::vector<S>> r_data;
+        g->raytrace(Tx, t0, Rx, tt, l_data, 1);
+        g->raytrace(Tx, t0, Rx, tt2, r_data, l2, 1);
+        bool ok = l_data.size() == 3 && l_data[2].empty() && tt[2] == 0.0f && !l_data[0].empty() && !l_data[1].empty() && r_data.size() == 3;
+        for (size_t n = 0; n < 2 && ok; ++n) {
+            double len = 0, straight = std::sqrt((double)(Rx[n].x - Tx[0].x) * (Rx[n].x - Tx[0].x) + (double)(Rx[n].z - Tx[0].z) * (Rx[n].z - Tx[0].z));
+            for (size_t e = 0; e < l_data[n].size(); ++e) {
+                ok = ok && l_data[n][e].i < 240 && (e == 0 || l_data[n][e - 1].i <= l_data[n][e].i) && l2[n][e].i == l_data[n][e].i && l2[n][e].v == l_data[n][e].v;
+                len += l_data[n][e].v;
+            }
+            ok = ok && len >= straight * 0.999 && r_data[n].size() >= 2;
+        }
+        CHECK(ok, "l_data overloads: entries sorted by cell, none for a receiver on the source, lengths cover the straight distance");
+        std::printf("l2_entries %zu %zu tt %a %a\n", l_data[0].size(), l_data[1].size(), tt[0], tt[1]);
+    }
     std::printf("failures %d\n", failures);
     return failures;
 }

@@ -49,7 +49,11 @@ extern "C" {
     REAL fsm_interp2d_##S(const fsm_grid2d_##S* g, const REAL* T, REAL px, REAL pz);                 \
     int fsm_raypath2d_##S(const fsm_grid2d_##S* g, const REAL* sn, const REAL* sc, const REAL* T,    \
                           int n_src, const REAL* src, const REAL* t0, const REAL rx[2], int record,  \
-                          long max_steps, REAL* tt_out, REAL* pts, long cap, long* npts);
+                          long max_steps, REAL* tt_out, REAL* pts, long cap, long* npts);                   \
+    int fsm_raypath2d_l_##S(const fsm_grid2d_##S* g, const REAL* sn, const REAL* sc, const REAL* T,  \
+                            int n_src, const REAL* src, const REAL* t0, const REAL rx[2],            \
+                            int with_rays, long max_steps, REAL* tt_out, REAL* pts, long cap,        \
+                            long* npts, long long* lcell, REAL* lval, long lcap, long* nlen);
 
 FSM_ORACLE_DECL(float, f32)
 FSM_ORACLE_DECL(double, f64)

@@ -1432,5 +1432,93 @@ int SFX(fsm_raypath2d)(const SFX(fsm_grid2d) * g, const REAL* sn, const REAL* sc
     return over ? 3 : 0;
 }
 
+/* Grid2Drn::getRaypath with l_data (the ray-projection matrix L of compute_L):
+ *   with_rays != 0: getRaypath(Tx, t0, Rx, r_data, l_data, tt, threadNo), ttcr/Grid2Drn.h:1852-2021
+ *   with_rays == 0: getRaypath(Tx, t0, Rx, l_data, tt, threadNo), :2023-2190
+ * A walk of its own: a step that leaves the grid ends it (the reference throws; no second try along the face as in
+ * fsm_raypath2d); every segment is booked as (cell of its mid-point, length) in push order -- UNSORTED here, Grid2D::raytrace sorts
+ * afterwards (ttcr/Grid2D.h:608-611).  When the last two segments lie in one cell the reference pushes the first entry and then
+ * one holding the sum (:1985-1992, :2163-2170); without r_data the last hop's traveltime is slowness x that sum (:2181).
+ * Returns 0 ok, 1 outside the grid, 2 step limit, 3 capacity. */
+int SFX(fsm_raypath2d_l)(const SFX(fsm_grid2d) * g, const REAL* sn, const REAL* sc, const REAL* T, int n_src, const REAL* src,
+                         const REAL* t0, const REAL rx[2], int with_rays, long max_steps, REAL* tt_out, REAL* pts, long cap,
+                         long* npts, long long* lcell, REAL* lval, long lcap, long* nlen) {
+    REAL tt = 0.0, s1 = 0.0, s2 = 0.0, slown = 0.0;
+    long np = 0, nl = 0;
+    int over = 0;
+    REAL back[2] = {rx[0], rx[1]}, cur[2] = {rx[0], rx[1]}, gv[2];
+#define FSM_PUSHL(P) do { if (with_rays) { if (np < cap) { pts[2 * np] = (P)[0]; pts[2 * np + 1] = (P)[1]; } else over = 1; ++np; } \
+                          back[0] = (P)[0]; back[1] = (P)[1]; } while (0)
+#define FSM_BOOK(Cc, V) do { if (nl < lcap) { lcell[nl] = (long long)(Cc); lval[nl] = (V); } else over = 1; ++nl; } while (0)
+#define FSM_DONE(RC) do { *tt_out = tt; if (npts) *npts = np; if (nlen) *nlen = nl; return (RC); } while (0)
+    if (with_rays) { if (np < cap) { pts[0] = rx[0]; pts[1] = rx[1]; } else over = 1; ++np; }
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[2 * ns] && rx[1] == src[2 * ns + 1]) { tt = t0[ns]; FSM_DONE(0); }
+    if (!sc) s1 = SFX(fsm_interp2d)(g, sn, cur[0], cur[1]);
+    const REAL dx = g->dx, dz = g->dz;
+    const REAL maxDist = (REAL)sqrt(dx * dx + dz * dz);
+    int reached = 0;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) FSM_DONE(2);
+        SFX(grad2d)(g, T, cur[0], cur[1], &gv[0], &gv[1]);
+        gv[0] *= (REAL)-1.0; gv[1] *= (REAL)-1.0;
+        const ptrdiff_t i = (ptrdiff_t)(FSM_SMALL + (cur[0] - g->xmin) / dx);
+        const ptrdiff_t k = (ptrdiff_t)(FSM_SMALL + (cur[1] - g->zmin) / dz);
+        SFX(step2d)(g, i, k, cur, gv);
+        if (cur[0] < g->xmin || cur[0] > g->xmax || cur[1] < g->zmin || cur[1] > g->zmax) FSM_DONE(1);
+        {
+            const REAL mx = (REAL)0.5 * (back[0] + cur[0]), mz = (REAL)0.5 * (back[1] + cur[1]);
+            const uint32_t c = SFX(cellno2d)(g, mx, mz);
+            const REAL v = SFX(dist2d)(cur[0], cur[1], back[0], back[1]);
+            FSM_BOOK(c, v);
+            if (sc) slown = sc[c];
+            else { s2 = SFX(fsm_interp2d)(g, sn, cur[0], cur[1]); slown = 0.5 * (s1 + s2); s1 = s2; }
+            tt += slown * v;
+            FSM_PUSHL(cur);
+        }
+        for (int ns = 0; ns < n_src; ++ns) {
+            const REAL* tx = src + 2 * ns;
+            const REAL dist = SFX(dist2d)(cur[0], cur[1], tx[0], tx[1]);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1];
+                SFX(step2d)(g, i, k, cur, gv);
+                if (SFX(dist2d)(cur[0], cur[1], back[0], back[1]) > dist || (cur[0] == tx[0] && cur[1] == tx[1])) {
+                    const uint32_t c = SFX(cellno2d)(g, tx[0], tx[1]);
+                    const REAL v = SFX(dist2d)(tx[0], tx[1], back[0], back[1]);
+                    FSM_BOOK(c, v);
+                    if (sc) slown = sc[c];
+                    else { s2 = SFX(fsm_interp2d)(g, sn, tx[0], tx[1]); slown = 0.5 * (s1 + s2); }
+                    tt += slown * v;
+                    if (with_rays) FSM_PUSHL(tx);
+                } else {
+                    const REAL mx = (REAL)0.5 * (back[0] + cur[0]), mz = (REAL)0.5 * (back[1] + cur[1]);
+                    uint32_t c = SFX(cellno2d)(g, mx, mz);
+                    REAL v = SFX(dist2d)(cur[0], cur[1], back[0], back[1]);
+                    FSM_BOOK(c, v);
+                    if (sc) slown = sc[c];
+                    else { s2 = SFX(fsm_interp2d)(g, sn, cur[0], cur[1]); slown = 0.5 * (s1 + s2); s1 = s2; }
+                    tt += slown * v;
+                    FSM_PUSHL(cur);
+                    const uint32_t c2 = SFX(cellno2d)(g, tx[0], tx[1]);
+                    const REAL hop = SFX(dist2d)(tx[0], tx[1], back[0], back[1]);
+                    if (c == c2) v += hop; else { c = c2; v = hop; }
+                    FSM_BOOK(c, v);
+                    if (sc) slown = sc[c];
+                    else { s2 = SFX(fsm_interp2d)(g, sn, tx[0], tx[1]); slown = 0.5 * (s1 + s2); }
+                    tt += slown * (with_rays ? hop : v);
+                    if (with_rays) FSM_PUSHL(tx);
+                }
+                tt += t0[ns];
+                reached = 1;
+            }
+        }
+    }
+    FSM_DONE(over ? 3 : 0);
+#undef FSM_PUSHL
+#undef FSM_BOOK
+#undef FSM_DONE
+}
+
 #undef FSM_SMALL
 #undef FSM_SMALL2

@@ -357,8 +357,10 @@ def compute_slowness2d(dtype, ncells, dx, dz, origin, slowness, pts, cell_slowne
 
 
 def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-            cell_slowness=False, rcv=None, weno=False, rotated=False, tt_from_rp=False, return_rays=False):
-    """Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (rotated: sweep45 after every sweep, ttcr/Grid2Drnfs.h:277-286;
+            cell_slowness=False, rcv=None, weno=False, rotated=False, tt_from_rp=False, return_rays=False, compute_L=False):
+    """compute_L: the overloads with l_data (ttcr/Grid2D.h:583-640): out["l"] = per receiver (cells, lengths) sorted by cell
+    (stable -- the reference's std::sort may order the entries of ONE cell differently), traveltimes of that overload.
+    Restatement of Grid2Drnfs / Grid2Drcfs ::raytrace (rotated: sweep45 after every sweep, ttcr/Grid2Drnfs.h:277-286;
     tt_from_rp / return_rays: Grid2Drn::getTraveltimeFromRaypath / getRaypath, ttcr/Grid2Drn.h:1478-1850)."""
     dt = np.dtype(dtype)
     sfx, ct, _, G2 = _TYPES[dt]
@@ -393,7 +395,39 @@ def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, max
         r_chk = _prep_pts(dt, rcv, 2)
         if getattr(L, "fsm_outside2d_" + sfx)(C.byref(g), C.c_int(r_chk.shape[0]), _p(r_chk)):   # Grid2Drnfs::raytrace: checkPts(Rx)
             raise RuntimeError("Error: Point outside grid.")
-    if rcv is not None and (tt_from_rp or return_rays):
+    if rcv is not None and compute_L:
+        r = _prep_pts(dt, rcv, 2)
+        fl = getattr(L, "fsm_raypath2d_l_" + sfx)
+        vals = np.empty(r.shape[0], dtype=dt)
+        rays, ls = [], []
+        cap = 4 * (ncx + ncz) + 64
+        sc_p = _p(s) if cell_slowness else None
+        for n, pnt in enumerate(r):
+            pp = np.ascontiguousarray(pnt, dtype=dt)
+            v = ct(0)
+            while True:
+                buf = np.empty((cap, 2), dtype=dt)
+                lc = np.empty(cap, dtype=np.int64)
+                lv = np.empty(cap, dtype=dt)
+                npts, nl = C.c_long(0), C.c_long(0)
+                rc = fl(C.byref(g), _p(sn), sc_p, _p(T), C.c_int(nsrc), _p(src), _p(t0), _p(pp), C.c_int(int(return_rays)),
+                        C.c_long(1000000), C.byref(v), _p(buf), C.c_long(cap), C.byref(npts), _p(lc), _p(lv), C.c_long(cap), C.byref(nl))
+                if rc != 3:
+                    break
+                cap *= 4
+            if rc == 1:
+                raise RuntimeError("Error while computing raypaths: going outside grid")
+            if rc == 2:
+                raise RuntimeError("raypath did not reach the source")
+            vals[n] = v.value
+            rays.append(buf[:npts.value].copy())
+            o = np.argsort(lc[:nl.value], kind="stable")
+            ls.append((lc[:nl.value][o].copy(), lv[:nl.value][o].copy()))
+        out["tt_rcv"] = vals
+        out["l"] = ls
+        if return_rays:
+            out["rays"] = rays
+    elif rcv is not None and (tt_from_rp or return_rays):
         r = _prep_pts(dt, rcv, 2)
         frp = getattr(L, "fsm_raypath2d_" + sfx)
         vals = np.empty(r.shape[0], dtype=dt)
@@ -428,7 +462,7 @@ def solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, max
 
 
 def ref_solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5, maxit=50,
-                cell_slowness=False, rcv=None, weno=False, rotated=False, tt_from_rp=False, return_rays=False):
+                cell_slowness=False, rcv=None, weno=False, rotated=False, tt_from_rp=False, return_rays=False, compute_L=False):
     dt = np.dtype(dtype)
     sfx, ct = _TYPES[dt][:2]
     R = ref()
@@ -448,6 +482,11 @@ def ref_solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5,
             rbuf = np.empty((cap, 2), dtype=np.float64)
             roff = np.zeros(r.shape[0] + 1, dtype=np.int64)
             R.ref_set_rays(_p(rbuf), C.c_long(cap), _p(roff))
+        if compute_L:
+            lcb = np.empty(cap, dtype=np.int64)
+            lvb = np.empty(cap, dtype=np.float64)
+            loff = np.zeros(r.shape[0] + 1, dtype=np.int64)
+            R.ref_set_l(_p(lcb), _p(lvb), C.c_long(cap), _p(loff))
         try:
             rc = getattr(R, "ref_fsm2d_" + sfx)(C.c_int(int(cell_slowness)), C.c_uint32(ncx), C.c_uint32(ncz), ct(dx),
                                                 ct(dz), ct(origin[0]), ct(origin[1]), ct(eps), C.c_int(maxit),
@@ -457,14 +496,19 @@ def ref_solve2d(dtype, ncells, dx, dz, origin, slowness, src, t0=None, eps=1e-5,
         finally:
             if return_rays:
                 R.ref_set_rays(None, C.c_long(0), None)
+            if compute_L:
+                R.ref_set_l(None, None, C.c_long(0), None)
         if rc != 0:
             raise RuntimeError(R.ref_last_error().decode())
-        if not return_rays or roff[-1] <= cap:
+        need = max(int(roff[-1]) if return_rays else 0, int(loff[-1]) if compute_L else 0)
+        if need <= cap:
             break
-        cap = int(roff[-1])
+        cap = need
     out = dict(tt=T, niter=int(niter[0]), niterw=int(niter[1]), tt_rcv=tt_rcv)
     if return_rays:
         out["rays"] = [rbuf[roff[n]:roff[n + 1]].astype(dt) for n in range(r.shape[0])]
+    if compute_L:
+        out["l"] = [(lcb[loff[n]:loff[n + 1]].copy(), lvb[loff[n]:loff[n + 1]].astype(dt)) for n in range(r.shape[0])]
     return out
 
 

@@ -62,6 +62,19 @@ extern "C" void ref_set_m(long long* j, double* v, long cap, long* off) {
     g_m_cap = cap;
     g_m_off = off;
 }
+// when set, the next 2-D solve uses the overload with l_data, Grid2D::raytrace(Tx,t0,Rx,tt,[r_data,]l_data,threadNo)
+// (ttcr/Grid2D.h:583-640; with r_data when ref_set_rays is on as well): the (cell, length) entries of receiver n, sorted as the
+// reference sorts them, occupy [off[n], off[n+1])
+static thread_local long long* g_l_i = nullptr;
+static thread_local double* g_l_v = nullptr;
+static thread_local long g_l_cap = 0;
+static thread_local long* g_l_off = nullptr;
+extern "C" void ref_set_l(long long* cell, double* v, long cap, long* off) {
+    g_l_i = cell;
+    g_l_v = v;
+    g_l_cap = cap;
+    g_l_off = off;
+}
 extern "C" void ref_set_save(const char* base, int all, int format) {
     g_save_base = base ? base : "";
     g_save_all = all;
@@ -131,7 +144,32 @@ static int run2d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
         std::vector<T> vt0(t0, t0 + n_src), tt;
         for (int n = 0; n < n_src; ++n) Tx[n] = {src_xz[2 * n], src_xz[2 * n + 1]};
         for (int n = 0; n < n_rcv; ++n) Rx[n] = {rcv_xz[2 * n], rcv_xz[2 * n + 1]};
-        if (g_ray_buf) {   // Grid2D::raytrace(Tx,t0,Rx,tt,r_data,threadNo): xz pairs
+        if (g_l_i) {   // the overloads with l_data
+            std::vector<std::vector<sxz<T>>> r_data;
+            std::vector<std::vector<siv<T>>> l_data;
+            if (g_ray_buf) static_cast<Grid2D<T, uint32_t, sxz<T>>&>(g).raytrace(Tx, vt0, Rx, tt, r_data, l_data, 0);
+            else static_cast<Grid2D<T, uint32_t, sxz<T>>&>(g).raytrace(Tx, vt0, Rx, tt, l_data, 0);
+            long k = 0;
+            for (int n = 0; n < n_rcv; ++n) {
+                g_l_off[n] = k;
+                for (const auto& e : l_data[n]) {
+                    if (k < g_l_cap) { g_l_i[k] = (long long)e.i; g_l_v[k] = e.v; }
+                    ++k;
+                }
+            }
+            g_l_off[n_rcv] = k;
+            if (g_ray_buf) {
+                k = 0;
+                for (int n = 0; n < n_rcv; ++n) {
+                    g_ray_off[n] = k;
+                    for (const auto& p : r_data[n]) {
+                        if (k < g_ray_cap) { g_ray_buf[2 * k] = p.x; g_ray_buf[2 * k + 1] = p.z; }
+                        ++k;
+                    }
+                }
+                g_ray_off[n_rcv] = k;
+            }
+        } else if (g_ray_buf) {   // Grid2D::raytrace(Tx,t0,Rx,tt,r_data,threadNo): xz pairs
             std::vector<std::vector<sxz<T>>> r_data;
             static_cast<Grid2D<T, uint32_t, sxz<T>>&>(g).raytrace(Tx, vt0, Rx, tt, r_data, 0);
             long k = 0;

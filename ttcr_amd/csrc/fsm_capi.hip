@@ -102,6 +102,10 @@ class GridBase {
     virtual void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) = 0;
     virtual void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const = 0;
     virtual void get_slot_m(int slot, long long* row_off, long long* j, void* v) const = 0;
+    // the raytrace overloads with l_data (2-D cell grids): ray-projection matrix L, one CSR row per receiver
+    virtual void raytrace_l(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool with_rays) = 0;
+    virtual void slot_l_size(int slot, size_t* n_rows, size_t* nnz) const = 0;
+    virtual void get_slot_l(int slot, long long* row_off, long long* cell, void* v) const = 0;
     virtual void validate_points(int n_tx, const void* tx, int n_rx, const void* rx) = 0;   // throws like raytrace would
     // single-source calls that arrive together (ttcrpy's thread pool: nt host threads, one slot each) are solved together
     struct Request {
@@ -1716,6 +1720,119 @@ class GridT : public GridBase {
         }
     }
 
+    // ---- matrix L (the raytrace overloads with l_data, ttcr/Grid2D.h:583-640 -> Grid2Drn::getRaypath(Tx, t0, Rx, [r_data,] l_data,
+    // tt, threadNo), ttcr/Grid2Drn.h:1852-2190): per receiver the (cell, length) entries of its ray, sorted by cell with the
+    // reference's comparator (CompareSiv_i, ttcr/ttcr_t.h:417-422, std::sort -- entries of one cell keep whatever order that
+    // gives them, like in the reference).  The walk is a kernel of its own (fsm_raypath2d_l).
+    std::vector<std::vector<long long>> slot_l_off, slot_l_cell;
+    std::vector<std::vector<T>> slot_l_val;
+    DevBuf<uint32_t> d_lcell;
+    DevBuf<T> d_lval;
+    DevBuf<int> d_lnum;
+    void raytrace_l(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool with_rays) override {
+        HIP_CHECK(hipSetDevice(device));
+        check_slot(slot);
+        if (dim != 2) throw Unsupported("compute_L defined for the FSM");   // (3-D: ttcrpy itself raises, rgrid.pyx:916-917)
+        if (!cell) throw Unsupported("compute_L defined only for grids with slowness defined for cells");
+        if (n_tx < 1) throw ValueError("every source needs at least one point");
+        // the solve (Grid2D::raytrace(Tx, t0, Rx, threadNo)), without receivers: the walk below gives the traveltimes
+        {
+            const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, 0};
+            const int keep_ttrp = ttrp;
+            ttrp = 0;
+            try { raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot); } catch (...) { ttrp = keep_ttrp; throw; }
+            ttrp = keep_ttrp;
+        }
+        if (slot_l_off.empty()) { slot_l_off.assign(n_slots, std::vector<long long>{0}); slot_l_cell.resize(n_slots); slot_l_val.resize(n_slots); }
+        if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
+        const int ps = P(slot);
+        std::vector<long long>& loff = slot_l_off[slot];
+        std::vector<long long>& lcell = slot_l_cell[slot];
+        std::vector<T>& lval = slot_l_val[slot];
+        loff.assign(1, 0); lcell.clear(); lval.clear();
+        slot_rays_off[slot].assign(1, 0); slot_rays_pts[slot].clear();
+        if (n_rx <= 0) return;
+        check_pts((const T*)rx_v, n_rx);
+        T* tt_out = (T*)tt_out_v;
+        d_rsrc.reserve(2 * (size_t)n_tx);
+        d_rt0.reserve(n_tx);
+        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, tx_v, sizeof(T) * 2 * n_tx, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0_v, sizeof(T) * n_tx, hipMemcpyHostToDevice, stream));
+        RayGeom2<T> rg2;
+        rg2.nnx = ncx + 1; rg2.nnz = ncz + 1;
+        rg2.dx = dx; rg2.dz = dz; rg2.xmin = xmin; rg2.zmin = zmin; rg2.xmax = xmax; rg2.zmax = zmax;
+        const long max_steps = walk_step_limit;
+        long cap = std::min<long>(max_steps, 8L * ((long)ncx + ncz + 3)) + 4;
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rx, ((size_t)256 << 20) / (sizeof(T) * 4 * cap)));
+        std::vector<int> st(chunk), np(chunk), nl(chunk);
+        std::vector<uint32_t> hc;
+        std::vector<T> hv, hp;
+        for (int c0 = 0; c0 < n_rx; c0 += chunk) {
+            const int m = std::min(chunk, n_rx - c0);
+            const T* pc = (const T*)rx_v + 2 * (size_t)c0;
+            d_rx.reserve(2 * (size_t)m); d_out.reserve(m); d_rstat.reserve(m); d_raynp.reserve(m); d_lnum.reserve(m);
+            HIP_CHECK(hipMemcpyAsync(d_rx.p, pc, sizeof(T) * 2 * m, hipMemcpyHostToDevice, stream));
+            for (int attempt = 0;; ++attempt) {
+                if (with_rays) d_raypts.reserve((size_t)m * cap * 2);
+                d_lcell.reserve((size_t)m * cap); d_lval.reserve((size_t)m * cap);
+                const dim3 rgrid((m + 63) / 64), rblock(64);
+                if (with_rays)
+                    fsm_raypath2d_l<T, true><<<rgrid, rblock, 0, stream>>>(tt_ptr(ps), NS, d_s.p, d_cells.p, rg2, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m, d_out.p,
+                                                                           d_rstat.p, max_steps, d_raypts.p, cap, d_raynp.p, d_lcell.p, d_lval.p, cap, d_lnum.p);
+                else
+                    fsm_raypath2d_l<T, false><<<rgrid, rblock, 0, stream>>>(tt_ptr(ps), NS, d_s.p, d_cells.p, rg2, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m, d_out.p,
+                                                                            d_rstat.p, max_steps, nullptr, 0, d_raynp.p, d_lcell.p, d_lval.p, cap, d_lnum.p);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemcpyAsync(tt_out + c0, d_out.p, sizeof(T) * m, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(nl.data(), d_lnum.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+                if (with_rays) HIP_CHECK(hipMemcpyAsync(np.data(), d_raynp.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                long need = 0;
+                for (int q = 0; q < m; ++q) {
+                    if (st[q] == 1 || st[q] == 2) throw_walk_error(st[q], pc + 2 * (size_t)q, (const T*)tx_v, max_steps);
+                    if (st[q] == 3) need = std::max<long>(need, std::max<long>(nl[q], with_rays ? np[q] : 0) + 1);
+                }
+                if (need == 0) break;
+                if (attempt > 2) throw DeviceError("raypath: a long ray did not retrace to the same length");
+                cap = need;   // a ray longer than a row: the chunk once more with the room it asked for
+            }
+            hc.resize((size_t)m * cap); hv.resize((size_t)m * cap);
+            HIP_CHECK(hipMemcpyAsync(hc.data(), d_lcell.p, sizeof(uint32_t) * (size_t)m * cap, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(hv.data(), d_lval.p, sizeof(T) * (size_t)m * cap, hipMemcpyDeviceToHost, stream));
+            if (with_rays) { hp.resize((size_t)m * cap * 2); HIP_CHECK(hipMemcpyAsync(hp.data(), d_raypts.p, sizeof(T) * (size_t)m * cap * 2, hipMemcpyDeviceToHost, stream)); }
+            HIP_CHECK(hipStreamSynchronize(stream));
+            struct Siv { size_t i; T v; };
+            std::vector<Siv> row;
+            for (int q = 0; q < m; ++q) {
+                row.resize(nl[q]);
+                for (int e = 0; e < nl[q]; ++e) { row[e].i = hc[(size_t)q * cap + e]; row[e].v = hv[(size_t)q * cap + e]; }
+                std::sort(row.begin(), row.end(), [](const Siv n1, const Siv n2) { return n1.i < n2.i; });   // CompareSiv_i
+                for (const Siv& e : row) { lcell.push_back((long long)e.i); lval.push_back(e.v); }
+                loff.push_back((long long)lcell.size());
+                if (with_rays) {
+                    slot_rays_pts[slot].insert(slot_rays_pts[slot].end(), hp.begin() + (size_t)q * cap * 2, hp.begin() + ((size_t)q * cap + np[q]) * 2);
+                    slot_rays_off[slot].push_back(slot_rays_off[slot].back() + np[q]);
+                }
+            }
+        }
+    }
+    void slot_l_size(int slot, size_t* n_rows, size_t* nnz) const override {
+        check_slot(slot);
+        if (slot_l_off.empty()) { *n_rows = 0; *nnz = 0; return; }
+        *n_rows = slot_l_off[slot].size() - 1;
+        *nnz = slot_l_cell[slot].size();
+    }
+    void get_slot_l(int slot, long long* row_off, long long* cellno, void* v) const override {
+        check_slot(slot);
+        if (slot_l_off.empty()) { row_off[0] = 0; return; }
+        std::memcpy(row_off, slot_l_off[slot].data(), slot_l_off[slot].size() * sizeof(long long));
+        if (!slot_l_cell[slot].empty()) {
+            std::memcpy(cellno, slot_l_cell[slot].data(), slot_l_cell[slot].size() * sizeof(long long));
+            std::memcpy(v, slot_l_val[slot].data(), slot_l_val[slot].size() * sizeof(T));
+        }
+    }
+
     // rays of the last raytrace_rays call of every slot
     std::vector<std::vector<long long>> slot_rays_off;
     std::vector<std::vector<T>> slot_rays_pts;
@@ -1984,6 +2101,13 @@ class MultiGrid : public GridBase {
         timing = g.timing;
     }
     void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const override { int l; GridBase& g = of(slot, l); g.slot_m_size(l, n_rows, nnz); }
+    void raytrace_l(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool with_rays) override {
+        int l; GridBase& g = of(slot, l);
+        g.raytrace_l(l, n_tx, tx, t0, n_rx, rx, tt_out, with_rays);
+        timing = g.timing;
+    }
+    void slot_l_size(int slot, size_t* n_rows, size_t* nnz) const override { int l; GridBase& g = of(slot, l); g.slot_l_size(l, n_rows, nnz); }
+    void get_slot_l(int slot, long long* row_off, long long* cellno, void* v) const override { int l; GridBase& g = of(slot, l); g.get_slot_l(l, row_off, cellno, v); }
     void get_slot_m(int slot, long long* row_off, long long* j, void* v) const override { int l; GridBase& g = of(slot, l); g.get_slot_m(l, row_off, j, v); }
     void slot_rays_size(int slot, size_t* n_rays, size_t* n_points) const override { int l; GridBase& g = of(slot, l); g.slot_rays_size(l, n_rays, n_points); }
     void get_slot_rays(int slot, long long* offsets, void* pts) const override { int l; GridBase& g = of(slot, l); g.get_slot_rays(l, offsets, pts); }
@@ -2451,6 +2575,19 @@ int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_
 }
 int ttcr_fsm_get_slot_m(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* j, void* v) {
     return guarded_on(g, [&] { g->impl->get_slot_m(slot, row_off, j, v); });
+}
+int ttcr_fsm_raytrace_l(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                        void* tt_out, int with_rays) {
+    return guarded_on(g, [&] { g->impl->raytrace_l(slot, n_tx, tx, t0, n_rx, rx, tt_out, with_rays != 0); });
+}
+int ttcr_fsm_slot_l_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz) {
+    return guarded_on(g, [&] {
+        if (!n_rows || !nnz) throw ValueError("null output pointer");
+        g->impl->slot_l_size(slot, n_rows, nnz);
+    });
+}
+int ttcr_fsm_get_slot_l(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* cell, void* v) {
+    return guarded_on(g, [&] { g->impl->get_slot_l(slot, row_off, cell, v); });
 }
 int ttcr_fsm_slot_rays_size(const ttcr_fsm_grid* g, int slot, size_t* n_rays, size_t* n_points) {
     return guarded_on(g, [&] {

@@ -2902,6 +2902,110 @@ __global__ void fsm_raypath2d(const T* __restrict__ Tn, int ts, const T* __restr
     finish(0, tt);
 }
 
+// Grid2Drn::getRaypath with l_data -- the ray-projection matrix L of a cell grid (compute_L of ttcrpy):
+//   RAYS = true : getRaypath(Tx, t0, Rx, r_data, l_data, tt, threadNo), ttcr/Grid2Drn.h:1852-2021
+//   RAYS = false: getRaypath(Tx, t0, Rx, l_data, tt, threadNo), :2023-2190
+// A walk of its own, not the one of fsm_raypath2d: a step that leaves the grid is an error at once (no second try along the
+// face), every segment is booked to the cell of its mid-point (cell index, length) in push order, and the two overloads
+// differ where the reference does: without r_data the traveltime of the last hop is slowness x the ENTRY's value, which
+// is the sum of the two last segments when both lie in one cell (:2168-2181) -- that entry is pushed beside the entry of
+// the segment before it, not instead of it.  sc: the cell slowness (a Grid2Drcfs); sn is used when sc is null.
+// status 1: outside the grid, 2: step limit, 3: a row overflowed (np / nl hold what was needed).
+template <typename T, bool RAYS>
+__global__ void fsm_raypath2d_l(const T* __restrict__ Tn, int ts, const T* __restrict__ sn, const T* __restrict__ sc, RayGeom2<T> g, int n_src,
+                                const T* __restrict__ src, const T* __restrict__ t0, const T* __restrict__ rcv, int n_rcv,
+                                T* __restrict__ out, int* __restrict__ status, long max_steps, T* __restrict__ pts, long cap,
+                                int* __restrict__ npts, uint32_t* __restrict__ lcell, T* __restrict__ lval, long lcap, int* __restrict__ nlen) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rcv) return;
+    const T rx[2] = {rcv[2 * r], rcv[2 * r + 1]};
+    long np = 0, nl = 0;
+    T* my_pts = RAYS ? pts + (size_t)r * cap * 2 : nullptr;
+    uint32_t* my_c = lcell + (size_t)r * lcap;
+    T* my_v = lval + (size_t)r * lcap;
+    T back[2] = {rx[0], rx[1]}, cur[2] = {rx[0], rx[1]}, gv[2];
+    auto push = [&](const T* p) {   // r_data.push_back (RAYS) / prev_pt = (the other overload)
+        if (RAYS) { if (np < cap) { my_pts[2 * np] = p[0]; my_pts[2 * np + 1] = p[1]; } ++np; }
+        back[0] = p[0]; back[1] = p[1];
+    };
+    auto book = [&](uint32_t c, T v) { if (nl < lcap) { my_c[nl] = c; my_v[nl] = v; } ++nl; };
+    auto finish = [&](int st, T tt) {
+        if (RAYS) npts[r] = (int)np;
+        nlen[r] = (int)nl;
+        if (st == 0 && ((RAYS && np > cap) || nl > lcap)) st = 3;
+        status[r] = st;
+        out[r] = tt;
+    };
+    auto slow = [&](T px, T pz) { return interp2d_pt(sn, 1, g.nnx, g.nnz, g.dx, g.dz, g.xmin, g.zmin, px, pz); };
+    if (RAYS) { if (np < cap) { my_pts[0] = rx[0]; my_pts[1] = rx[1]; } ++np; }
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[2 * ns] && rx[1] == src[2 * ns + 1]) { finish(0, t0[ns]); return; }
+    T tt = 0, s1 = 0, s2 = 0, slown = 0;
+    if (!sc) s1 = slow(cur[0], cur[1]);
+    const T maxDist = (T)__builtin_sqrt((double)(g.dx * g.dx + g.dz * g.dz));
+    bool reached = false;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) { finish(2, tt); return; }
+        grad2d(g, Tn, ts, cur[0], cur[1], gv);
+        gv[0] *= (T)-1.0; gv[1] *= (T)-1.0;
+        const double small = 1.e-4;
+        const long i = (long)(small + (double)((cur[0] - g.xmin) / g.dx));
+        const long k = (long)(small + (double)((cur[1] - g.zmin) / g.dz));
+        step2d(g, i, k, cur, gv);
+        if (cur[0] < g.xmin || cur[0] > g.xmax || cur[1] < g.zmin || cur[1] > g.zmax) { finish(1, tt); return; }
+        {
+            const T mx = (T)0.5 * (back[0] + cur[0]), mz = (T)0.5 * (back[1] + cur[1]);
+            const uint32_t c = cellno2d(g, mx, mz);
+            const T v = dist2(cur, back);
+            book(c, v);
+            if (sc) slown = sc[c];
+            else { s2 = slow(cur[0], cur[1]); slown = (T)(0.5 * (double)(s1 + s2)); s1 = s2; }
+            tt += slown * v;
+            push(cur);
+        }
+        for (int ns = 0; ns < n_src; ++ns) {
+            const T tx[2] = {src[2 * ns], src[2 * ns + 1]};
+            const T dist = dist2(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1];
+                step2d(g, i, k, cur, gv);
+                if (dist2(cur, back) > dist || (cur[0] == tx[0] && cur[1] == tx[1])) {   // no intersection, or arrived
+                    const uint32_t c = cellno2d(g, tx[0], tx[1]);
+                    const T v = dist2(tx, back);
+                    book(c, v);
+                    if (sc) slown = sc[c];
+                    else { s2 = slow(tx[0], tx[1]); slown = (T)(0.5 * (double)(s1 + s2)); }
+                    tt += slown * v;
+                    if (RAYS) push(tx);
+                } else {
+                    // to the intersection ...
+                    const T mx = (T)0.5 * (back[0] + cur[0]), mz = (T)0.5 * (back[1] + cur[1]);
+                    uint32_t c = cellno2d(g, mx, mz);
+                    T v = dist2(cur, back);
+                    book(c, v);
+                    if (sc) slown = sc[c];
+                    else { s2 = slow(cur[0], cur[1]); slown = (T)(0.5 * (double)(s1 + s2)); s1 = s2; }
+                    tt += slown * v;
+                    push(cur);
+                    // ... and on to the source point: the entry is kept and extended when the cell is the same
+                    const uint32_t c2 = cellno2d(g, tx[0], tx[1]);
+                    const T hop = dist2(tx, back);
+                    if (c == c2) v += hop; else { c = c2; v = hop; }
+                    book(c, v);
+                    if (sc) slown = sc[c];
+                    else { s2 = slow(tx[0], tx[1]); slown = (T)(0.5 * (double)(s1 + s2)); }
+                    tt += slown * (RAYS ? hop : v);   // (with r_data: the hop, :2009; without: the entry's value, :2181)
+                    if (RAYS) push(tx);
+                }
+                tt += t0[ns];
+                reached = true;
+            }
+        }
+    }
+    finish(0, tt);
+}
+
 // rays recorded in fixed-capacity rows -> one dense array, 2-D (x, z) pairs
 template <typename T>
 __global__ void fsm_compact_rays2(const T* __restrict__ pts, long cap, const long long* __restrict__ off, T* __restrict__ out) {

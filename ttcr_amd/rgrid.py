@@ -805,11 +805,11 @@ class _Grid2d(_GridBase):
             raise NotImplementedError('Anisotropic raytracing implemented only for SPM')
         if compute_L and not self.cell_slowness:
             raise NotImplementedError('compute_L defined only for grids with slowness defined for cells')
-        if compute_L:
-            raise NotImplementedError('compute_L is not built for the FSM grids (straight-ray L: data_kernel_straight_rays)')
         vTx, vt0, vRx, iRx = self._split_sources(source, rcv, aggregate_src)
         if slowness is not None:
             self.set_slowness(slowness)
+        if compute_L:
+            return self._run_l(vTx, vt0, vRx, iRx, rcv.shape[0], return_rays)
         if not return_rays:
             return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no)
         # -> (tt, rays): Grid2D::raytrace(Tx,t0,Rx,tt,r_data,threadNo) -> Grid2Drn::getRaypath (ttcr/Grid2Drn.h:1663-1850)
@@ -818,6 +818,49 @@ class _Grid2d(_GridBase):
             return self._run(vTx, vt0, vRx, iRx, rcv.shape[0], thread_no, return_rays=True)
         finally:
             self.set_option("return_rays", 0)
+
+
+    def _run_l(self, vTx, vt0, vRx, iRx, n_rcv, return_rays):
+        """compute_L=True (rgrid.pyx:3996-4010, :4043-4143): per event the overload with l_data (and r_data), one scipy CSR matrix
+        (receivers of the event x cells) per event with the entries in the order the reference's loops emit them (ascending cell,
+        entries of one cell in the order of the sorted l_data), stacked, then rows taken as `tmp[itmp, :]` like the reference does."""
+        import scipy.sparse as sp
+
+        dt = self._dtype
+        tt = np.zeros((n_rcv,), dtype=dt)
+        rays = [[0.0] for _ in range(n_rcv)]
+        L = []
+        NN = self.get_number_of_cells()
+        for n in range(len(vTx)):
+            slot = n % self._n_threads
+            tx = np.ascontiguousarray(vTx[n], dtype=dt)
+            t0 = np.ascontiguousarray(vt0[n], dtype=dt)
+            rx = np.ascontiguousarray(vRx[n], dtype=dt).reshape(-1, 2)
+            out = np.empty(max(rx.shape[0], 1), dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_raytrace_l(self._h, slot, tx.shape[0], _ptr(tx), _ptr(t0), rx.shape[0], _ptr(rx), _ptr(out),
+                                                     1 if return_rays else 0))
+            tt[iRx[n]] = out[:rx.shape[0]]
+            nrow, nnz = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(self._lib.ttcr_fsm_slot_l_size(self._h, slot, C.byref(nrow), C.byref(nnz)))
+            off = np.zeros(nrow.value + 1, dtype=np.int64)
+            jj = np.empty(max(nnz.value, 1), dtype=np.int64)
+            vv = np.empty(max(nnz.value, 1), dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_get_slot_l(self._h, slot, _ptr(off), _ptr(jj), _ptr(vv)))
+            L.append(sp.csr_matrix((vv[:nnz.value].astype(np.float64), jj[:nnz.value], off), shape=(rx.shape[0], NN)))
+            if return_rays:
+                nr, npnt = C.c_size_t(0), C.c_size_t(0)
+                _lib.check(self._lib.ttcr_fsm_slot_rays_size(self._h, slot, C.byref(nr), C.byref(npnt)))
+                roff = np.zeros(nr.value + 1, dtype=np.int64)
+                pts = np.empty((max(npnt.value, 1), 2), dtype=dt)
+                _lib.check(self._lib.ttcr_fsm_get_slot_rays(self._h, slot, _ptr(roff), _ptr(pts)))
+                for k, row in enumerate(iRx[n]):
+                    rays[row] = np.array(pts[roff[k]:roff[k + 1]], dtype=np.float64)
+        tmp = sp.vstack(L).tocsr()
+        itmp = [row for n in range(len(vTx)) for row in iRx[n]]
+        Lm = tmp[itmp, :]
+        if return_rays:
+            return tt, rays, Lm
+        return tt, Lm
 
 
 class Grid2d_d(_Grid2d):
