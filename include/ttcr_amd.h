@@ -170,7 +170,15 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
 /* Tuning / measurement knobs (no reference equivalent):
  *   "fixed_iters"  > 0: run exactly that many sweep-iterations, ignore eps
  *   "max_batch"    sources swept concurrently by one launch sequence (default: n_slots)
- *   "use_graph"    1: replay the per-iteration launch sequence from a hipGraph (default 1)
+ *   "use_graph"    1: the tile-per-launch driver (mode 0) replays its launch sequence from a hipGraph, the persistent drivers
+ *                  launch their kernels directly (default); 0: no graphs; 2: graphs for every driver
+ *   "stopping_rule" 1 (default): an iteration whose fp64 change lies within [1/2, 16] x eps * N (fp64 grids: 1e-6 either side)
+ *                  is decided by the reference's own quantity -- the sequential T1 sum of abs(times[n] - T[n]) over the nodes
+ *                  (ttcr/Grid3Drnfs.h:141-152), computed on the device from a snapshot of the field -- so that the iteration
+ *                  count is the reference's where the two sums differ; 0: the fp64 sum of decreases alone
+ *   "wave"         1: first-order 3-D sweeps of fp32 grids with one field per slot use the one-wavefront kernel
+ *                  (fsm_wave_kernels.h; slower at present, see profiles/r04/wave_kernel.txt); default off
+ *   "pair_sources" 1 (default): the sources of a batch are paired by distance before they share a workgroup two by two
  *   "combine_window_us"  single-source calls from several host threads wait this long for one another before they go
  *                  to the device as one batch (default 200; 0: every call on its own)
  *   "mode"         2: persistent sweep kernel, ONE launch per sweep-iteration: patches ordered by

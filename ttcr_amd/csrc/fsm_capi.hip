@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -141,6 +143,9 @@ class GridBase {
     // point that takes a slot translates.
     std::vector<int> phys;
     int P(int slot) const { return phys.empty() ? slot : phys[slot]; }
+    int stopping_rule = 1;      // option "stopping_rule": 1 the reference's sequential T1 sum decides wherever it could differ from the
+                                // fp64 sum of decreases (default), 0 the fp64 sum alone
+    long long reference_sums = 0, reference_sums_missed = 0;   // decisions taken with the reference's sum / that would have needed a snapshot
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
     virtual void set_wave(int) {}   // option "wave" (GridT)
     // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
@@ -178,6 +183,7 @@ class GridBase {
         else if (k == "return_rays") return_rays = value != 0;
         else if (k == "pair_sources") pair_by_distance = value != 0;
         else if (k == "wave") set_wave((int)value);
+        else if (k == "stopping_rule") stopping_rule = (int)value;
         else throw ValueError("unknown option '" + k + "'");
     }
     virtual void get_niter(int slot, int* it, int* itw) const {
@@ -1087,6 +1093,79 @@ class GridT : public GridBase {
     }
 
     // One batch: sources src_ids[b] solved concurrently, source b in slot slot_ids[b].
+    // ---- the reference's stopping rule where it matters (option stopping_rule = 1) ---------------------------------
+    // Grid3Drnfs::raytrace (ttcr/Grid3Drnfs.h:141-152) sums abs(times[n] - T[n]) over the nodes in order, in T1.  The sweep kernels
+    // accumulate the same quantity as an fp64 sum of decreases; the two agree to a few percent near eps * N at 1.3e8 fp32 nodes
+    // (profiles/r03/stopping_rule_512.txt), so an iteration whose fp64 change lies within [1/2, 16] x eps * N (fp64 grids: 1e-6
+    // either side) is decided by the reference's own sum, computed by fsm_reference_change from a snapshot of the field.  The
+    // snapshot of a slot group is taken before an iteration when the change of the iteration before was below 1e4 x 16 x eps * N
+    // (consecutive iterations differ by factors of 4 - 40); an iteration that lands in the window without one is decided by the
+    // fp64 sum and counted (reference_sums_missed).
+    std::map<int, DevBuf<T>> snap;            // slot group -> field(s) before the current iteration
+    std::vector<int> snap_iter;               // [group] iteration (stage-local, 1-based) the snapshot belongs to, 0: none
+    std::vector<double> prev_change;          // [slot] fp64 change of the iteration before (inf: none yet)
+    DevBuf<size_t> d_ref_off;
+    DevBuf<T> d_ref_out;
+    double window_lo() const { return sizeof(T) == 4 ? 0.5 : 1.0 - 1e-6; }
+    double window_hi() const { return sizeof(T) == 4 ? 16.0 : 1.0 + 1e-6; }
+    void snapshots_before_iteration(const std::vector<int>& active, int it_next) {
+        if (!stopping_rule || fixed_iters > 0) return;
+        if ((int)snap_iter.size() != n_groups()) snap_iter.assign(n_groups(), 0);
+        std::vector<char> done(n_groups(), 0);
+        for (int s2 : active) {
+            const int gi = s2 / NS;
+            if (done[gi] || !(prev_change[s2] < 1e4 * window_hi() * (double)epsilon)) continue;
+            done[gi] = 1;
+            DevBuf<T>& b = snap[gi];
+            b.reserve(n_nodes * (size_t)NS);
+            HIP_CHECK(hipMemcpyAsync(b.p, d_tt.p + (size_t)gi * n_nodes * NS, n_nodes * (size_t)NS * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            snap_iter[gi] = it_next;
+        }
+    }
+    // go on after this iteration?  (active slot s2, its fp64 change c, iteration `it` just done)
+    std::vector<char> decide_go_on(const std::vector<int>& active, int it) {
+        std::vector<char> go(active.size(), 0);
+        std::vector<int> ask;
+        for (size_t q = 0; q < active.size(); ++q) {
+            const int s2 = active[q];
+            const double c = h_change[s2];
+            go[q] = c >= (double)epsilon;
+            if (!stopping_rule || !(c >= window_lo() * (double)epsilon && c <= window_hi() * (double)epsilon)) continue;
+            if ((int)snap_iter.size() == n_groups() && snap_iter[s2 / NS] == it) ask.push_back((int)q);
+            else ++reference_sums_missed;
+        }
+        if (ask.empty()) return go;
+        std::vector<size_t> off(ask.size());
+        // (snapshots of different groups live in different allocations: one launch per group)
+        std::vector<T> res(ask.size());
+        d_ref_off.reserve(1);
+        d_ref_out.reserve(ask.size());
+        for (size_t a = 0; a < ask.size(); ++a) {
+            const int s2 = active[ask[a]], gi = s2 / NS;
+            RefChangeArgs<T> ra;
+            ra.cur = d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS;
+            ra.old = snap[gi].p + s2 % NS;
+            const size_t zero = 0;
+            HIP_CHECK(hipMemcpyAsync(d_ref_off.p, &zero, sizeof(size_t), hipMemcpyHostToDevice, stream));
+            ra.off = d_ref_off.p;
+            ra.out = d_ref_out.p + a;
+            ra.n_nodes = n_nodes;
+            ra.stride = NS;
+            fsm_reference_change<T><<<1, 256, 0, stream>>>(ra);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(stream));   // (`zero` goes out of scope)
+        }
+        HIP_CHECK(hipMemcpyAsync(res.data(), d_ref_out.p, sizeof(T) * ask.size(), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (size_t a = 0; a < ask.size(); ++a) {
+            go[ask[a]] = res[a] >= epsilon;   // `change >= epsilon`, both T1 (ttcr/Grid3Drnfs.h:153)
+            ref_change_last[active[ask[a]]] = (double)res[a];
+            ++reference_sums;
+        }
+        return go;
+    }
+    std::vector<double> ref_change_last;   // [slot] the reference's sum of the last iteration decided with it (NaN: none)
+
     // TTCR_FSM_HOST_PROF=1: wall clock of the host-side phases of a call (stderr), tuning only
     bool host_prof = std::getenv("TTCR_FSM_HOST_PROF") != nullptr;
     std::chrono::steady_clock::time_point hp_t = std::chrono::steady_clock::now();
@@ -1188,6 +1267,9 @@ class GridT : public GridBase {
         for (stage = 0; stage < (weno ? 2 : 1); ++stage) {
             std::vector<int> active(slot_ids);
             int it = 0;
+            prev_change.assign(n_slots, std::numeric_limits<double>::infinity());   // (the first iteration of a stage always runs: no snapshot)
+            snap_iter.assign(n_groups(), 0);
+            if ((int)ref_change_last.size() != n_slots) ref_change_last.assign(n_slots, std::nan(""));
             // batch entries: slot groups for the persistent kernel (with a lane mask), slots otherwise
             std::vector<int> groups;
             for (int s2 : slot_ids)
@@ -1210,6 +1292,7 @@ class GridT : public GridBase {
                 HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemcpyAsync(d_lmask.p, h_lmask, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
+                snapshots_before_iteration(active, it + 1);
                 h_iter[0] = it_total;
                 h_iter[1] = (int)launch_epoch;   // epoch of this iteration's (first) sweep launch
                 launch_epoch += (persistent_now() && mode == 2) ? 1u : (unsigned)ndir;
@@ -1227,12 +1310,14 @@ class GridT : public GridBase {
                 ++it;
                 ++it_total;
                 std::vector<int> next;
-                for (int s2 : active) {
+                const std::vector<char> go = fixed_iters > 0 ? std::vector<char>(active.size(), 1) : decide_go_on(active, it);
+                for (size_t q = 0; q < active.size(); ++q) {
+                    const int s2 = active[q];
                     (stage == 0 ? niter : niterw)[s2] = it;
                     (stage == 0 ? change_hist : change_histw)[s2].push_back(h_change[s2]);
                     timing.node_updates += (long long)n_nodes * ndir;
-                    const bool go_on = fixed_iters > 0 ? true : (h_change[s2] >= (double)epsilon);
-                    if (go_on) next.push_back(s2);
+                    prev_change[s2] = h_change[s2];
+                    if (go[q]) next.push_back(s2);
                 }
                 active.swap(next);
             }

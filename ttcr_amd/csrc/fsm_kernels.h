@@ -2056,6 +2056,71 @@ __global__ void fsm_fill(T* p, size_t n, T v, int stride) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i * stride] = v;
 }
 
+// The reference's stopping rule as it stands (ttcr/Grid3Drnfs.h:141-152, ttcr/Grid2Drnfs.h:265-290): change = sum over the nodes,
+// in node order, in T1, of abs(times[n] - T[n]) with `times` the field before the sweep-iteration.  A sequential sum in the grid's
+// own precision is not the fp64 sum the sweep kernels accumulate (at 1.3e8 fp32 nodes small addends vanish below half an ulp of
+// the accumulator or round up to a whole one); where the two could fall on different sides of eps * N the host asks for this
+// kernel: one workgroup per field, old[] = a snapshot taken before the iteration.  The adds are done in node order by ONE wavefront
+// (lane-uniform arithmetic); adding 0 does not change an IEEE sum, so only the nodes that changed are visited -- the other waves of
+// the workgroup stream the two fields through LDS a tile ahead and mark the 64-node blocks that hold a change.
+template <typename T>
+struct RefChangeArgs {
+    const T* cur;        // [n_fields][node][stride] current fields (entry b: cur + off[b])
+    const T* old;        // the snapshots, same layout
+    const size_t* off;   // element offset of field b in both
+    T* out;              // [n_fields] the reference's `change`
+    size_t n_nodes;
+    int stride;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void fsm_reference_change(const RefChangeArgs<T> a) {
+    constexpr int TILE = 4096;                 // nodes per tile: 16 rounds of 256
+    __shared__ T dbuf[2][TILE];
+    __shared__ unsigned long long mask[2][TILE / 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const T* __restrict__ cur = a.cur + a.off[blockIdx.x];
+    const T* __restrict__ old = a.old + a.off[blockIdx.x];
+    const size_t n = a.n_nodes;
+    const size_t ntiles = (n + TILE - 1) / TILE;
+    T acc = 0;
+    auto fill = [&](size_t t, int buf) {
+#pragma unroll 4
+        for (int r = 0; r < TILE / 256; ++r) {
+            const size_t i = t * TILE + (size_t)r * 256 + tid;
+            T d = 0;
+            if (i < n) {
+                const T df = old[i * a.stride] - cur[i * a.stride];   // times[n] - T[n], in T1
+                d = df < 0 ? -df : df;
+            }
+            dbuf[buf][r * 256 + tid] = d;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(d != (T)0);
+            if (lane == 0) mask[buf][r * 4 + wave] = m;
+        }
+    };
+    fill(0, 0);
+    __syncthreads();
+    for (size_t t = 0; t < ntiles; ++t) {
+        const int buf = (int)(t & 1);
+        // every wave helps to fill the next tile; wave 0 then walks this one
+        if (t + 1 < ntiles) fill(t + 1, buf ^ 1);
+        if (wave == 0) {
+            for (int blk = 0; blk < TILE / 64; ++blk) {
+                unsigned long long m = mask[buf][blk];
+                if (m == 0ull) continue;
+                const T d = dbuf[buf][blk * 64 + lane];
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const T v = __shfl(d, l, 64);   // (lane-uniform: every lane carries the same accumulator)
+                    acc = acc + v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.out[blockIdx.x] = acc;
+}
+
 // de-interleave one source's field for the host (getTT)
 template <typename T>
 __global__ void fsm_gather_field(const T* __restrict__ p, T* __restrict__ out, size_t n, int stride) {
