@@ -120,6 +120,11 @@ def test_bench_runs_under_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
     assert d["config"]["sources_total"] == 6 and d["config"]["sources_per_rank"] == [3, 3]
     assert d["value"] > 0 and d["sources_per_s"] > 0
+    # the line says which collective backend ran and on which device every rank sat: nccl (= RCCL) whenever the box has a GPU per rank --
+    # gloo is only ever accepted on a one-GPU box, where both ranks share device 0
+    assert d["config"]["collective_backend"] == backend and d["config"]["world_size"] == 2 and len(d["config"]["devices"]) == 2
+    if torch.cuda.device_count() >= 2:
+        assert d["config"]["collective_backend"] == "nccl" and d["config"]["devices"][0].split("uuid")[-1] != d["config"]["devices"][1].split("uuid")[-1]
     # whole-job value = nodes x iterations of ALL sources / max-over-ranks time
     it = d["config"]["sweep_iterations_per_source"]
     assert len(it) == 1

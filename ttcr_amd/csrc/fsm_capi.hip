@@ -2629,6 +2629,11 @@ int ttcr_fsm_raytrace(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, cons
             } catch (...) {
                 // (an allocation failed somewhere above: nobody may be left waiting for a leader that is gone)
                 if (batch.empty()) { batch.swap(gb->queue); }
+                // (thrown while the batch was being picked: its requests are still queued -- they are marked done below and their
+                // callers return, so the queue must not keep pointers to them; remove / erase do not allocate)
+                gb->queue.erase(std::remove_if(gb->queue.begin(), gb->queue.end(),
+                                               [&](GridBase::Request* q) { return std::find(batch.begin(), batch.end(), q) != batch.end(); }),
+                                gb->queue.end());
                 for (auto* r : batch)
                     if (r->status == TTCR_OK) { r->status = TTCR_ERR_RUNTIME; r->err = "out of memory while combining raytrace calls"; }
             }

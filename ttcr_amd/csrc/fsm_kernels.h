@@ -789,6 +789,8 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     constexpr int NHI = (NDH + RPI - 1) / RPI;   // passes over the downwind halo columns
     constexpr int NUPI = (NUP + RPI - 1) / RPI;  // passes over the upwind halo columns
     static_assert(NT % C == 0 && (IS3D || PK == 1) && C <= FSM_BRICK && (H == 1 || H == 2), "tile shape");
+    // (the early publish would let a unit's final progress value go out before its brick stamps: round-3 advice)
+    static_assert(!(SKIP && FSM_EARLY_PUB > 0), "FSM_EARLY_PUB is a tuning option of the kernels without exact skipping");
     const SweepArgs<T>& a = pa.s;
     // Launch epoch.  Nothing the kernel synchronises on is reset between the launches of a solve: every word carries the number
     // of the launch that wrote it, and a word of another launch reads as "nothing published" -- what a word held before (the
