@@ -172,10 +172,14 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "max_batch"    sources swept concurrently by one launch sequence (default: n_slots)
  *   "use_graph"    1: the tile-per-launch driver (mode 0) replays its launch sequence from a hipGraph, the persistent drivers
  *                  launch their kernels directly (default); 0: no graphs; 2: graphs for every driver
- *   "stopping_rule" 1 (default): an iteration whose fp64 change lies within [1/2, 16] x eps * N (fp64 grids: 1e-6 either side)
- *                  is decided by the reference's own quantity -- the sequential T1 sum of abs(times[n] - T[n]) over the nodes
- *                  (ttcr/Grid3Drnfs.h:141-152), computed on the device from a snapshot of the field -- so that the iteration
- *                  count is the reference's where the two sums differ; 0: the fp64 sum of decreases alone
+ *   "stopping_rule" 0 (default): an iteration ends the solve when the fp64 sum of the decreases of its nodes is below eps * N --
+ *                  the quantity the reference sums sequentially in T1 (ttcr/Grid3Drnfs.h:141-152); at 1.3e8 fp32 nodes the
+ *                  reference's sum reads 1-3 % low near the threshold, so the counts can differ when an iteration lands there.
+ *                  1: such an iteration (fp64 change within [1/2, 16] x eps * N; fp64 grids: 1e-6 either side) is decided by
+ *                  the reference's own sum, computed on the device in node order from a snapshot of the field taken before the
+ *                  iteration (taken once an iteration has announced that the next may be the last -- never for the second
+ *                  iteration of a stage).  Exact, and slow where it is asked for: the sum is one chain of dependent additions
+ *                  (up to 0.5 s per 512^3 field and iteration); tests/test_stopping_rule_gpu.py
  *   "wave"         1: first-order 3-D sweeps of fp32 grids with one field per slot use the one-wavefront kernel
  *                  (fsm_wave_kernels.h; slower at present, see profiles/r04/wave_kernel.txt); default off
  *   "pair_sources" 1 (default): the sources of a batch are paired by distance before they share a workgroup two by two

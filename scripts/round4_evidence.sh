@@ -29,3 +29,13 @@ PY
 rm -rf $O/raw
 cd $ROOT && python scripts/pmc_to_json.py $O $TAG 512 64 $O/traffic.json
 head -5 $O/${TAG}_kernel_stats.csv | cut -c1-220
+# the other configurations: kernel stats per configuration (one process each)
+cd /tmp && export TMPDIR=/tmp
+for CF in S1 C2 C4 C5 W1 W8; do
+  mkdir -p $O/raw_$CF
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_$CF -o r04_$CF -- python $ROOT/scripts/config_one.py $CF 2 > $O/r04_${CF}_run.txt 2>&1
+  find $O/raw_$CF -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $O/r04_${CF}_kernel_stats.csv
+  rm -rf $O/raw_$CF
+  grep "^$CF:" $O/r04_${CF}_run.txt | tee -a $O/configs.txt
+done
+cd $ROOT
