@@ -27,6 +27,7 @@ while time.time() < t_end:
     src = np.column_stack([rng.uniform(a[1], a[-2], ns) for a in axes])
     if rng.random() < 0.3: src[0] = [a[int(rng.integers(1, a.size - 1))] for a in axes]   # on a node
     rcv = np.column_stack([rng.uniform(a[1], a[-2], ns) for a in axes])
+    os.environ['TTCR_FSM_PAIR'] = '1' if rng.random() < 0.5 else '0'   # (default: pairs for big batches only)
     fields = {}
     # (driver, exact skipping): the whole-iteration launch with the skipping scheduler is the reference of the comparison
     for mode, skip in ((2, 1), (2, 0), (1, 1), (0, 0)):

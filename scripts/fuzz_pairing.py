@@ -3,6 +3,7 @@ than slots: several rounds), max_batch, single-source calls on thread numbers in
 = 1 against one with 0: receiver traveltimes, per-thread fields, iteration counts and change histories must be identical.
 usage: fuzz_pairing.py <seconds> [seed]"""
 import sys, time, os
+os.environ.setdefault('TTCR_FSM_PAIR', '1')   # the pair layout is the default of big batches only: asked for here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, ttcr_amd
 

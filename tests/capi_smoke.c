@@ -87,7 +87,8 @@ int main(void) {
     CHECK(ttcr_fsm_last_timing(g, &tm) == TTCR_OK && tm.n_sources == 1 && tm.iterations == niter, "last_timing");
     void* dptr = NULL;
     size_t stride = 0;
-    CHECK(ttcr_fsm_get_tt_device_view(g, 1, &dptr, &stride) == TTCR_OK && dptr && stride == 2, "get_tt_device_view (2 slots: stride 2)");
+    CHECK(ttcr_fsm_get_tt_device_view(g, 1, &dptr, &stride) == TTCR_OK && dptr && stride == 1,
+          "get_tt_device_view (2 slots of a small grid: contiguous fields, stride 1)");
     CHECK(ttcr_fsm_get_tt_device(g, 1, &dptr) == TTCR_OK && dptr, "get_tt_device");
 
     /* Grid3Drn::checkPts: runtime_error("Error: Point (x y z) outside grid.") -- receiver and source */

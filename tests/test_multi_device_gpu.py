@@ -117,10 +117,11 @@ def test_multi_device_2d_and_env(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pair", [1, 0])
-def test_paired_by_distance_sources_are_found_under_their_thread_numbers(oracle, pair):
+def test_paired_by_distance_sources_are_found_under_their_thread_numbers(oracle, pair, monkeypatch):
     """The batch driver pairs the sources of a call by distance (first-order 3-D grids): whatever slot storage a source ends
     up in, its field, iteration count and change history are found under the thread number the block distribution gives it."""
     import ttcr_amd
+    monkeypatch.setenv("TTCR_FSM_PAIR", "1")   # (pairs are the layout of big batches: asked for on this small grid)
     n = 33
     x = np.arange(n) * 0.5
     rng = np.random.default_rng(5)

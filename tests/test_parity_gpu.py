@@ -616,7 +616,7 @@ def test_hip_one_grid_from_several_host_threads(oracle):
             assert niter == o["niter"]
 
 
-def test_hip_device_views_of_a_field():
+def test_hip_device_views_of_a_field(monkeypatch):
     """ttcr_fsm_get_tt_device: n_nodes contiguous values; ttcr_fsm_get_tt_device_view: the field where it lies + stride
     (2 where two slots share an interleaved field: first-order 3-D grids with n_threads >= 2).  The raw device pointers are consumed the way a zero-copy consumer would:
     handed to another grid as device-resident input (set_slowness_device) and read back from there."""
@@ -631,11 +631,16 @@ def test_hip_device_views_of_a_field():
     sink2 = ttcr_amd.Grid3d(np.arange(2 * n) * 0.5, x, x, cell_slowness=0, method="FSM", dtype=np.float32)   # 2 nn values
     # (one slot; three slots of a first-order grid: interleaved pairs; three slots with weno=1: one field per slot)
     # (pair: the sources of a call paired by distance -- a slot's field may lie in another slot's storage -- or not)
-    for nthr, weno, want_stride, pair in ((1, 0, 1, 1), (3, 0, 2, 1), (3, 0, 2, 0), (3, 1, 1, 1)):
+    # (source pairs are the layout of big batches -- slots x patches > 12 288 --; on this small grid they are asked for)
+    for nthr, weno, want_stride, pair in ((1, 0, 1, 1), (3, 0, 2, 1), (3, 0, 2, 0), (3, 1, 1, 1), (3, 0, 1, 1)):
+        if want_stride == 2:
+            monkeypatch.setenv("TTCR_FSM_PAIR", "1")
+        else:
+            monkeypatch.delenv("TTCR_FSM_PAIR", raising=False)
         g = ttcr_amd.Grid3d(x, x, x, n_threads=nthr, cell_slowness=0, method="FSM", tt_from_rp=0, weno=weno, dtype=np.float32)
         g.set_option("pair_sources", pair)
         srcs = rng.uniform(0.5, 9.0, (nthr, 3))
-        if pair and nthr == 3:
+        if pair and nthr == 3 and want_stride == 2:
             srcs[2] = srcs[0] + 0.2   # sources 0 and 2 end up in one pair
         g.raytrace(srcs, np.zeros((nthr, 3)), slowness=s)
         fields = [g._flat_tt(k) for k in range(nthr)]
