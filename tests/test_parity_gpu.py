@@ -199,6 +199,30 @@ def test_hip_weno_matches_oracle_multi_patch(oracle, kind):
     np.testing.assert_array_equal(r["tt"], o["tt"])
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hip_weno_operands_outside_the_tame_range(oracle, dim, dt):
+    """Slowness contrasts of 1e12: the second differences of the WENO stencils leave the range in which the fp32 kernel writes its
+    divisions out (weno_axes, fsm_kernels.h) and the wavefronts concerned take the compiler's IEEE divisions -- same bits."""
+    if dim == 3:
+        nn = (37, 33, 35)
+        s = np.ones(nn); s[10:20, 8:30, 5:25] = 3e12; s[25:30, :, :] = 7e9
+        c = dict(name="untame3d", dim=3, ncells=tuple(v - 1 for v in nn), dx=0.5, origin=(0.0, 0.0, 0.0), cell_slowness=False,
+                 slowness=s.flatten("F"), translate=False, src=np.array([[2.3, 4.1, 3.9]]), t0=np.array([0.0]), rcv=np.array([[1.0, 2.0, 3.0]]))
+        r = run_case(c, dt, weno=1)
+        o = oracle.solve3d(dt, c["ncells"], r["grid"].dx, c["origin"], c["slowness"], c["src"], rcv=c["rcv"], weno=True)
+    else:
+        nn = (150, 90)
+        s = np.ones(nn); s[40:70, 20:60] = 3e12; s[100:110, :] = 7e9
+        c = dict(name="untame2d", dim=2, ncells=tuple(v - 1 for v in nn), dx=0.5, dz=0.5, origin=(0.0, 0.0), cell_slowness=False,
+                 slowness=s.ravel(), translate=False, src=np.array([[2.3, 4.1]]), t0=np.array([0.0]), rcv=np.array([[1.0, 2.0]]))
+        r = run_case(c, dt, weno=1)
+        o = oracle.solve2d(dt, c["ncells"], r["grid"].dx, r["grid"].dz, c["origin"], c["slowness"], c["src"], rcv=c["rcv"], weno=True)
+    assert (r["niter"], r["niterw"]) == (o["niter"], o["niterw"])
+    assert o["niterw"] > 1 and np.nanmax(o["tt"]) > 1e12
+    np.testing.assert_array_equal(r["tt"], o["tt"])
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("pair", ["0", "1"], ids=["unpaired", "pairs"])
 def test_hip_weno_wide_batch(oracle, monkeypatch, dt, pair):

@@ -36,6 +36,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace ttcr_amd {
 
@@ -639,6 +640,124 @@ __device__ __forceinline__ T weno_axis(T m2, T m1, T c, T p1, T p2, int idx, int
     return c0 ? p1 : (cn ? m1 : a);
 }
 
+// fp32 grids: the same two stencils with the work they share done once, and the divisions of TAME operands written out.
+//  * second differences and one-sided differences: 2 v, 3 v and 4 v are exact in double for a float v, so
+//    fma(-2, b, a) rounds like the reference's a - 2.0 * b (one rounding either way), fma(2 r, r, 1) like 1.0 + 2.0 * r * r;
+//  * both stencils divide by the same eps + den^2: one reciprocal refinement serves both quotients;
+//  * the operation sequence of an IEEE division on this target is  scale, rcp, two (f64: four) fused refinement steps,
+//    quotient, residual, [f32: a second correction,] final fused correction, fix-up;  for operands whose quotient and
+//    reciprocal stay far from the ends of the exponent range the scale and fix-up steps are identities (fp32: numerator
+//    and denominator in [2^-23, 2^73) -- they are eps + a square, so only the upper bound is tested; fp64: the divisor
+//    1 + 2 r^2 is in [1, 2^193) then).  The wavefront takes the written-out sequence when every lane is tame, the
+//    compiler's division otherwise (next to unreached or out-of-grid entries): bit-identical either way, 24 instructions
+//    instead of 44 for the four divisions of an axis.
+#ifndef FSM_WENO_PLAIN
+#define FSM_WENO_PLAIN 0   // 1: the operation-by-operation form above for fp32 too (A/B builds)
+#endif
+__device__ __forceinline__ float weno_quot_tame(float A, float B, float y) {
+    float q = A * y;
+    float r = __builtin_fmaf(-B, q, A);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-B, q, A);
+    return __builtin_fmaf(r, y, q);
+}
+__device__ __forceinline__ double weno_recip_tame(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double r = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(r, y, y);
+}
+// One axis in three steps, so that ONE wave-uniform branch covers the divisions of all axes of a node and the independent
+// chains of the axes stay in one basic block (a lone wavefront issues in order: they fill each other's latencies).
+struct WenoAxisF {
+    double dm2, dm1, dc, dp1, dp2;
+    float Bq, AF, AB;   // eps + den^2, eps + num^2 of the forward / backward stencil
+    float wF, wB;
+};
+__device__ __forceinline__ WenoAxisF weno_pre(float m2, float m1, float c, float p1, float p2) {
+    const float eps = 1.1920928955078125e-07f;
+    WenoAxisF x;
+    x.dm2 = m2; x.dm1 = m1; x.dc = c; x.dp1 = p1; x.dp2 = p2;
+    const float den = (float)(__builtin_fma(-2.0, x.dc, x.dp1) + x.dm1);   // (p1 - 2 c) + m1: `den` of both stencils
+    const float nF = (float)(__builtin_fma(-2.0, x.dp1, x.dp2) + x.dc);    // forward:  (p2 - 2 p1) + c
+    const float nB = (float)(__builtin_fma(-2.0, x.dm1, x.dc) + x.dm2);    // backward: (c - 2 m1) + m2
+    x.Bq = eps + den * den; x.AF = eps + nF * nF; x.AB = eps + nB * nB;
+    return x;
+}
+__device__ __forceinline__ float weno_span(const WenoAxisF& x) { return __builtin_fmaxf(__builtin_fmaxf(x.AF, x.AB), x.Bq); }
+__device__ __forceinline__ void weno_weights_tame(WenoAxisF& x) {
+    float y = __builtin_amdgcn_rcpf(x.Bq);
+    const float e = __builtin_fmaf(-x.Bq, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    const double rF = weno_quot_tame(x.AF, x.Bq, y), rB = weno_quot_tame(x.AB, x.Bq, y);
+    x.wF = (float)weno_recip_tame(__builtin_fma(2.0 * rF, rF, 1.0));
+    x.wB = (float)weno_recip_tame(__builtin_fma(2.0 * rB, rB, 1.0));
+}
+// The compiler's divisions for the wavefronts that are not tame: ONE copy for the whole kernel, reached by a call -- inlined
+// into the eight unrolled levels it costs the level march a fifth more code, and the loop no longer fits the instruction cache
+// (measured: 256^3 single source 421 ms -> 488 ms with the inlined copies, 384 ms without them).
+struct WenoW6 { float w[6]; };
+__device__ __attribute__((noinline)) WenoW6 weno_weights_ieee(float AF0, float AB0, float B0, float AF1, float AB1, float B1,
+                                                              float AF2, float AB2, float B2) {
+    const float A[6] = {AF0, AB0, AF1, AB1, AF2, AB2};
+    const float B[3] = {B0, B1, B2};
+    WenoW6 o;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double r = A[i] / B[i >> 1];
+        o.w[i] = (float)(1.0 / __builtin_fma(2.0 * r, r, 1.0));
+    }
+    return o;
+}
+__device__ __forceinline__ float weno_post(const WenoAxisF& x, float m1, float c, float p1, int idx, int n, float h, double r2) {
+    const double d31 = p1 - m1;   // (float difference, then widened: T1 d31 = v3 - v1)
+    const double h2 = 2.0 * (double)h;
+    const double ap = div_h2((1.0 - (double)x.wF) * d31, h2, r2) +
+                      div_h2((double)x.wF * __builtin_fma(-3.0, x.dc, __builtin_fma(4.0, x.dp1, -x.dp2)), h2, r2);
+    const double am = div_h2((1.0 - (double)x.wB) * d31, h2, r2) +
+                      div_h2((double)x.wB * (__builtin_fma(-4.0, x.dm1, 3.0 * x.dc) + x.dm2), h2, r2);
+    const float F = c + h * (float)ap;
+    const float B = c - h * (float)am;
+    const bool c0 = idx == 0;
+    const bool c1 = !c0 && idx == 1;
+    const bool cn = !c0 && !c1 && idx == n;
+    const bool cm = !c0 && !c1 && !cn && idx == n - 1;
+    float a = cm ? B : F;
+    const float t = c1 ? m1 : (cm ? p1 : B);
+    a = a < t ? a : t;
+    return c0 ? p1 : (cn ? m1 : a);
+}
+// the axis values of one node: K, J, F (2-D: J, F)
+template <bool IS3D>
+__device__ __forceinline__ void weno_axes(const float (&vF)[5], const float (&vJ)[5], const float (&vK)[5], int iF, int nF, int iJ, int nJ,
+                                          int iK, int nK, float hF, double r2F, float hJ, double r2J, float& aF, float& aJ, float& aK) {
+    WenoAxisF xF = weno_pre(vF[0], vF[1], vF[2], vF[3], vF[4]);
+    WenoAxisF xJ = weno_pre(vJ[0], vJ[1], vJ[2], vJ[3], vJ[4]);
+    WenoAxisF xK = xJ;
+    float span = __builtin_fmaxf(weno_span(xF), weno_span(xJ));
+    if (IS3D) {
+        xK = weno_pre(vK[0], vK[1], vK[2], vK[3], vK[4]);
+        span = __builtin_fmaxf(span, weno_span(xK));
+    }
+    const bool tame = span < 0x1p73f;   // (a NaN operand gives NaN on both paths)
+#ifndef FSM_WENO_EXP
+#define FSM_WENO_EXP 0   // TIMING builds: 1 = no test, every wavefront takes the written-out divisions
+#endif
+    if (FSM_WENO_EXP == 1 || __builtin_expect(__builtin_amdgcn_ballot_w64(!tame) == 0ull, 1)) {
+        weno_weights_tame(xF); weno_weights_tame(xJ);
+        if (IS3D) weno_weights_tame(xK);
+    } else {
+        const WenoW6 o = weno_weights_ieee(xF.AF, xF.AB, xF.Bq, xJ.AF, xJ.AB, xJ.Bq, xK.AF, xK.AB, xK.Bq);
+        xF.wF = o.w[0]; xF.wB = o.w[1]; xJ.wF = o.w[2]; xJ.wB = o.w[3]; xK.wF = o.w[4]; xK.wB = o.w[5];
+    }
+    aF = weno_post(xF, vF[1], vF[2], vF[3], iF, nF, hF, r2F);
+    aJ = weno_post(xJ, vJ[1], vJ[2], vJ[3], iJ, nJ, hJ, r2J);
+    aK = IS3D ? weno_post(xK, vK[1], vK[2], vK[3], iK, nK, hJ, r2J) : 0.0f;
+}
+
 // Local solver of the WENO stage: the reference's literal compare/swap network and nested ifs
 // (ttcr/Grid3Drn.h:3432-3452) -- WENO axis values may be NaN/inf next to unreached nodes, and
 // min/max/med3 would not propagate them the way the swaps do.  Discriminants as in update3.
@@ -1026,6 +1145,10 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     P* __restrict__ Tg = reinterpret_cast<P*>(a.tt) + (size_t)grp * a.g.n_nodes;
     const T INF = real_traits<T>::inf();
     const P PINF = pack_fill<T, NS>(INF);
+    // what the tile holds where the grid has no node.  First-order stage: INF (the minimum of a neighbour pair ignores it).  WENO
+    // stage: no out-of-grid entry ever reaches a result (the first / second / last node cases of weno_axis pick their operands
+    // inside the grid), so any value will do -- 0 keeps the dropped stencils of boundary nodes tame (weno_axis)
+    const P PFILL = H == 2 ? pack_fill<T, NS>((T)0) : PINF;
     const int lm = NS == 1 ? 1 : a.lmask[z];   // sources of the group still being solved
     const int sf = rf ? -1 : 1;
 
@@ -1187,7 +1310,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         const int sL = sf * L;
 #pragma unroll
         for (int it = 0; it < NOWN + NHI; ++it) {
-            P v = PINF;
+            P v = PFILL;
             if ((unsigned)(L + ipb[it]) < (unsigned)NF) v = XS ? ld_sc1(Tg + (abase[it] + sL)) : Tg[abase[it] + sL];
             tv[it] = v;
         }
@@ -1208,7 +1331,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     // at levels L0..L0+H-1
     P carry[2 * H];
 #pragma unroll
-    for (int q = 0; q < 2 * H; ++q) carry[q] = PINF;
+    for (int q = 0; q < 2 * H; ++q) carry[q] = PFILL;
     bool have_prev = false;   // carry[] is valid (the previous chunk was evaluated)
     int pref_for = -(1 << 30);  // level for which sv/tv were prefetched
     int pending = 0;            // progress value of the previous chunk, published once its stores have drained
@@ -1508,12 +1631,12 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         } else {
 #pragma unroll
             for (int it = 0; it < NUPI; ++it) {
-                P v = PINF;
+                P v = PFILL;
                 if ((unsigned)(L0 + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * L0));
                 uv[it] = v;
             }
         }
-        P xv = PINF;
+        P xv = PFILL;
         if (H == 2 && (unsigned)(L0 + xipb) < (unsigned)NF) {
             const P* src = Tg + (xabase + sf * L0);
             if (x_up || XS) xv = ld_sc1(src); else xv = *src;
@@ -1529,7 +1652,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
 #pragma unroll
             for (int q = 0; q < 2 * H; ++q) {
                 const int ip = L0 - H + q - jp - kp;
-                P v = PINF;
+                P v = PFILL;
                 if (col_ok && (unsigned)ip < (unsigned)NF) {
                     const P* src = Tg + (colbase + (rf ? NF - 1 - ip : ip));
                     v = XS ? ld_sc1(src) : *src;
@@ -1562,7 +1685,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
             if (sj >= need_n && sk >= need_n) {
 #pragma unroll
                 for (int it = 0; it < NUPI; ++it) {
-                    P v = PINF;
+                    P v = PFILL;
                     if ((unsigned)(L0 + C + uipb[it]) < (unsigned)NF) v = ld_sc1(Tg + (uabase[it] + sf * (L0 + C)));
                     uvn[it] = v;
                 }
