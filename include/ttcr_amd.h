@@ -240,20 +240,27 @@ int ttcr_fsm_get_slot_rays(const ttcr_fsm_grid* g, int slot, long long* offsets,
 
 /* Replaces: Grid3D::raytrace(Tx, t0, Rx, traveltimes, m_data, threadNo) (ttcr/Grid3D.h:743-772) -> Grid3Drn::getRaypath(Tx,
  * t0, Rx, m_data, RxNo, tt, threadNo) (ttcr/Grid3Drn.h:1503-1800): what `compute_M=True` of the Python layer reaches
- * (src/ttcrpy/rgrid.pyx:1040-1060, :1171-1191).  One call solves the source in `slot`, walks every receiver's ray on the
- * device and assembles, per receiver, the (node index, value) entries of the matrix of traveltime derivatives in the order
- * the reference pushes them; traveltimes are those of that overload (integrated along the ray; 0 for a receiver on the
- * source).  The reference's formula is restated AS IT STANDS: it overwrites prev_pt with curr_pt before it forms a
- * segment's mid-point and length (:1590-1597), so every step of the walk contributes signed zeros at the eight nodes around
- * the step's end point and only the last hop (or two) to the source carries weight; its weights drop xmin and its node
- * indices may lie one node past the grid (the Python layer drops those).  Bit-identical to the compiled reference
- * (tests/golden/m_golden.npz, tests/test_m_matrix.py).  3-D node grids (TTCR_ERR_UNSUPPORTED otherwise, like the Python layer);
- * a source may have several points as long as only one of them lies within a cell diagonal of the end of a ray.
+ * (src/ttcrpy/rgrid.pyx:1059, :1171-1191).  One call solves the source in `slot`, walks every receiver's ray on the device
+ * with the walk of THAT overload (a kernel of its own) and assembles, per receiver, the (node index, value) entries of the
+ * matrix of traveltime derivatives in the order the reference pushes them; traveltimes are those of that overload
+ * (integrated along the ray; 0 for a receiver on the source).  The reference's formula is restated AS IT STANDS: it
+ * overwrites prev_pt with curr_pt before it forms a segment's mid-point and length (:1590-1597), so every step of the walk
+ * contributes signed zeros at the eight nodes around the step's end point and only the last hop (or two) to each source point
+ * within a cell diagonal carries weight; its weights drop xmin and its node indices may lie one node past the grid (the
+ * Python layer drops those).  Bit-identical to the compiled reference (tests/golden/m_golden.npz, tests/test_m_matrix.py),
+ * sources of several points -- closely spaced ones included -- as well.  3-D node grids (TTCR_ERR_UNSUPPORTED otherwise, like
+ * the Python layer).
+ * ttcr_fsm_raytrace_rm replaces the overload that keeps the rays too, Grid3D::raytrace(Tx, t0, Rx, traveltimes, r_data, m_data,
+ * threadNo) (ttcr/Grid3D.h:646-680) -> Grid3Drn::getRaypath(Tx, t0, Rx, r_data, m_data, RxNo, tt, threadNo) (ttcr/Grid3Drn.h:
+ * 2144-2470), what `compute_M=True, return_rays=True` reaches (rgrid.pyx:1050).  NOT the same matrix: this overload takes
+ * prev_pt before it pushes the point, so its segments carry their lengths (one exception, restated as well: the plane point
+ * between the walk and a source point, :2359-2366).  The rays of the call: ttcr_fsm_slot_rays_size / ttcr_fsm_get_slot_rays.
  * ttcr_fsm_slot_m_size: rows (= receivers) and entries of the last call on `slot`; ttcr_fsm_get_slot_m: row_off[n_rows+1],
- * j[nnz] node indices, v[nnz] values of the grid dtype.  The rays of the same call are available through
- * ttcr_fsm_slot_rays_size / ttcr_fsm_get_slot_rays (the overload with r_data AND m_data, ttcr/Grid3D.h:646-680). */
+ * j[nnz] node indices, v[nnz] values of the grid dtype. */
 int ttcr_fsm_raytrace_m(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx,
                         const void* rx, void* tt_out);
+int ttcr_fsm_raytrace_rm(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx,
+                         const void* rx, void* tt_out);
 int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz);
 int ttcr_fsm_get_slot_m(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* j, void* v);
 

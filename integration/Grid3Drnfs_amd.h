@@ -167,7 +167,7 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
     }
     void raytrace(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<sxyz<T1>>& Rx, std::vector<T1>& traveltimes,
                   std::vector<std::vector<sxyz<T1>>>& r_data, std::vector<std::vector<sijv<T1>>>& m_data, const size_t threadNo = 0) const override {
-        solve_m(Tx, t0, Rx, traveltimes, m_data, threadNo);
+        solve_m(Tx, t0, Rx, traveltimes, m_data, threadNo, true);   // (this overload's own terms: ttcr_fsm_raytrace_rm)
         fetch_slot_rays(r_data, threadNo);
     }
 
@@ -233,10 +233,11 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
         for (size_t n = 0; n < nr; ++n) r_data[n].assign(pts.begin() + off[n], pts.begin() + off[n + 1]);
     }
     void solve_m(const std::vector<sxyz<T1>>& Tx, const std::vector<T1>& t0, const std::vector<sxyz<T1>>& Rx, std::vector<T1>& traveltimes,
-                 std::vector<std::vector<sijv<T1>>>& m_data, const size_t threadNo) const {
+                 std::vector<std::vector<sijv<T1>>>& m_data, const size_t threadNo, bool with_rays = false) const {
         if (t0.size() != Tx.size()) throw std::runtime_error("Error: Tx and t0 of different sizes.");
         traveltimes.resize(Rx.size());
-        chk(ttcr_fsm_raytrace_m(h, (int)threadNo, (int)Tx.size(), Tx.data(), t0.data(), (int)Rx.size(), Rx.data(), traveltimes.data()));
+        chk((with_rays ? ttcr_fsm_raytrace_rm : ttcr_fsm_raytrace_m)(h, (int)threadNo, (int)Tx.size(), Tx.data(), t0.data(), (int)Rx.size(),
+                                                                     Rx.data(), traveltimes.data()));
         last_slot.store((int)threadNo);
         size_t nrow = 0, nnz = 0;
         chk(ttcr_fsm_slot_m_size(h, (int)threadNo, &nrow, &nnz));

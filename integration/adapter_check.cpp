@@ -201,6 +201,21 @@ int main() {
             for (const auto& row : m_data) for (const auto& e : row) { okm = okm && e.v == e.v; nz += e.v != 0.0f; }
             CHECK(okm && nz >= 8 && nz <= 48, "m_data overload: entries per receiver, none for a receiver on the source");
             std::printf("m3_entries %zu %zu nonzero %zu\n", m_data[0].size(), m_data[1].size(), nz);
+            // the overload that keeps the rays: its own terms (every segment carries its length), the rays of the r_data overload
+            std::vector<std::vector<sijv<float>>> m2;
+            std::vector<std::vector<sxyz<float>>> r2, r1;
+            std::vector<float> tt2, tt1;
+            g->raytrace(Tx, t0, Rm, tt2, r2, m2, 0);
+            g->raytrace(Tx, t0, Rm, tt1, r1, 0);
+            size_t nz2 = 0;
+            for (const auto& row : m2) for (const auto& e : row) nz2 += e.v != 0.0f;
+            bool okrm = m2.size() == 3 && r2.size() == 3 && m2[2].empty() && r2[2].size() == 1 && tt2[2] == 0.0f && nz2 > nz;
+            for (size_t n = 0; n < 3 && okrm; ++n) {
+                okrm = okrm && r2[n].size() == r1[n].size() && (n == 2 || tt2[n] == tt1[n]);
+                for (size_t k = 0; k < r2[n].size() && okrm; ++k) okrm = r2[n][k] == r1[n][k];
+            }
+            CHECK(okrm, "r_data + m_data overload: rays of the r_data overload, more weighted entries than the m_data-only overload");
+            std::printf("rm3_entries %zu %zu nonzero %zu\n", m2[0].size(), m2[1].size(), nz2);
         }
     }
     {   // ------------------------------------------------ 3-D cell grid, fp64, translated origin (Grid3Drcfs seat)

@@ -39,6 +39,10 @@ extern "C" {
     int fsm_raypath3d_m_##S(const fsm_grid3d_##S* g, const REAL* sn, const REAL* T, int n_src,       \
                             const REAL* src, const REAL* t0, const REAL rx[3], int iv, long max_steps, \
                             REAL* tt_out, long long* mj, REAL* mv, long cap, long* nm);              \
+    int fsm_raypath3d_rm_##S(const fsm_grid3d_##S* g, const REAL* sn, const REAL* T, int n_src,      \
+                             const REAL* src, const REAL* t0, const REAL rx[3], int iv, long max_steps, \
+                             REAL* tt_out, REAL* pts, long cap_pts, long* npts, long long* mj, REAL* mv, \
+                             long cap, long* nm);                                                    \
     void fsm_grid2d_init_##S(fsm_grid2d_##S* g, uint32_t ncx, uint32_t ncz, REAL dx, REAL dz,        \
                              REAL xmin, REAL zmin);                                                  \
     int fsm_outside2d_##S(const fsm_grid2d_##S* g, int n, const REAL* p);                            \

@@ -871,6 +871,88 @@ int SFX(fsm_raypath3d_m)(const SFX(fsm_grid3d) * g, const REAL* sn, const REAL* 
     return nm > cap ? 3 : 0;
 }
 
+/* Grid3Drn::getRaypath(Tx, t0, Rx, r_data, m_data, RxNo, tt, threadNo), ttcr/Grid3Drn.h:2144-2470 -- the overload ttcrpy calls
+ * for compute_M WITH return_rays (src/ttcrpy/rgrid.pyx:1050): the walk and the points of the r_data overload, and for every
+ * pushed point the terms of M of the segment from the point pushed before it -- here prev_pt is taken BEFORE the push
+ * (:2228-2236), so the segments carry their length (unlike the m_data-only overload above).  One exception, as the reference
+ * has it: for the plane point pushed between the walk and Tx prev_pt is read AFTER the push (:2359-2366), a zero-length
+ * segment at that point.  A receiver on a source point: the point, tt = 0 (not t0), no terms.
+ * Returns like fsm_raypath3d (3: a capacity exceeded; *npts and *nm still count). */
+int SFX(fsm_raypath3d_rm)(const SFX(fsm_grid3d) * g, const REAL* sn, const REAL* T, int n_src, const REAL* src,
+                          const REAL* t0, const REAL rx[3], int iv, long max_steps, REAL* tt_out, REAL* pts, long cap_pts,
+                          long* npts, long long* mj, REAL* mv, long cap, long* nm_out) {
+    REAL tt = 0.0, s1, s2;
+    long nm = 0, np = 0;
+    REAL back[3], prev[3], mid[3];
+#define FSM_PUSH(P) do { if (np < cap_pts) { pts[3 * np] = (P)[0]; pts[3 * np + 1] = (P)[1]; pts[3 * np + 2] = (P)[2]; } \
+                         back[0] = (P)[0]; back[1] = (P)[1]; back[2] = (P)[2]; ++np; } while (0)
+#define FSM_MID(A, B) do { mid[0] = (REAL)0.5 * ((A)[0] + (B)[0]); mid[1] = (REAL)0.5 * ((A)[1] + (B)[1]); mid[2] = (REAL)0.5 * ((A)[2] + (B)[2]); } while (0)
+    *tt_out = tt;
+    *nm_out = 0;
+    FSM_PUSH(rx);
+    *npts = np;
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) return 0;
+    REAL cur[3] = {rx[0], rx[1], rx[2]}, gv[3];
+    s1 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+    const REAL dx = g->dx;
+    const REAL maxDist = (REAL)sqrt(dx * dx + dx * dx + dx * dx);
+    int reached = 0;
+    long steps = 0;
+    while (!reached) {
+        if (++steps > max_steps) { *nm_out = nm; *npts = np; return 2; }
+        SFX(grad3d)(g, T, cur[0], cur[1], cur[2], &gv[0], &gv[1], &gv[2]);
+        gv[0] *= (REAL)-1.0; gv[1] *= (REAL)-1.0; gv[2] *= (REAL)-1.0;
+        SFX(step_to_plane)(g, cur, gv);
+        if (cur[0] < g->xmin || cur[0] > g->xmax || cur[1] < g->ymin || cur[1] > g->ymax || cur[2] < g->zmin ||
+            cur[2] > g->zmax) { *nm_out = nm; *npts = np; return 1; }
+        prev[0] = back[0]; prev[1] = back[1]; prev[2] = back[2];
+        s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+        tt += 0.5 * (s1 + s2) * SFX(dist3)(back, cur);
+        s1 = s2;
+        FSM_PUSH(cur);
+        FSM_MID(cur, prev);
+        SFX(m_terms3d)(g, sn, mid, SFX(dist3)(cur, prev), iv, mj, mv, cap, &nm);
+        for (int ns = 0; ns < n_src; ++ns) {
+            const REAL* tx = src + 3 * ns;
+            REAL dist = SFX(dist3)(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1]; gv[2] = tx[2] - cur[2];
+                SFX(step_to_plane)(g, cur, gv);
+                if (SFX(dist3)(cur, back) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
+                    prev[0] = back[0]; prev[1] = back[1]; prev[2] = back[2];
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(back, tx);
+                    FSM_PUSH(tx);
+                    FSM_MID(tx, prev);
+                    SFX(m_terms3d)(g, sn, mid, SFX(dist3)(tx, prev), iv, mj, mv, cap, &nm);
+                } else {
+                    s2 = SFX(slowness_at3d)(g, sn, cur[0], cur[1], cur[2], iv);
+                    tt += 0.5 * (s1 + s2) * SFX(dist3)(back, cur);
+                    FSM_PUSH(cur);
+                    s1 = s2;
+                    prev[0] = back[0]; prev[1] = back[1]; prev[2] = back[2];   /* = cur: read after the push */
+                    FSM_MID(cur, prev);
+                    SFX(m_terms3d)(g, sn, mid, SFX(dist3)(cur, prev), iv, mj, mv, cap, &nm);
+                    prev[0] = back[0]; prev[1] = back[1]; prev[2] = back[2];
+                    s2 = SFX(slowness_at3d)(g, sn, tx[0], tx[1], tx[2], iv);
+                    tt += t0[ns] + 0.5 * (s1 + s2) * SFX(dist3)(cur, tx);
+                    FSM_PUSH(tx);
+                    FSM_MID(tx, prev);
+                    SFX(m_terms3d)(g, sn, mid, SFX(dist3)(tx, prev), iv, mj, mv, cap, &nm);
+                }
+                reached = 1;
+            }
+        }
+    }
+#undef FSM_MID
+#undef FSM_PUSH
+    *tt_out = tt;
+    *nm_out = nm;
+    *npts = np;
+    return (nm > cap || np > cap_pts) ? 3 : 0;
+}
+
 /* ------------------------------------------------------------------ 2D -- */
 /* 2D node index is z-fastest: n = i*(ncz+1)+j (ttcr/Grid2Drn.h:720). */
 

@@ -149,7 +149,41 @@ def solve3d(dtype, ncells, dx, origin, slowness, src, t0=None, eps=1e-5, maxit=5
             r -= np.array([g.ox, g.oy, g.oz], dtype=dt)
         if getattr(L, "fsm_outside3d_" + sfx)(C.byref(g), C.c_int(r.shape[0]), _p(r)):   # Grid3Drnfs::raytrace: checkPts(Rx)
             raise RuntimeError("Error: Point outside grid.")
-        if return_rays:
+        if return_rays and compute_m:
+            # Grid3D::raytrace(Tx,t0,Rx,tt,r_data,m_data,threadNo) (ttcr/Grid3D.h:646-680): the rays and, per receiver, the
+            # entries of M of the overload that keeps both (its segments carry their lengths)
+            frm = getattr(L, "fsm_raypath3d_rm_" + sfx)
+            vals = np.empty(r.shape[0], dtype=dt)
+            rays, ms = [], []
+            cap = 4 * (ncx + ncy + ncz) + 64
+            for n, pnt in enumerate(r):
+                pp = np.ascontiguousarray(pnt, dtype=dt)
+                v = ct(0)
+                while True:
+                    buf = np.empty((cap, 3), dtype=dt)
+                    mj = np.empty(16 * cap, dtype=np.int64)
+                    mv = np.empty(16 * cap, dtype=dt)
+                    npts, nm = C.c_long(0), C.c_long(0)
+                    rc = frm(C.byref(g), _p(sn), _p(T), C.c_int(nsrc), _p(src), _p(t0), _p(pp), C.c_int(int(interp_vel)),
+                             C.c_long(1000000), C.byref(v), _p(buf), C.c_long(cap), C.byref(npts), _p(mj), _p(mv), C.c_long(16 * cap),
+                             C.byref(nm))
+                    if rc != 3:
+                        break
+                    cap *= 4
+                if rc == 1:
+                    raise RuntimeError("Error while computing raypaths: going outside grid")
+                if rc == 2:
+                    raise RuntimeError("raypath did not reach the source")
+                vals[n] = v.value
+                ray = buf[:npts.value].copy()
+                if translate:
+                    ray += np.array([g.ox, g.oy, g.oz], dtype=dt)
+                rays.append(ray)
+                ms.append((mj[:nm.value].copy(), mv[:nm.value].copy()))
+            out["tt_rcv"] = vals
+            out["rays"] = rays
+            out["m"] = ms
+        elif return_rays:
             # Grid3D::raytrace(Tx,t0,Rx,tt,r_data,threadNo) (ttcr/Grid3D.h:546-586): getRaypath with tt for
             # every receiver; rays are shifted back by the origin of a translated grid (:579-584)
             frp = getattr(L, "fsm_raypath3d_" + sfx)

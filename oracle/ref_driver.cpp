@@ -92,7 +92,31 @@ static int run3d(GRID& g, const T* slowness, size_t n_slowness, int n_src, const
         std::vector<T> vt0(t0, t0 + n_src), tt;
         for (int n = 0; n < n_src; ++n) Tx[n] = {src_xyz[3 * n], src_xyz[3 * n + 1], src_xyz[3 * n + 2]};
         for (int n = 0; n < n_rcv; ++n) Rx[n] = {rcv_xyz[3 * n], rcv_xyz[3 * n + 1], rcv_xyz[3 * n + 2]};
-        if (g_ray_buf) {
+        if (g_ray_buf && g_m_j) {
+            // both: Grid3D::raytrace(Tx,t0,Rx,tt,r_data,m_data,threadNo) (ttcr/Grid3D.h:646-680 -> Grid3Drn::getRaypath(Tx,t0,Rx,
+            // r_data,m_data,RxNo,tt,threadNo), ttcr/Grid3Drn.h:2144-2470) -- what ttcrpy calls for compute_M with return_rays
+            std::vector<std::vector<sxyz<T>>> r_data;
+            std::vector<std::vector<sijv<T>>> m_data;
+            static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, r_data, m_data, 0);
+            long k = 0;
+            for (int n = 0; n < n_rcv; ++n) {
+                g_ray_off[n] = k;
+                for (const auto& p : r_data[n]) {
+                    if (k < g_ray_cap) { g_ray_buf[3 * k] = p.x; g_ray_buf[3 * k + 1] = p.y; g_ray_buf[3 * k + 2] = p.z; }
+                    ++k;
+                }
+            }
+            g_ray_off[n_rcv] = k;
+            k = 0;
+            for (int n = 0; n < n_rcv; ++n) {
+                g_m_off[n] = k;
+                for (const auto& e : m_data[n]) {
+                    if (k < g_m_cap) { g_m_j[k] = (long long)e.j; g_m_v[k] = (double)e.v; }
+                    ++k;
+                }
+            }
+            g_m_off[n_rcv] = k;
+        } else if (g_ray_buf) {
             std::vector<std::vector<sxyz<T>>> r_data;
             static_cast<Grid3D<T, uint32_t>&>(g).raytrace(Tx, vt0, Rx, tt, r_data, 0);
             long k = 0;

@@ -162,6 +162,12 @@ int main(void) {
     size_t sr2 = 0, sp2 = 0;
     CHECK(ttcr_fsm_slot_rays_size(g, 0, &sr2, &sp2) == TTCR_OK && sr2 == sr && sp2 == sp, "rays of slot 0 untouched by slot 1");
     CHECK(ttcr_fsm_raytrace_m(g, 2, 1, tx, t0, 2, ry, mtt2) == TTCR_ERR_VALUE, "raytrace_m slot out of range -> TTCR_ERR_VALUE");
+    /* the overload with r_data and m_data (compute_M with return_rays): more entries, the rays of slot 1 alongside */
+    size_t mrows2 = 0, mnnz2 = 0, sr3 = 0, sp3 = 0;
+    CHECK(ttcr_fsm_raytrace_rm(g, 1, 1, tx, t0, 2, ry, mtt2) == TTCR_OK, "raytrace_rm slot 1");
+    CHECK(ttcr_fsm_slot_m_size(g, 1, &mrows2, &mnnz2) == TTCR_OK && mrows2 == 2 && mnnz2 >= mnnz, "slot_m_size after raytrace_rm");
+    CHECK(ttcr_fsm_slot_rays_size(g, 1, &sr3, &sp3) == TTCR_OK && sr3 == 2 && sp3 == sp, "rays of raytrace_rm = rays of raytrace_rays");
+    printf("ttrm %a %a\n", mtt2[0], mtt2[1]);
     double ch[50], chw[50];
     CHECK(ttcr_fsm_get_changes(g, 1, ch, 50, chw, 50) == TTCR_OK && ch[0] > 0 && ch[niter - 1] >= 0 && chw[0] == 0, "get_changes");
     printf("change3d %a %a\n", ch[0], ch[niter - 1]);

@@ -5,6 +5,9 @@
   <case>/<dtype>/slowness, src, t0, rcv, meta = (ncx, ncy, ncz, dx, ox, oy, oz, translate, weno)      inputs
   <case>/<dtype>/tt_rcv           traveltimes of that overload (0 for a receiver on the source)
   <case>/<dtype>/m_off, m_j, m_v  per receiver n the entries [m_off[n], m_off[n+1]) in the order the reference pushed them
+  <case>/<dtype>/rm_tt_rcv, rm_off, rm_j, rm_v, rm_ray_off, rm_ray_pts   the same through the overload that keeps the rays as well,
+                                  Grid3D::raytrace(Tx, t0, Rx, traveltimes, r_data, m_data, threadNo) (ttcr/Grid3D.h:646-680 ->
+                                  Grid3Drn.h:2144-2470; what ttcrpy calls for compute_M with return_rays): another matrix
 
 usage: python tests/golden/make_m_golden.py"""
 import os, sys
@@ -25,7 +28,10 @@ def cases_m():
             ("m_translate", (12, 16, 10), 2.0, (500000.0, 4000000.0, -1000.0), 1, 0, True, [500009.0, 4000011.5, -993.0]),
             ("m_weno", (16, 16, 16), 1.0, (0.0, 0.0, 0.0), 0, 1, False, [8.0, 8.0, 8.0]),
             # a source of two points with their own origin times (aggregate_src): every ray ends at the point it reaches first
-            ("m_two_points", (20, 16, 14), 1.0, (0.0, 0.0, 0.0), 0, 0, True, [[3.3, 4.1, 5.7], [16.2, 11.4, 8.9]])):
+            ("m_two_points", (20, 16, 14), 1.0, (0.0, 0.0, 0.0), 0, 0, True, [[3.3, 4.1, 5.7], [16.2, 11.4, 8.9]]),
+            # three points of one source within a cell of each other: the end game of a ray runs once per point within a cell
+            # diagonal, on a point the previous run has moved (ttcr/Grid3Drn.h:1628-1795 / :2262-2460)
+            ("m_close_points", (16, 18, 14), 1.0, (0.0, 0.0, 0.0), 0, 0, True, [[8.3, 7.1, 6.4], [8.6, 6.9, 6.65], [7.9, 7.45, 6.5]])):
         nn = tuple(v + 1 for v in nc)
         if rough:
             s = rng.uniform(0.4, 1.0, nn[0] * nn[1] * nn[2])
@@ -36,7 +42,7 @@ def cases_m():
         rcv = rng.uniform(lo + 0.6 * dx, hi - 0.6 * dx, (7, 3))
         srcs = np.atleast_2d(np.array(src, dtype=float))
         rcv = np.vstack([rcv, srcs[:1], hi - 0.25 * dx, lo + np.array([0.5, 0.5, 0.5]) * dx])
-        out.append(dict(name=name, nc=nc, dx=dx, org=org, translate=tr, weno=weno, slowness=s, src=srcs, t0=np.array([0.25, 0.4][:srcs.shape[0]]), rcv=rcv))
+        out.append(dict(name=name, nc=nc, dx=dx, org=org, translate=tr, weno=weno, slowness=s, src=srcs, t0=np.array([0.25, 0.4, 0.1][:srcs.shape[0]]), rcv=rcv))
     return out
 
 
@@ -53,6 +59,15 @@ def main():
             out[key + "/m_off"] = np.cumsum([0] + [len(j) for j, _ in r["m"]]).astype(np.int64)
             out[key + "/m_j"] = np.concatenate([j for j, _ in r["m"]]).astype(np.int64)
             out[key + "/m_v"] = np.concatenate([v for _, v in r["m"]]).astype(dt)
+            r2 = O.ref_solve3d(dt, c["nc"], c["dx"], c["org"], c["slowness"], c["src"], t0=c["t0"], rcv=c["rcv"], weno=bool(c["weno"]),
+                               translate=bool(c["translate"]), compute_m=True, return_rays=True)
+            out[key + "/rm_tt_rcv"] = r2["tt_rcv"]
+            out[key + "/rm_off"] = np.cumsum([0] + [len(j) for j, _ in r2["m"]]).astype(np.int64)
+            out[key + "/rm_j"] = np.concatenate([j for j, _ in r2["m"]]).astype(np.int64)
+            out[key + "/rm_v"] = np.concatenate([v for _, v in r2["m"]]).astype(dt)
+            out[key + "/rm_ray_off"] = np.cumsum([0] + [len(ray) for ray in r2["rays"]]).astype(np.int64)
+            out[key + "/rm_ray_pts"] = np.concatenate(r2["rays"]).astype(dt)
+            print(key, "rm entries", out[key + "/rm_j"].size, "nonzero", int(np.count_nonzero(out[key + "/rm_v"])))
             print(key, "entries", out[key + "/m_j"].size, "nonzero", int(np.count_nonzero(out[key + "/m_v"])),
                   "past the grid", int(np.sum(out[key + "/m_j"] >= np.prod([v + 1 for v in c["nc"]]))))
         out[c["name"] + "/slowness"] = c["slowness"]

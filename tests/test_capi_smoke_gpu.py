@@ -60,7 +60,7 @@ def test_capi_smoke_runs_and_matches_the_oracle(oracle):
     vals = {}
     for line in out.splitlines():
         k, *rest = line.split()
-        if k in ("tt3d", "ttmulti", "ttcells", "tt2d", "field3d_sum", "field3d_probe", "ttrays", "ttm", "change3d"):
+        if k in ("tt3d", "ttmulti", "ttcells", "tt2d", "field3d_sum", "field3d_probe", "ttrays", "ttm", "ttrm", "change3d"):
             vals[k] = [float.fromhex(v) for v in rest]
         elif k in ("niter3d", "rays_npts", "m_shape"):
             vals[k] = [int(v) for v in rest]
@@ -93,6 +93,8 @@ def test_capi_smoke_runs_and_matches_the_oracle(oracle):
     assert vals["m_shape"] == [len(j) for j, _ in om["m"]]
     assert vals["m_sums"][1] == int(sum(int(np.sum(j)) for j, _ in om["m"]))
     assert vals["m_sums"][0] == float(sum(np.sum(v.astype(np.float64)) for _, v in om["m"]))
+    orm = oracle.solve3d(np.float32, nc, dx, org, s, [[3.3, 1.1, 2.7]], t0=[0.25], rcv=ry, compute_m=True, return_rays=True)
+    np.testing.assert_array_equal(np.array(vals["ttrm"], dtype=np.float32), orm["tt_rcv"])
     # the stopping rule's quantity: fp64 sum of the decreases vs the reference's sequential fp32 sum
     # (iteration 1 lowers every node from the initial "infinity": huge in both)
     assert vals["change3d"][0] > 1e30 and o["change"][0] > 1e30

@@ -1,5 +1,6 @@
 """The matrix M of `compute_M` (Grid3D::raytrace(..., m_data, threadNo), ttcr/Grid3D.h:743-772 -> Grid3Drn::getRaypath(...,
-m_data, ...), ttcr/Grid3Drn.h:1503-1800): the oracle's restatement against golden vectors made with the compiled reference
+m_data, ...), ttcr/Grid3Drn.h:1503-1800; and the overload that keeps the rays as well, ttcr/Grid3D.h:646-680 -> Grid3Drn.h:2144-2470,
+which ttcrpy calls for compute_M with return_rays and which gives ANOTHER matrix -- keys rm_*): the oracle's restatement against golden vectors made with the compiled reference
 (tests/golden/m_golden.npz + make_m_golden.py) and against the live reference (build container); the HIP path against the same
 vectors through the C ABI (-m gpu), entry for entry in the reference's push order, signed zeros included."""
 import ctypes as C
@@ -9,7 +10,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = ["m_grad", "m_rough", "m_translate", "m_weno", "m_two_points"]
+CASES = ["m_grad", "m_rough", "m_translate", "m_weno", "m_two_points", "m_close_points"]
 
 
 @pytest.fixture(scope="module")
@@ -39,13 +40,22 @@ def test_oracle_m_matches_golden(oracle, mg, name, dt):
     assert len(r["m"]) == off.size - 1
     for n, (j, v) in enumerate(r["m"]):
         _same_entries(j, v, mg[key + "/m_j"][off[n]:off[n + 1]], mg[key + "/m_v"][off[n]:off[n + 1]])
+    # the overload with r_data and m_data: its own traveltimes (0 on the source too), terms and rays
+    r2 = oracle.solve3d(dt, c["nc"], c["dx"], c["org"], mg[name + "/slowness"], mg[name + "/src"], t0=mg[name + "/t0"], rcv=mg[name + "/rcv"],
+                        weno=c["weno"], translate=c["translate"], compute_m=True, return_rays=True)
+    np.testing.assert_array_equal(r2["tt_rcv"], mg[key + "/rm_tt_rcv"])
+    off2, roff = mg[key + "/rm_off"], mg[key + "/rm_ray_off"]
+    for n, (j, v) in enumerate(r2["m"]):
+        _same_entries(j, v, mg[key + "/rm_j"][off2[n]:off2[n + 1]], mg[key + "/rm_v"][off2[n]:off2[n + 1]])
+        np.testing.assert_array_equal(r2["rays"][n], mg[key + "/rm_ray_pts"][roff[n]:roff[n + 1]])
+    assert np.count_nonzero(mg[key + "/rm_v"]) > 3 * np.count_nonzero(mg[key + "/m_v"])   # (every segment carries weight there)
     # what the walk of that overload is: a receiver on the source has no entries and traveltime 0; of a ray's entries only
     # those of the last hop(s) carry weight
     on_src = int(np.nonzero(np.all(mg[name + "/rcv"] == mg[name + "/src"][0], axis=1))[0][0])
     assert off[on_src + 1] == off[on_src] and r["tt_rcv"][on_src] == 0
     for n in range(off.size - 1):
         if n != on_src:
-            assert 1 <= np.count_nonzero(mg[key + "/m_v"][off[n]:off[n + 1]]) <= 24
+            assert 1 <= np.count_nonzero(mg[key + "/m_v"][off[n]:off[n + 1]]) <= 24 * mg[name + "/src"].shape[0]
 
 
 def test_oracle_m_matches_live_reference(oracle):
@@ -61,8 +71,10 @@ def test_oracle_m_matches_live_reference(oracle):
             s = np.repeat(1.0 / (1.0 + 0.05 * z), nn[0] * nn[1]) * rng.uniform(0.9, 1.1, nn[0] * nn[1] * nn[2])
             hi = np.array(nc) * dx
             src = rng.uniform(1.5 * dx, hi - 1.5 * dx, (1, 3))
+            if trial >= 2:   # one or two more points of the same source within a cell of the first
+                src = np.vstack([src] + [src[0] + rng.uniform(-0.6, 0.6, 3) * dx for _ in range(trial % 2 + 1)])
             rcv = rng.uniform(0.7 * dx, hi - 0.7 * dx, (6, 3))
-            kw = dict(rcv=rcv, compute_m=True, weno=bool(trial % 2))
+            kw = dict(rcv=rcv, compute_m=True, weno=bool(trial % 2), return_rays=bool(trial % 3 == 0), t0=rng.uniform(0, 0.5, src.shape[0]).round(3))
             try:
                 a = oracle.solve3d(dt, nc, dx, (0, 0, 0), s, src, **kw)
             except RuntimeError as e:   # a walk that leaves the grid: the reference throws as well
@@ -76,6 +88,9 @@ def test_oracle_m_matches_live_reference(oracle):
             np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
             for (j1, v1), (j2, v2) in zip(a["m"], b["m"]):
                 _same_entries(j1, v1, j2, v2)
+            if kw["return_rays"]:
+                for r1, r2 in zip(a["rays"], b["rays"]):
+                    np.testing.assert_array_equal(r1, r2)
 
 
 @pytest.mark.gpu
@@ -120,11 +135,25 @@ def test_hip_m_matches_golden(mg, name, dt):
         o = np.argsort(gj, kind="stable")
         np.testing.assert_array_equal(row.indices, gj[o])
         np.testing.assert_array_equal(row.data, gv[o].astype(np.float64))
+    # with the rays: the overload with r_data and m_data -- its own matrix, traveltimes and the rays of the r_data overload
+    _lib.check(L.ttcr_fsm_raytrace_rm(g._h, 0, tx.shape[0], p(tx), p(t0), rx.shape[0], p(rx), p(out)))
+    np.testing.assert_array_equal(out, mg[key + "/rm_tt_rcv"])
+    _lib.check(L.ttcr_fsm_slot_m_size(g._h, 0, C.byref(nrow), C.byref(nnz)))
+    off = np.zeros(nrow.value + 1, dtype=np.int64); jj = np.empty(max(nnz.value, 1), dtype=np.int64); vv = np.empty(max(nnz.value, 1), dtype=dt)
+    _lib.check(L.ttcr_fsm_get_slot_m(g._h, 0, p(off), p(jj), p(vv)))
+    np.testing.assert_array_equal(off, mg[key + "/rm_off"])
+    _same_entries(jj[:nnz.value], vv[:nnz.value], mg[key + "/rm_j"], mg[key + "/rm_v"])
     tt2, rays, M2 = g.raytrace(srows, rcv, compute_M=True, return_rays=True, aggregate_src=multi)
-    np.testing.assert_array_equal(tt2, tt)
-    assert (M2[0] != M[0]).nnz == 0 and len(rays) == rcv.shape[0]
+    np.testing.assert_array_equal(tt2, mg[key + "/rm_tt_rcv"])
+    assert len(rays) == rcv.shape[0] and len(M2) == 1
+    goff, roff = mg[key + "/rm_off"], mg[key + "/rm_ray_off"]
     for n in range(rcv.shape[0]):
-        np.testing.assert_array_equal(rays[n][0], rcv[n].astype(dt).astype(np.float64))
+        np.testing.assert_array_equal(rays[n], mg[key + "/rm_ray_pts"][roff[n]:roff[n + 1]].astype(np.float64))
+        row = M2[0].getrow(n)
+        gj, gv = mg[key + "/rm_j"][goff[n]:goff[n + 1]], mg[key + "/rm_v"][goff[n]:goff[n + 1]]
+        o = np.argsort(gj, kind="stable")
+        np.testing.assert_array_equal(row.indices, gj[o])
+        np.testing.assert_array_equal(row.data, gv[o].astype(np.float64))
     # refused where the reference's Python layer refuses, and where this backend does not follow it
     gc = ttcr_amd.Grid3d(*axes, cell_slowness=1, method="FSM", dtype=dt)
     with pytest.raises(NotImplementedError):

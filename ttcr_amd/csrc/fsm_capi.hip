@@ -101,7 +101,8 @@ class GridBase {
     virtual void slot_rays_size(int slot, size_t* n_rays, size_t* n_points) const = 0;
     virtual void get_slot_rays(int slot, long long* offsets, void* pts) const = 0;
     // the same with the entries of the matrix M per receiver (m_data overloads), kept per slot like the rays
-    virtual void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) = 0;
+    // both: the overload that keeps the rays as well (its terms differ, see fsm_raypath3d_m)
+    virtual void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool both) = 0;
     virtual void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const = 0;
     virtual void get_slot_m(int slot, long long* row_off, long long* j, void* v) const = 0;
     // the raytrace overloads with l_data (2-D cell grids): ray-projection matrix L, one CSR row per receiver
@@ -1689,100 +1690,131 @@ class GridT : public GridBase {
     DevBuf<int> d_raynp;
     DevBuf<long long> d_rayoff;
 
-    bool rays_in_grid_coords = false;   // (raytrace_m: the rays stay in the coordinates of a translated grid)
-    bool shift_rays() const { return translate && !rays_in_grid_coords; }
+    bool shift_rays() const { return translate; }
 
-    // ---- matrix M (the raytrace overloads with m_data, ttcr/Grid3D.h:743-772 -> Grid3Drn::getRaypath(Tx, t0, Rx, m_data,
-    // RxNo, tt, threadNo), ttcr/Grid3Drn.h:1503-1800).  The walk of that overload visits exactly the points the r_data
-    // overload records (same gradient steps, same end game), so M is assembled on the host from the rays the device
-    // walked: per step point the reference adds -s^2 * ds * w at the eight nodes around the segment's mid-point, with
-    // prev_pt overwritten by curr_pt BEFORE mid-point and length are taken (:1590-1597): ds = 0, the mid-point is the
-    // step's end point and the eight entries are signed zeros; only the last hop (or two) to the source carries weight.
-    // Restated as it stands (weights without xmin, node indices that may lie one past the grid -- the Python layer
-    // drops those), entries merged by node in push order; a receiver on the source: no entries and tt = 0, not t0.
+    // ---- matrix M (the raytrace overloads with m_data: ttcr/Grid3D.h:743-772 -> Grid3Drn::getRaypath(Tx, t0, Rx, m_data, RxNo, tt,
+    // threadNo), ttcr/Grid3Drn.h:1503-1800; with r_data as well, what ttcrpy calls for compute_M with return_rays:
+    // ttcr/Grid3D.h:646-680 -> getRaypath(Tx, t0, Rx, r_data, m_data, RxNo, tt, threadNo), ttcr/Grid3Drn.h:2144-2470).  The walk
+    // of either overload is a kernel of its own (fsm_raypath3d_m) that leaves one record (mid-point, length, slowness at the
+    // mid-point) per term block of the reference; the host adds -s^2 * ds * w at the eight nodes around each mid-point.
+    // Restated as it stands (weights without xmin, node indices that may lie one past the grid -- the Python layer drops those;
+    // the zero-length segments of the m_data-only overload give signed zeros), entries merged by node in push order; a receiver
+    // on the source: no entries and tt = 0, not t0.
     std::vector<std::vector<long long>> slot_m_off, slot_m_j;
     std::vector<std::vector<T>> slot_m_v;
-    static T host_dist3(const T* a, const T* b) {
-        const T d2 = (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
-        return (T)std::sqrt((double)d2);
+    DevBuf<T> d_msegs, d_mlong;
+    DevBuf<int> d_mnseg;
+    // records of every receiver's walk: seg_off[q] .. seg_off[q+1] in segs (5 values each), traveltimes of the overload in out
+    void walk_m(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out, bool both, std::vector<long long>& seg_off,
+                std::vector<T>& segs) {
+        seg_off.assign(1, 0);
+        segs.clear();
+        if (n <= 0) return;
+        d_rsrc.reserve((size_t)3 * n_tx);
+        d_rt0.reserve(n_tx);
+        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txp, sizeof(T) * 3 * n_tx, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0p, sizeof(T) * n_tx, hipMemcpyHostToDevice, stream));
+        RayGeom<T> rg;
+        rg.nnx = ncx + 1; rg.nny = ncy + 1; rg.nnz = ncz + 1;
+        rg.dx = dx; rg.xmin = xmin; rg.ymin = ymin; rg.zmin = zmin; rg.xmax = xmax; rg.ymax = ymax; rg.zmax = zmax;
+        rg.interp_vel = interp_vel;
+        const long max_steps = walk_step_limit;
+        // one record per step, up to two per source point at the end; a longer walk is done again with the room it asked for
+        const long cap = std::min<long>(max_steps, 8L * ((long)ncx + ncy + ncz + 3)) + 2L * n_tx + 1;
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (sizeof(T) * 5 * cap)));
+        std::vector<int> st(chunk), ns(chunk);
+        std::vector<T> rows;
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            const int m = std::min(chunk, n - c0);
+            const T* pc = p + (size_t)3 * c0;
+            d_rx.reserve((size_t)3 * m);
+            d_out.reserve(m);
+            d_rstat.reserve(m);
+            d_msegs.reserve((size_t)m * cap * 5);
+            d_mnseg.reserve(m);
+            HIP_CHECK(hipMemcpyAsync(d_rx.p, pc, sizeof(T) * 3 * m, hipMemcpyHostToDevice, stream));
+            const dim3 rgrid((m + 63) / 64), rblock(64);
+            if (both)
+                fsm_raypath3d_m<T, true><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m, d_out.p,
+                                                                       d_rstat.p, max_steps, d_msegs.p, cap, d_mnseg.p);
+            else
+                fsm_raypath3d_m<T, false><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m, d_out.p,
+                                                                        d_rstat.p, max_steps, d_msegs.p, cap, d_mnseg.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(out + c0, d_out.p, sizeof(T) * m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(ns.data(), d_mnseg.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            for (int q = 0; q < m; ++q)
+                if (st[q] != 0 && st[q] != 3) throw_walk_error(st[q], pc + (size_t)3 * q, txp, max_steps);
+            size_t base = segs.size(), tot = 0;
+            for (int q = 0; q < m; ++q) tot += (size_t)5 * ns[q];
+            segs.resize(base + tot);   // (once per chunk: the copies below are asynchronous)
+            for (int q = 0; q < m; ++q) {
+                if (st[q] == 0) {
+                    if (ns[q] > 0)
+                        HIP_CHECK(hipMemcpyAsync(segs.data() + base, d_msegs.p + (size_t)q * cap * 5, sizeof(T) * 5 * ns[q], hipMemcpyDeviceToHost, stream));
+                } else {   // status 3: once more, alone, with room
+                    const long need = (long)ns[q] + 1;
+                    d_mlong.reserve((size_t)need * 5);
+                    if (both)
+                        fsm_raypath3d_m<T, true><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)3 * q, 1,
+                                                                       d_out.p + q, d_rstat.p + q, max_steps, d_mlong.p, need, d_mnseg.p + q);
+                    else
+                        fsm_raypath3d_m<T, false><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)3 * q, 1,
+                                                                        d_out.p + q, d_rstat.p + q, max_steps, d_mlong.p, need, d_mnseg.p + q);
+                    HIP_CHECK(hipGetLastError());
+                    int st2 = 0, ns2 = 0;
+                    HIP_CHECK(hipMemcpyAsync(&st2, d_rstat.p + q, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipMemcpyAsync(&ns2, d_mnseg.p + q, sizeof(int), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipMemcpyAsync(segs.data() + base, d_mlong.p, sizeof(T) * 5 * ns[q], hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    if (st2 != 0 || ns2 != ns[q]) throw DeviceError("compute_M: a long walk did not retrace to the same length");
+                }
+                base += (size_t)5 * ns[q];
+                seg_off.push_back(seg_off.back() + ns[q]);
+            }
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
     }
-    struct MSeg { size_t row; T mid[3]; T ds; bool real; };   // real: needs the slowness at mid (the last hops)
-    void raytrace_m(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v) override {
+    void raytrace_m(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool both) override {
         check_slot(slot);
         if (dim != 3) throw Unsupported("compute_M is implemented for 3-D grids only");
         if (cell) throw Unsupported("compute_M not defined for grids with slowness defined for cells");
         if (n_tx < 1) throw ValueError("every source needs at least one point");
         const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
-        rays_in_grid_coords = true;
-        try {
-            raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot, nullptr, true);
-        } catch (...) { rays_in_grid_coords = false; throw; }
-        rays_in_grid_coords = false;
+        // the field of the source (and, for the overload that keeps them, the rays: the points of that overload are those of
+        // the r_data overload); the receivers' traveltimes are then replaced by those of the m_data walk
+        raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot, nullptr, both);
         T* tt_out = (T*)tt_out_v;
-        std::vector<T> txs((const T*)tx_v, (const T*)tx_v + 3 * (size_t)n_tx);
-        if (translate)
+        std::vector<T> txs((const T*)tx_v, (const T*)tx_v + 3 * (size_t)n_tx), rxs((const T*)rx_v, (const T*)rx_v + 3 * (size_t)n_rx);
+        if (translate) {
             for (int q = 0; q < n_tx; ++q) { txs[3 * q] -= ox; txs[3 * q + 1] -= oy; txs[3 * q + 2] -= oz; }
-        const T maxDist = (T)std::sqrt((double)(dx * dx + dx * dx + dx * dx));
-        // segments of every ray, in the order the reference visits them
-        std::vector<MSeg> segs;
-        for (int r = 0; r < n_rx; ++r) {
-            const T* P = rays_pts.data() + 3 * (size_t)rays_off[r];
-            const long long np = rays_off[r + 1] - rays_off[r];
-            bool on_src = false;
-            for (int q = 0; q < n_tx; ++q) on_src = on_src || (P[0] == txs[3 * q] && P[1] == txs[3 * q + 1] && P[2] == txs[3 * q + 2]);
-            if (np == 1 && on_src) { tt_out[r] = (T)0; continue; }   // Rx == Tx (:1516-1520): no entries, and 0 -- not t0
-            if (np < 3) throw std::runtime_error("compute_M: unexpected ray of fewer than three points");
-            // The walk stops at the FIRST step point that is closer than a cell diagonal to a source point: the step points are
-            // P[1..m], the end game follows -- [.., c_m, Tx] or [.., c_m, x, Tx] (x: the plane crossed between c_m and Tx).
-            long long m = -1;
-            int ns = -1, near = 0;
-            for (long long k = 1; k < np && m < 0; ++k)
-                for (int q = 0; q < n_tx; ++q)
-                    if (host_dist3(P + 3 * k, txs.data() + 3 * q) < maxDist) { if (m < 0) { m = k; ns = q; } ++near; }
-            if (m < 0 || np - m < 2 || np - m > 3) throw std::runtime_error("compute_M: the end of a ray does not have the expected shape");
-            if (near > 1)   // (the reference then runs its end game once per such point, on a point the first run has moved)
-                throw Unsupported("compute_M: two points of a source within a cell diagonal of the end of a ray are not supported");
-            const T* tx = txs.data() + 3 * ns;
-            const bool via = np - m == 3;
-            for (long long k = 1; k <= m; ++k) {
-                MSeg sg; sg.row = (size_t)r; sg.real = false; sg.ds = (T)0;
-                for (int c = 0; c < 3; ++c) sg.mid[c] = (T)0.5 * (P[3 * k + c] + P[3 * k + c]);
-                segs.push_back(sg);
-            }
-            auto hop = [&](const T* a, const T* b) {   // mid = 0.5 * (a + b), ds = a.getDistance(b)
-                MSeg sg; sg.row = (size_t)r; sg.real = true; sg.ds = host_dist3(a, b);
-                for (int c = 0; c < 3; ++c) sg.mid[c] = (T)0.5 * (a[c] + b[c]);
-                segs.push_back(sg);
-            };
-            const T* cm = P + 3 * m;
-            if (!via) hop(tx, cm);
-            else { hop(P + 3 * (m + 1), cm); hop(tx, P + 3 * (m + 1)); }
+            for (int q = 0; q < n_rx; ++q) { rxs[3 * q] -= ox; rxs[3 * q + 1] -= oy; rxs[3 * q + 2] -= oz; }
         }
-        // slowness at the mid-points of the weighted hops: one device call (computeSlowness(mid_pt, true))
-        std::vector<T> mids, sl;
-        for (const MSeg& sg : segs) if (sg.real) { mids.push_back(sg.mid[0]); mids.push_back(sg.mid[1]); mids.push_back(sg.mid[2]); }
-        sl.resize(mids.size() / 3);
-        if (!sl.empty()) compute_slowness((int)sl.size(), mids.data(), true, sl.data());
+        std::vector<long long> seg_off;
+        std::vector<T> segs;
+        walk_m(slot, n_tx, txs.data(), (const T*)t0_v, n_rx, rxs.data(), tt_out, both, seg_off, segs);
         if (slot_m_off.empty()) { slot_m_off.resize(n_slots); slot_m_j.resize(n_slots); slot_m_v.resize(n_slots); }
         std::vector<long long>& mo = slot_m_off[slot]; std::vector<long long>& mj = slot_m_j[slot]; std::vector<T>& mv = slot_m_v[slot];
         mo.assign((size_t)n_rx + 1, 0); mj.clear(); mv.clear();
         const size_t nnx = ncx + 1, nny = ncy + 1;
-        size_t q = 0, isl = 0;
         for (int r = 0; r < n_rx; ++r) {
             const size_t row0 = mj.size();
-            for (; q < segs.size() && segs[q].row == (size_t)r; ++q) {
-                const MSeg& sg = segs[q];
-                T sq = (T)1;   // any finite positive value: times ds = 0 it is the same signed zero
-                if (sg.real) { sq = sl[isl++]; sq *= sq; }
-                const size_t ix = (size_t)((sg.mid[0] - xmin) / dx), iy = (size_t)((sg.mid[1] - ymin) / dx), iz = (size_t)((sg.mid[2] - zmin) / dx);
+            for (long long q = seg_off[r]; q < seg_off[r + 1]; ++q) {
+                const T* sg = segs.data() + 5 * (size_t)q;
+                const T ds = sg[3];
+                T sq = sg[4];
+                sq *= sq;
+                const size_t ix = (size_t)((sg[0] - xmin) / dx), iy = (size_t)((sg[1] - ymin) / dx), iz = (size_t)((sg[2] - zmin) / dx);
                 for (size_t ii = 0; ii < 2; ++ii)
                     for (size_t jj = 0; jj < 2; ++jj)
                         for (size_t kk = 0; kk < 2; ++kk) {
                             const size_t iv = ix + ii, jv = iy + jj, kv = iz + kk;
-                            const T dvdv = (T)((1. - std::abs(sg.mid[0] - iv * dx) / dx) * (1. - std::abs(sg.mid[1] - jv * dx) / dx) *
-                                               (1. - std::abs(sg.mid[2] - kv * dx) / dx));
+                            const T dvdv = (T)((1. - std::abs(sg[0] - iv * dx) / dx) * (1. - std::abs(sg[1] - jv * dx) / dx) *
+                                               (1. - std::abs(sg[2] - kv * dx) / dx));
                             const long long j = (long long)((kv * nny + jv) * nnx + iv);
-                            const T v = -sq * sg.ds * dvdv;
+                            const T v = -sq * ds * dvdv;
                             size_t e = row0;
                             for (; e < mj.size(); ++e)
                                 if (mj[e] == j) { mv[e] += v; break; }
@@ -1791,12 +1823,15 @@ class GridT : public GridBase {
             }
             mo[r + 1] = (long long)mj.size();
         }
-        // the rays of the call, for callers that want them as well (compute_M with return_rays): shifted back like any ray
+        // the rays of the overload that keeps them (already shifted back by the origin of a translated grid)
         if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
-        slot_rays_off[slot] = rays_off;
-        slot_rays_pts[slot] = rays_pts;
-        if (translate)
-            for (size_t k = 0; k + 2 < slot_rays_pts[slot].size(); k += 3) { slot_rays_pts[slot][k] += ox; slot_rays_pts[slot][k + 1] += oy; slot_rays_pts[slot][k + 2] += oz; }
+        if (both) {
+            slot_rays_off[slot] = rays_off;
+            slot_rays_pts[slot] = rays_pts;
+        } else {
+            slot_rays_off[slot].assign(1, 0);
+            slot_rays_pts[slot].clear();
+        }
         rays_off.assign(1, 0);
         rays_pts.clear();
     }
@@ -2191,9 +2226,9 @@ class MultiGrid : public GridBase {
         g.raytrace_rays(l, n_tx, tx, t0, n_rx, rx, tt_out);
         timing = g.timing;
     }
-    void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out) override {
+    void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool both) override {
         int l; GridBase& g = of(slot, l);
-        g.raytrace_m(l, n_tx, tx, t0, n_rx, rx, tt_out);
+        g.raytrace_m(l, n_tx, tx, t0, n_rx, rx, tt_out, both);
         timing = g.timing;
     }
     void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const override { int l; GridBase& g = of(slot, l); g.slot_m_size(l, n_rows, nnz); }
@@ -2666,7 +2701,11 @@ int ttcr_fsm_raytrace_rays(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx,
 }
 int ttcr_fsm_raytrace_m(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
                         void* tt_out) {
-    return guarded_on(g, [&] { g->impl->raytrace_m(slot, n_tx, tx, t0, n_rx, rx, tt_out); });
+    return guarded_on(g, [&] { g->impl->raytrace_m(slot, n_tx, tx, t0, n_rx, rx, tt_out, false); });
+}
+int ttcr_fsm_raytrace_rm(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                        void* tt_out) {
+    return guarded_on(g, [&] { g->impl->raytrace_m(slot, n_tx, tx, t0, n_rx, rx, tt_out, true); });
 }
 int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz) {
     return guarded_on(g, [&] {

@@ -2793,6 +2793,93 @@ __global__ void fsm_raypath3d(const T* __restrict__ Tn, int ts, const T* __restr
 }
 
 
+// The walks of the two overloads that fill the matrix M (compute_M), one thread per receiver; per term block of the reference
+// (the eight nodes around a segment's mid-point get -s^2 ds w) one record  mid[3], ds, s(mid)  in segs[r][cap][5] -- the host
+// spreads them over the nodes in the reference's push order.
+// BOTH = false: Grid3Drn::getRaypath(Tx, t0, Rx, m_data, RxNo, tt, threadNo) (ttcr/Grid3Drn.h:1503-1800).  prev_pt is
+//               overwritten with curr_pt BEFORE mid-point and length are formed (:1590-1597): every step of the walk is a
+//               zero-length segment at its end point; the end game measures from the last step point, for EVERY source point
+//               within a cell diagonal (prev_pt does not move between them).
+// BOTH = true:  Grid3Drn::getRaypath(Tx, t0, Rx, r_data, m_data, RxNo, tt, threadNo) (:2144-2470), what ttcrpy calls for
+//               compute_M with return_rays: prev_pt = r_data.back() BEFORE the push, the segments carry their lengths -- except
+//               the plane point between walk and Tx, read AFTER the push (:2359-2366).  Points as fsm_raypath3d<T, true>.
+// A receiver on a source point: tt = 0 (not t0), no records.  status as fsm_raypath3d (3: more than cap records).
+template <typename T, bool BOTH>
+__global__ void fsm_raypath3d_m(const T* __restrict__ Tn, int ts, const T* __restrict__ sn, RayGeom<T> g, int n_src,
+                                const T* __restrict__ src, const T* __restrict__ t0, const T* __restrict__ rcv, int n_rcv,
+                                T* __restrict__ out, int* __restrict__ status, long max_steps, T* __restrict__ segs, long cap,
+                                int* __restrict__ nsegs) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rcv) return;
+    const T rx[3] = {rcv[3 * r], rcv[3 * r + 1], rcv[3 * r + 2]};
+    long nsg = 0;
+    T* my = segs + (size_t)r * cap * 5;
+    auto seg = [&](const T* a, const T* b) {   // mid_pt = 0.5 * (a + b), ds = a.getDistance(b), s = computeSlowness(mid_pt, true)
+        if (nsg < cap) {
+            T* p = my + 5 * nsg;
+            p[0] = (T)0.5 * (a[0] + b[0]); p[1] = (T)0.5 * (a[1] + b[1]); p[2] = (T)0.5 * (a[2] + b[2]);
+            p[3] = dist3(a, b);
+            p[4] = slowness_at3d(g, sn, p[0], p[1], p[2]);
+        }
+        ++nsg;
+    };
+    auto finish = [&](int st, T tt) {
+        nsegs[r] = (int)nsg;
+        if (st == 0 && nsg > cap) st = 3;
+        status[r] = st;
+        out[r] = tt;
+    };
+    for (int ns = 0; ns < n_src; ++ns)
+        if (rx[0] == src[3 * ns] && rx[1] == src[3 * ns + 1] && rx[2] == src[3 * ns + 2]) { finish(0, (T)0); return; }
+    T back[3] = {rx[0], rx[1], rx[2]}, cur[3] = {rx[0], rx[1], rx[2]}, gv[3];
+    T tt = 0, s1, s2;
+    s1 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
+    const T dx = g.dx;
+    const T maxDist = (T)__builtin_sqrt((double)(dx * dx + dx * dx + dx * dx));
+    bool reached = false;
+    long steps = 0;
+    auto set_back = [&](const T* p) { back[0] = p[0]; back[1] = p[1]; back[2] = p[2]; };
+    while (!reached) {
+        if (++steps > max_steps) { finish(2, tt); return; }
+        grad3d(g, Tn, ts, cur[0], cur[1], cur[2], gv);
+        gv[0] *= (T)-1.0; gv[1] *= (T)-1.0; gv[2] *= (T)-1.0;
+        step_to_plane(g, cur, gv);
+        if (cur[0] < g.xmin || cur[0] > g.xmax || cur[1] < g.ymin || cur[1] > g.ymax || cur[2] < g.zmin || cur[2] > g.zmax) {
+            finish(1, tt); return;
+        }
+        s2 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
+        tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(back, cur));
+        s1 = s2;
+        if (BOTH) { seg(cur, back); set_back(cur); } else { set_back(cur); seg(cur, back); }
+        for (int ns = 0; ns < n_src; ++ns) {
+            const T tx[3] = {src[3 * ns], src[3 * ns + 1], src[3 * ns + 2]};
+            const T dist = dist3(cur, tx);
+            if (dist < maxDist) {
+                gv[0] = tx[0] - cur[0]; gv[1] = tx[1] - cur[1]; gv[2] = tx[2] - cur[2];
+                step_to_plane(g, cur, gv);
+                if (dist3(cur, back) > dist || (cur[0] == tx[0] && cur[1] == tx[1] && cur[2] == tx[2])) {
+                    s2 = slowness_at3d(g, sn, tx[0], tx[1], tx[2]);
+                    tt = (T)((double)tt + ((double)t0[ns] + (0.5 * (double)(s1 + s2)) * (double)dist3(back, tx)));
+                    seg(tx, back);
+                    if (BOTH) set_back(tx);
+                } else {
+                    s2 = slowness_at3d(g, sn, cur[0], cur[1], cur[2]);
+                    tt = (T)((double)tt + (0.5 * (double)(s1 + s2)) * (double)dist3(back, cur));
+                    s1 = s2;
+                    if (BOTH) set_back(cur);
+                    seg(cur, back);
+                    s2 = slowness_at3d(g, sn, tx[0], tx[1], tx[2]);
+                    tt = (T)((double)tt + ((double)t0[ns] + (0.5 * (double)(s1 + s2)) * (double)dist3(cur, tx)));
+                    seg(tx, cur);
+                    if (BOTH) set_back(tx);
+                }
+                reached = true;
+            }
+        }
+    }
+    finish(0, tt);
+}
+
 // rays recorded in fixed-capacity rows -> one dense array (ray r occupies points [off[r], off[r+1]))
 template <typename T>
 __global__ void fsm_compact_rays(const T* __restrict__ pts, long cap, const long long* __restrict__ off,

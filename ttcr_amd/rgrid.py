@@ -561,7 +561,8 @@ class _Grid3d(_GridBase):
             self.set_option("return_rays", 0)
 
     def _run_m(self, vTx, vt0, vRx, iRx, n_rcv, return_rays):
-        """compute_M=True (rgrid.pyx:1040-1060, :1171-1199): per event the overload with m_data, then one scipy CSR matrix
+        """compute_M=True (rgrid.pyx:1040-1060, :1171-1199): per event the overload with m_data (with r_data and m_data when the
+        rays are asked for as well), then one scipy CSR matrix
         (receivers of the event x nodes) per event, columns ascending, entries whose node index is not below the node count
         dropped -- what the reference's Python layer builds.  Traveltimes are those of that overload."""
         import scipy.sparse as sp
@@ -577,7 +578,9 @@ class _Grid3d(_GridBase):
             t0 = np.ascontiguousarray(vt0[n], dtype=dt)
             rx = np.ascontiguousarray(vRx[n], dtype=dt).reshape(-1, 3)
             out = np.empty(rx.shape[0], dtype=dt)
-            _lib.check(self._lib.ttcr_fsm_raytrace_m(self._h, slot, tx.shape[0], _ptr(tx), _ptr(t0), rx.shape[0], _ptr(rx), _ptr(out)))
+            # (with return_rays ttcrpy calls the overload that keeps r_data AND m_data, rgrid.pyx:1050 -- its matrix is another one)
+            call = self._lib.ttcr_fsm_raytrace_rm if return_rays else self._lib.ttcr_fsm_raytrace_m
+            _lib.check(call(self._h, slot, tx.shape[0], _ptr(tx), _ptr(t0), rx.shape[0], _ptr(rx), _ptr(out)))
             tt[iRx[n]] = out
             nrow, nnz = C.c_size_t(0), C.c_size_t(0)
             _lib.check(self._lib.ttcr_fsm_slot_m_size(self._h, slot, C.byref(nrow), C.byref(nnz)))
