@@ -53,6 +53,8 @@ def test_random_configurations_match_the_oracle(oracle, seed):
         src = np.column_stack([rng.uniform(a[1] if a.size > 2 else a[0], a[-2] if a.size > 2 else a[-1], npt) for a in axes])
         if rng.random() < 0.4:
             src[0] = [a[int(rng.integers(0, a.size))] for a in axes]
+        if npt == 2 and rng.random() < 0.4:   # the second point within a cell of the first: the end game of a ray serves both
+            src[1] = np.clip(src[0] + rng.uniform(-0.6, 0.6, dim) * np.array(steps), [a[0] for a in axes], [a[-1] for a in axes])
         t0 = np.round(rng.uniform(0, 0.5, npt), 3) if rng.random() < 0.5 else np.zeros(npt)
         rcv = np.column_stack([rng.uniform(a[0], a[-1], 4) for a in axes])
         rcv[0] = [a[int(rng.integers(0, a.size))] for a in axes]

@@ -84,6 +84,59 @@ def test_raypaths_2d_bit_exact_vs_reference(O, dt):
             f(**kw)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_raypaths_with_close_source_points_vs_reference(O, dt):
+    """Sources of two or three points within a cell of each other (aggregate_src): the end game of a ray runs once for EVERY point
+    within a cell diagonal of the walk's last step -- on a point the previous run has moved, and with origin times that add up.
+    tt_from_rp, return_rays (and compute_L in 2-D) of the restatement against the compiled reference."""
+    rng = np.random.default_rng(41)
+    for trial in range(8):
+        nc = tuple(int(v) for v in rng.integers(9, 15, 3))
+        dx = float(rng.choice([0.5, 1.0, 2.0]))
+        nn = tuple(v + 1 for v in nc)
+        s = np.repeat(1.0 / (1.0 + 0.05 * np.arange(nn[2]) * dx), nn[0] * nn[1]) * rng.uniform(0.9, 1.1, nn[0] * nn[1] * nn[2])
+        hi = np.array(nc) * dx
+        src = rng.uniform(1.5 * dx, hi - 1.5 * dx, (1, 3))
+        src = np.vstack([src] + [src[0] + rng.uniform(-0.6, 0.6, 3) * dx for _ in range(1 + trial % 2)])
+        kw = dict(dtype=dt, ncells=nc, dx=dx, origin=(0, 0, 0), slowness=s, src=src, t0=rng.uniform(0, 0.5, src.shape[0]).round(3),
+                  rcv=rng.uniform(0.7 * dx, hi - 0.7 * dx, (6, 3)), weno=bool(trial % 2))
+        for opt in (dict(tt_from_rp=True), dict(return_rays=True)):
+            try:
+                a = O.solve3d(**kw, **opt)
+            except RuntimeError as e:
+                assert "going outside grid" in str(e)
+                continue
+            b = O.ref_solve3d(**kw, **opt)
+            np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
+            for u, v in zip(a.get("rays", []), b.get("rays", [])):
+                np.testing.assert_array_equal(u, v)
+    for trial in range(8):
+        nc = tuple(int(v) for v in rng.integers(12, 30, 2))
+        dx, dz = float(rng.choice([0.5, 1.0])), float(rng.choice([0.5, 0.4, 1.0]))
+        cell = bool(trial % 2)
+        nn = tuple(v + 1 for v in nc)
+        X, Z = np.meshgrid(np.arange(nn[0]) * dx, np.arange(nn[1]) * dz, indexing="ij")
+        sn = 1.0 / (1.0 + 0.04 * Z) * (1.0 + 0.2 * np.exp(-((X - 4) ** 2 + (Z - 3) ** 2) / 6.0))
+        hi = np.array(nc) * np.array([dx, dz])
+        src = rng.uniform(1.5 * np.array([dx, dz]), hi - 1.5 * np.array([dx, dz]), (1, 2))
+        src = np.vstack([src] + [src[0] + rng.uniform(-0.6, 0.6, 2) * np.array([dx, dz]) for _ in range(1 + trial % 2)])
+        kw = dict(dtype=dt, ncells=nc, dx=dx, dz=dz, origin=(0, 0), slowness=(sn[:-1, :-1] if cell else sn).ravel(), src=src,
+                  t0=rng.uniform(0, 0.5, src.shape[0]).round(3), cell_slowness=cell, rcv=rng.uniform(0.7 * dz, hi - 0.7 * dx, (6, 2)), weno=False)
+        for opt in (dict(tt_from_rp=True), dict(return_rays=True)) + ((dict(compute_L=True), dict(compute_L=True, return_rays=True)) if cell else ()):
+            try:
+                a = O.solve2d(**kw, **opt)
+            except RuntimeError as e:
+                assert "going outside grid" in str(e)
+                continue
+            b = O.ref_solve2d(**kw, **opt)
+            np.testing.assert_array_equal(a["tt_rcv"], b["tt_rcv"])
+            for u, v in zip(a.get("rays", []), b.get("rays", [])):
+                np.testing.assert_array_equal(u, v)
+            for (c1, l1), (c2, l2) in zip(a.get("l", []), b.get("l", [])):
+                # (std::sort leaves the order of the entries of ONE cell open: equal as multisets per cell)
+                assert sorted(zip(c1.tolist(), l1.tolist())) == sorted(zip(c2.tolist(), l2.tolist()))
+
+
 def test_reference_rejects_outside_point(O):
     with pytest.raises(RuntimeError, match="outside grid"):
         O.ref_solve3d(np.float64, (4, 4, 4), 1.0, (0, 0, 0), np.ones(125), [[5.0, 1.0, 1.0]])
