@@ -1930,7 +1930,11 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
 // The WENO stage and the 2-D kernels keep one workgroup per unit: their units are long and alike, and the loop costs them
 // registers (WENO, one 256^3 source: 365 -> 406 ms looped; 2-D 4096^2 x 64: 17.6 -> 18.2 ms).
 template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE = false>
-__global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeof(T) == 4) ? 3 : FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
+#ifndef FSM_WENO_MINW
+#define FSM_WENO_MINW FSM_MINW   // resident workgroups per SIMD asked of the fp32 3-D WENO kernel (one field per workgroup)
+#endif
+__global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeof(T) == 4) ? 3
+                                     : (IS3D && H == 2 && NS == 1 && sizeof(T) == 4) ? FSM_WENO_MINW : FSM_MINW) void fsm_sweep_persistent(const PersistArgs<T> pa) {
     if constexpr (fsm_looped(IS3D, H)) {
         // Nothing is to be carried from one unit to the next: the arguments are read again from the kernel argument segment
         // through a pointer the compiler cannot see through (it would otherwise hoist everything that depends on them out of
