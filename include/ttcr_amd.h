@@ -132,7 +132,7 @@ int ttcr_fsm_get_tt(ttcr_fsm_grid* g, int slot, void* out, size_t n);
 /* The same field for a consumer on the device (no reference equivalent; the reference only has the host copy above).
  * ttcr_fsm_get_tt_device: pointer to n_nodes CONTIGUOUS values of slot `slot` in the flat order above.  Where every
  *   slot has its own field (one slot; 2-D grids; weno = 1) this is the field itself; on a first-order 3-D grid whose
- *   batches are big enough for source pairs to pay (n_slots x 16x16 column patches of a sweep > 12 288: e.g. 16 slots
+ *   batches are big enough for source pairs to pay (n_slots x 16x16 column patches of a sweep > 6 144: e.g. 8 slots
  *   at 512^3, 32 at 256^3) the fields of two slots are interleaved in HBM, so the call de-interleaves into a scratch buffer of
  *   the grid: the pointer stays valid until the next ttcr_fsm_get_tt / ttcr_fsm_get_tt_device call or the
  *   destruction of the grid.
@@ -183,7 +183,7 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  (up to 0.5 s per 512^3 field and iteration); tests/test_stopping_rule_gpu.py
  *   "wave"         1: first-order 3-D sweeps of fp32 grids with one field per slot use the one-wavefront kernel
  *                  (fsm_wave_kernels.h; slower at present, see profiles/r04/wave_kernel.txt); default off
- *   "pair_sources" 1 (default): where the grid keeps its fields in pairs (n_slots x patches of a sweep > 12 288, env
+ *   "pair_sources" 1 (default): where the grid keeps its fields in pairs (n_slots x patches of a sweep > 6 144, env
  *                  TTCR_FSM_PAIR_UNITS; TTCR_FSM_PAIR = 1 / 0 forces / forbids the pair layout at grid creation) the sources
  *                  of a batch are paired by distance before they share a workgroup two by two
  *   "combine_window_us"  single-source calls from several host threads wait this long for one another before they go

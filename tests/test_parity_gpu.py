@@ -655,7 +655,7 @@ def test_hip_device_views_of_a_field(monkeypatch):
     sink2 = ttcr_amd.Grid3d(np.arange(2 * n) * 0.5, x, x, cell_slowness=0, method="FSM", dtype=np.float32)   # 2 nn values
     # (one slot; three slots of a first-order grid: interleaved pairs; three slots with weno=1: one field per slot)
     # (pair: the sources of a call paired by distance -- a slot's field may lie in another slot's storage -- or not)
-    # (source pairs are the layout of big batches -- slots x patches > 12 288 --; on this small grid they are asked for)
+    # (source pairs are the layout of big batches -- slots x patches > 6 144 --; on this small grid they are asked for)
     for nthr, weno, want_stride, pair in ((1, 0, 1, 1), (3, 0, 2, 1), (3, 0, 2, 0), (3, 1, 1, 1), (3, 0, 1, 1)):
         if want_stride == 2:
             monkeypatch.setenv("TTCR_FSM_PAIR", "1")

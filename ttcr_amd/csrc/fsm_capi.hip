@@ -348,13 +348,17 @@ class GridT : public GridBase {
         // 16 sources 28.0 -> 20.8 ms, 64 sources 35.8 -> 28.9 ms, 256 sources 112 -> 87 ms unpaired); the WENO stage
         // is bound by its arithmetic, and pairs cost it a resident wave (256^3: 2 sources 761 -> 483 ms, 8 sources
         // 1208 -> 973 ms, 16 sources 1740 -> 1672 ms, 64 sources 5986 -> 6221 ms).  profiles/r02/pairing.txt
-        // Round 4, with exact skipping on by default for batches: pairs only pay once the chip has more work units than it can
-        // keep in flight -- a chunk of a pair is evaluated when EITHER source needs it and a pair's level is the longer chain.
-        // 512^3 (1 024 patches), ms per sweep-iteration paired / unpaired: 2 sources 10.1 / 8.1, 4: 12.0 / 10.6, 8: 17.3 / 16.2,
-        // 16: 27.2 / 30.2, 32: 45.9 / 58.4; 256^3 (256 patches): 8 sources 5.7 / 4.5, 16: 6.5 / 6.1 (profiles/r04/README.md).
-        // So: pairs when slots x patches of a sweep exceed pair_units_min.
+        // Round 4, with exact skipping on by default for batches: on a model where most chunks are skipped, pairs only pay once the
+        // chip has more work units than it can keep in flight -- a chunk of a pair is evaluated when EITHER source needs it and a
+        // pair's level is the longer chain; on a model where most chunks are evaluated they pay from 4 sources on.
+        // 512^3 (1 024 patches), ms per sweep-iteration paired / unpaired, gradient model (66 % of the updates skipped):
+        //   2 sources 10.1 / 8.1, 4: 12.0 / 10.6, 8: 17.3 / 16.2, 16: 27.2 / 30.2, 32: 45.9 / 58.4; 256^3: 8 sources 5.7 / 4.5, 16: 6.5 / 6.1
+        // ms per solve, random 16^3-block model (8-11 iterations, 75-83 % evaluated):
+        //   2 sources 109.9 / 110.5, 4: 191 / 203, 8: 314 / 372, 16: 556 / 710      (profiles/r04/README.md)
+        // So: pairs when slots x patches of a sweep exceed pair_units_min = 6 144 (512^3: from 8 sources on, where the smooth model
+        // loses 7 % and the rough one gains 18 %; below, the smooth model gains 13-25 % and the rough one loses 0-6 %).
         {
-            long long pair_units_min = 12288;
+            long long pair_units_min = 6144;
             if (const char* e = std::getenv("TTCR_FSM_PAIR_UNITS")) pair_units_min = std::atoll(e);   // tuning only
             const long long patches = dim == 3 ? (long long)((ny + 1 + TileCfg<T, 3>::PJ - 1) / TileCfg<T, 3>::PJ) * ((nz + 1 + TileCfg<T, 3>::PK - 1) / TileCfg<T, 3>::PK) : 0;
             NS = (n_slots >= 2 && dim == 3 && !weno && (long long)n_slots * patches > pair_units_min) ? 2 : 1;
