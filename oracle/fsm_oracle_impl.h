@@ -30,6 +30,13 @@
 /* ttcr/ttcr_t.h:42-43 */
 #define FSM_SMALL 1.e-4
 #define FSM_SMALL2 (FSM_SMALL * FSM_SMALL)
+/* Index of a coordinate.  The reference converts a double to its unsigned index type; for a point OUTSIDE the grid (the end game
+ * of a ray with several source points within a cell diagonal moves curr_pt without a bounds check, e.g. ttcr/Grid2Drn.h:1596-1655)
+ * the conversion of a negative value is undefined in C++ -- the compiled reference then reads far outside its arrays (garbage
+ * traveltimes, or a crash).  Here and in the HIP kernels: negative -> 0, followed by the callers' upper clamps, i.e. the nearest
+ * cell / node.  Identical to the plain conversion for every point inside the grid. */
+#undef FSM_U32
+#define FSM_U32(v) ((v) < 0 ? (uint32_t)0 : ((v) >= 4294967295.0 ? (uint32_t)4294967295u : (uint32_t)(v)))
 
 /* ------------------------------------------------------------------ 3D -- */
 
@@ -126,9 +133,9 @@ static void SFX(cell3d)(const SFX(fsm_grid3d) * g, REAL px, REAL py, REAL pz, pt
     REAL x = g->xmax - px < FSM_SMALL2 ? (REAL)(g->xmax - .5 * g->dx) : px;
     REAL y = g->ymax - py < FSM_SMALL2 ? (REAL)(g->ymax - .5 * g->dx) : py;
     REAL z = g->zmax - pz < FSM_SMALL2 ? (REAL)(g->zmax - .5 * g->dx) : pz;
-    uint32_t nx = (uint32_t)(FSM_SMALL2 + (x - g->xmin) / g->dx);
-    uint32_t ny = (uint32_t)(FSM_SMALL2 + (y - g->ymin) / g->dx);
-    uint32_t nz = (uint32_t)(FSM_SMALL2 + (z - g->zmin) / g->dx);
+    uint32_t nx = FSM_U32(FSM_SMALL2 + (x - g->xmin) / g->dx);
+    uint32_t ny = FSM_U32(FSM_SMALL2 + (y - g->ymin) / g->dx);
+    uint32_t nz = FSM_U32(FSM_SMALL2 + (z - g->zmin) / g->dx);
     const ptrdiff_t cellNo = (ptrdiff_t)(uint32_t)(ny * ncx + nz * (ncx * ncy) + nx);
     const ptrdiff_t k = cellNo / ((ptrdiff_t)ncy * ncx);
     const ptrdiff_t j = (cellNo - k * (ptrdiff_t)ncy * ncx) / ncx;
@@ -425,9 +432,9 @@ int SFX(fsm_solve3d)(const SFX(fsm_grid3d) * g, const REAL* s, int n_src, const 
 REAL SFX(fsm_interp3d)(const SFX(fsm_grid3d) * g, const REAL* T, REAL px, REAL py, REAL pz) {
     const size_t nnx = g->nnx, nny = g->nny, nnz = g->nnz;
     const REAL xmin = g->xmin, ymin = g->ymin, zmin = g->zmin, dx = g->dx, dy = g->dx, dz = g->dx;
-    const uint32_t i = (uint32_t)(FSM_SMALL2 + (px - xmin) / dx);
-    const uint32_t j = (uint32_t)(FSM_SMALL2 + (py - ymin) / dy);
-    const uint32_t k = (uint32_t)(FSM_SMALL2 + (pz - zmin) / dz);
+    const uint32_t i = FSM_U32(FSM_SMALL2 + (px - xmin) / dx);
+    const uint32_t j = FSM_U32(FSM_SMALL2 + (py - ymin) / dy);
+    const uint32_t k = FSM_U32(FSM_SMALL2 + (pz - zmin) / dz);
     const int onx = FABS(px - (xmin + i * dx)) < FSM_SMALL2;
     const int ony = FABS(py - (ymin + j * dy)) < FSM_SMALL2;
     const int onz = FABS(pz - (zmin + k * dz)) < FSM_SMALL2;
@@ -541,42 +548,42 @@ static REAL SFX(slowness_at3d)(const SFX(fsm_grid3d) * g, const REAL* sn, REAL p
     if (onX != -1 && onY != -1 && onZ != -1) {
         return sn[((size_t)onZ * nny + onY) * nnx + onX];
     } else if (onX != -1 && onY != -1) {
-        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        uint32_t k = FSM_U32(FSM_SMALL + (pz - zmin) / dz);
         s[0] = SN(onX, onY, k); s[1] = SN(onX, onY, k + 1);
         x[0] = pz; x[1] = zmin + k * dz; x[2] = zmin + (k + 1) * dz;
         RET(SFX(lin1)(x, s));
     } else if (onX != -1 && onZ != -1) {
-        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
+        uint32_t j = FSM_U32(FSM_SMALL + (py - ymin) / dy);
         s[0] = SN(onX, j, onZ); s[1] = SN(onX, j + 1, onZ);
         x[0] = py; x[1] = ymin + j * dy; x[2] = ymin + (j + 1) * dy;
         RET(SFX(lin1)(x, s));
     } else if (onY != -1 && onZ != -1) {
-        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+        uint32_t i = FSM_U32(FSM_SMALL + (px - xmin) / dx);
         s[0] = SN(i, onY, onZ); s[1] = SN(i + 1, onY, onZ);
         x[0] = px; x[1] = xmin + i * dx; x[2] = xmin + (i + 1) * dx;
         RET(SFX(lin1)(x, s));
     } else if (onX != -1) {
-        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
-        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        uint32_t j = FSM_U32(FSM_SMALL + (py - ymin) / dy);
+        uint32_t k = FSM_U32(FSM_SMALL + (pz - zmin) / dz);
         s[0] = SN(onX, j, k); s[1] = SN(onX, j, k + 1); s[2] = SN(onX, j + 1, k); s[3] = SN(onX, j + 1, k + 1);
         x[0] = py; y[0] = pz; x[1] = ymin + j * dy; y[1] = zmin + k * dz; x[2] = ymin + (j + 1) * dy; y[2] = zmin + (k + 1) * dz;
         RET(SFX(lin2)(x, y, s));
     } else if (onY != -1) {
-        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
-        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        uint32_t i = FSM_U32(FSM_SMALL + (px - xmin) / dx);
+        uint32_t k = FSM_U32(FSM_SMALL + (pz - zmin) / dz);
         s[0] = SN(i, onY, k); s[1] = SN(i, onY, k + 1); s[2] = SN(i + 1, onY, k); s[3] = SN(i + 1, onY, k + 1);
         x[0] = px; y[0] = pz; x[1] = xmin + i * dx; y[1] = zmin + k * dz; x[2] = xmin + (i + 1) * dx; y[2] = zmin + (k + 1) * dz;
         RET(SFX(lin2)(x, y, s));
     } else if (onZ != -1) {
-        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
-        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
+        uint32_t i = FSM_U32(FSM_SMALL + (px - xmin) / dx);
+        uint32_t j = FSM_U32(FSM_SMALL + (py - ymin) / dy);
         s[0] = SN(i, j, onZ); s[1] = SN(i, j + 1, onZ); s[2] = SN(i + 1, j, onZ); s[3] = SN(i + 1, j + 1, onZ);
         x[0] = px; y[0] = py; x[1] = xmin + i * dx; y[1] = ymin + j * dy; x[2] = xmin + (i + 1) * dx; y[2] = ymin + (j + 1) * dy;
         RET(SFX(lin2)(x, y, s));
     } else {
-        uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
-        uint32_t j = (uint32_t)(FSM_SMALL + (py - ymin) / dy);
-        uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        uint32_t i = FSM_U32(FSM_SMALL + (px - xmin) / dx);
+        uint32_t j = FSM_U32(FSM_SMALL + (py - ymin) / dy);
+        uint32_t k = FSM_U32(FSM_SMALL + (pz - zmin) / dz);
         s[0] = SN(i, j, k); s[1] = SN(i, j, k + 1); s[2] = SN(i, j + 1, k); s[3] = SN(i, j + 1, k + 1);
         s[4] = SN(i + 1, j, k); s[5] = SN(i + 1, j, k + 1); s[6] = SN(i + 1, j + 1, k); s[7] = SN(i + 1, j + 1, k + 1);
         x[0] = px; y[0] = py; z[0] = pz;
@@ -1146,8 +1153,8 @@ static void SFX(init2d)(const SFX(fsm_grid2d) * g, const REAL* s, REAL* T, unsig
         } else {
             REAL x = g->xmax - px < FSM_SMALL ? (REAL)(g->xmax - .5 * g->dx) : px;
             REAL z = g->zmax - pz < FSM_SMALL ? (REAL)(g->zmax - .5 * g->dz) : pz;
-            const uint32_t cnx = (uint32_t)(FSM_SMALL + (x - g->xmin) / g->dx);
-            const uint32_t cnz = (uint32_t)(FSM_SMALL + (z - g->zmin) / g->dz);
+            const uint32_t cnx = FSM_U32(FSM_SMALL + (x - g->xmin) / g->dx);
+            const uint32_t cnz = FSM_U32(FSM_SMALL + (z - g->zmin) / g->dz);
             const ptrdiff_t cellNo = (ptrdiff_t)(uint32_t)(cnx * (uint32_t)ncz + cnz);
             const ptrdiff_t i = cellNo / ncz;
             const ptrdiff_t j = cellNo - i * ncz;
@@ -1292,8 +1299,8 @@ int SFX(fsm_solve2d)(const SFX(fsm_grid2d) * g, const REAL* s, int n_src, const 
 REAL SFX(fsm_interp2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL pz) {
     const size_t nnx = g->nnx, nnz = g->nnz;
     const REAL xmin = g->xmin, zmin = g->zmin, dx = g->dx, dz = g->dz;
-    const uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
-    const uint32_t j = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+    const uint32_t i = FSM_U32(FSM_SMALL + (px - xmin) / dx);
+    const uint32_t j = FSM_U32(FSM_SMALL + (pz - zmin) / dz);
     const int onx = FABS(px - (xmin + i * dx)) < FSM_SMALL;
     const int onz = FABS(pz - (zmin + j * dz)) < FSM_SMALL;
 /* index = quotient + 1e-4 (in cells), "on the line" = ABSOLUTE distance below 1e-4: with dx > 1 a point between
@@ -1344,18 +1351,18 @@ REAL SFX(fsm_compute_slowness2d)(const SFX(fsm_grid2d) * g, const REAL* sn, REAL
     if (onX != -1 && onZ != -1) {
         return sn[(size_t)onX * nnz + onZ];
     } else if (onX != -1) {
-        const uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+        const uint32_t k = FSM_U32(FSM_SMALL + (pz - zmin) / dz);
         s[0] = S2(onX, k); s[1] = S2(onX, k + 1);
         x[0] = pz; x[1] = zmin + k * dz; x[2] = zmin + (k + 1) * dz;
         return SFX(lin1)(x, s);
     } else if (onZ != -1) {
-        const uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
+        const uint32_t i = FSM_U32(FSM_SMALL + (px - xmin) / dx);
         s[0] = S2(i, onZ); s[1] = S2(i + 1, onZ);
         x[0] = px; x[1] = xmin + i * dx; x[2] = xmin + (i + 1) * dx;
         return SFX(lin1)(x, s);
     }
-    const uint32_t i = (uint32_t)(FSM_SMALL + (px - xmin) / dx);
-    const uint32_t k = (uint32_t)(FSM_SMALL + (pz - zmin) / dz);
+    const uint32_t i = FSM_U32(FSM_SMALL + (px - xmin) / dx);
+    const uint32_t k = FSM_U32(FSM_SMALL + (pz - zmin) / dz);
     s[0] = S2(i, k); s[1] = S2(i, k + 1); s[2] = S2(i + 1, k); s[3] = S2(i + 1, k + 1);
     x[0] = px; z[0] = pz; x[1] = xmin + i * dx; z[1] = zmin + k * dz; x[2] = xmin + (i + 1) * dx; z[2] = zmin + (k + 1) * dz;
     return SFX(lin2)(x, z, s);
@@ -1390,8 +1397,8 @@ static void SFX(grad2d)(const SFX(fsm_grid2d) * g, const REAL* T, REAL px, REAL 
 static uint32_t SFX(cellno2d)(const SFX(fsm_grid2d) * g, REAL px, REAL pz) {
     const REAL x = g->xmax - px < FSM_SMALL ? (REAL)(g->xmax - .5 * g->dx) : px;
     const REAL z = g->zmax - pz < FSM_SMALL ? (REAL)(g->zmax - .5 * g->dz) : pz;
-    uint32_t nx = (uint32_t)(FSM_SMALL + (x - g->xmin) / g->dx);
-    uint32_t nz = (uint32_t)(FSM_SMALL + (z - g->zmin) / g->dz);
+    uint32_t nx = FSM_U32(FSM_SMALL + (x - g->xmin) / g->dx);
+    uint32_t nz = FSM_U32(FSM_SMALL + (z - g->zmin) / g->dz);
     /* (xmax - px < small is an absolute test, the index a relative one: with dx > 1 a point between 1e-4 and
      * 1e-4*dx below xmax gets the cell past the last one and the reference reads past its cell array: clamped) */
     if (nx > (uint32_t)(g->nnx - 2)) nx = (uint32_t)(g->nnx - 2);

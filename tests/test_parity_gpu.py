@@ -4,6 +4,8 @@
   (b) the CPU oracle on the same inputs.
 Bar: BIT-EXACT traveltime fields, receiver values and iteration counts, float32 and float64
 (north_star only asks for 1e-5 s RMS; the kernels mirror the reference's rounding exactly)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -753,3 +755,33 @@ def test_hip_concurrent_single_source_calls_are_combined_and_isolated(oracle):
         assert g.get_niter(k) == o["niter"]
     # the calls really went to the device together: the last batch held more than one source
     assert g.timing()["n_sources"] > 1
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hip_end_game_that_leaves_the_grid(oracle, dt):
+    """Found by the fuzz (seed 12, configuration 11 251): 8 x 7 cells of 2.3 x 0.125, a source of two points 1.5 apart.  The end game
+    of a ray runs once per source point within a cell diagonal and moves curr_pt WITHOUT a bounds check (ttcr/Grid2Drn.h:1596-1655):
+    the second run starts from a point outside the grid, the mid-point of its segment has a negative cell coordinate, and the
+    reference converts that to an unsigned index -- undefined behaviour: the compiled reference returns traveltimes read from outside
+    its cell array for receivers 0 and 3 and crashes for receiver 1.  HIP and the restatement define it the same way (negative ->
+    cell 0, idx_u32 / FSM_U32) and must agree: traveltimes from raypaths and rays."""
+    import ttcr_amd
+
+    c = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "endgame_outside_case.npz"))
+    nc = tuple(int(v) for v in c["nc"])
+    dx, dz, org = float(c["dx"]), float(c["dz"]), tuple(float(v) for v in c["org"])
+    axes = [org[0] + np.arange(nc[0] + 1) * dx, org[1] + np.arange(nc[1] + 1) * dz]
+    source = np.hstack([c["t0"][:, None], c["src"]])
+    kw = dict(dtype=dt, ncells=nc, dx=dx, dz=dz, origin=org, slowness=c["slowness"].ravel(), src=c["src"], t0=c["t0"], cell_slowness=True,
+              rcv=c["rcv"], weno=True)
+    for opt in (dict(tt_from_rp=True), dict(return_rays=True)):
+        o = oracle.solve2d(**kw, **opt)
+        g = ttcr_amd.Grid2d(*axes, cell_slowness=True, method="FSM", tt_from_rp=int(opt.get("tt_from_rp", False)), weno=1, dtype=dt)
+        out = g.raytrace(source, c["rcv"], slowness=c["slowness"], aggregate_src=True, return_rays=opt.get("return_rays", False))
+        tt = out[0] if isinstance(out, tuple) else out
+        np.testing.assert_array_equal(tt, o["tt_rcv"])
+        if "return_rays" in opt:
+            for a, b in zip(out[1], o["rays"]):
+                np.testing.assert_array_equal(a, b.astype(np.float64))
+            assert sum(len(r) >= 3 and np.array_equal(r[-1], c["src"][1].astype(dt)) and np.array_equal(r[-2], c["src"][0].astype(dt))
+                       for r in o["rays"]) == 3   # (both points of the source at the end of three of the four rays)

@@ -53,6 +53,13 @@ template <> struct real_traits<double> {
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
 };
 
+// Index of a coordinate (ray walks, interpolation).  The reference converts a double to its unsigned index type; for a point
+// OUTSIDE the grid -- the end game of a ray with several source points within a cell diagonal moves curr_pt without a bounds check
+// (e.g. ttcr/Grid2Drn.h:1596-1655) -- that conversion of a negative value is undefined in C++ and the compiled reference reads far
+// outside its arrays.  Here, as in the oracle (FSM_U32): negative -> 0, followed by the callers' upper clamps (the nearest cell /
+// node); identical to the plain conversion for every point inside the grid.
+__device__ __forceinline__ uint32_t idx_u32(double v) { return v < 0 ? 0u : (v >= 4294967295.0 ? 4294967295u : (uint32_t)v); }
+
 __device__ __forceinline__ float rmin(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ double rmin(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ float rmax(float a, float b) { return a < b ? b : a; }
@@ -2433,9 +2440,9 @@ __device__ __forceinline__ T interp3d_pt(const T* __restrict__ Tn, int ts, T px,
                                          T xmin, T ymin, T zmin) {
     const double small2 = 1.e-4 * 1.e-4;
     const T dy = dx, dz = dx;
-    const uint32_t i = (uint32_t)(small2 + (double)((px - xmin) / dx));
-    const uint32_t j = (uint32_t)(small2 + (double)((py - ymin) / dy));
-    const uint32_t k = (uint32_t)(small2 + (double)((pz - zmin) / dz));
+    const uint32_t i = idx_u32(small2 + (double)((px - xmin) / dx));
+    const uint32_t j = idx_u32(small2 + (double)((py - ymin) / dy));
+    const uint32_t k = idx_u32(small2 + (double)((pz - zmin) / dz));
     auto ab = [](T v) { return v < 0 ? -v : v; };
     const bool onx = (double)ab(px - (xmin + (T)i * dx)) < small2;
     const bool ony = (double)ab(py - (ymin + (T)j * dy)) < small2;
@@ -2603,42 +2610,42 @@ __device__ T slowness_at3d(const RayGeom<T>& g, const T* __restrict__ sn, T px, 
     if (onX != -1 && onY != -1 && onZ != -1) {
         return sn[((size_t)onZ * nny + onY) * nnx + onX];
     } else if (onX != -1 && onY != -1) {
-        const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+        const unsigned k = idx_u32(small + (double)((pz - zmin) / dz));
         s[0] = SN(onX, onY, k); s[1] = SN(onX, onY, k + 1);
         x[0] = pz; x[1] = zmin + (T)k * dz; x[2] = zmin + (T)(k + 1) * dz;
         return RET(lin1(x, s));
     } else if (onX != -1 && onZ != -1) {
-        const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
+        const unsigned j = idx_u32(small + (double)((py - ymin) / dy));
         s[0] = SN(onX, j, onZ); s[1] = SN(onX, j + 1, onZ);
         x[0] = py; x[1] = ymin + (T)j * dy; x[2] = ymin + (T)(j + 1) * dy;
         return RET(lin1(x, s));
     } else if (onY != -1 && onZ != -1) {
-        const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
+        const unsigned i = idx_u32(small + (double)((px - xmin) / dx));
         s[0] = SN(i, onY, onZ); s[1] = SN(i + 1, onY, onZ);
         x[0] = px; x[1] = xmin + (T)i * dx; x[2] = xmin + (T)(i + 1) * dx;
         return RET(lin1(x, s));
     } else if (onX != -1) {
-        const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
-        const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+        const unsigned j = idx_u32(small + (double)((py - ymin) / dy));
+        const unsigned k = idx_u32(small + (double)((pz - zmin) / dz));
         s[0] = SN(onX, j, k); s[1] = SN(onX, j, k + 1); s[2] = SN(onX, j + 1, k); s[3] = SN(onX, j + 1, k + 1);
         x[0] = py; y[0] = pz; x[1] = ymin + (T)j * dy; y[1] = zmin + (T)k * dz; x[2] = ymin + (T)(j + 1) * dy; y[2] = zmin + (T)(k + 1) * dz;
         return RET(lin2(x, y, s));
     } else if (onY != -1) {
-        const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
-        const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+        const unsigned i = idx_u32(small + (double)((px - xmin) / dx));
+        const unsigned k = idx_u32(small + (double)((pz - zmin) / dz));
         s[0] = SN(i, onY, k); s[1] = SN(i, onY, k + 1); s[2] = SN(i + 1, onY, k); s[3] = SN(i + 1, onY, k + 1);
         x[0] = px; y[0] = pz; x[1] = xmin + (T)i * dx; y[1] = zmin + (T)k * dz; x[2] = xmin + (T)(i + 1) * dx; y[2] = zmin + (T)(k + 1) * dz;
         return RET(lin2(x, y, s));
     } else if (onZ != -1) {
-        const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
-        const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
+        const unsigned i = idx_u32(small + (double)((px - xmin) / dx));
+        const unsigned j = idx_u32(small + (double)((py - ymin) / dy));
         s[0] = SN(i, j, onZ); s[1] = SN(i, j + 1, onZ); s[2] = SN(i + 1, j, onZ); s[3] = SN(i + 1, j + 1, onZ);
         x[0] = px; y[0] = py; x[1] = xmin + (T)i * dx; y[1] = ymin + (T)j * dy; x[2] = xmin + (T)(i + 1) * dx; y[2] = ymin + (T)(j + 1) * dy;
         return RET(lin2(x, y, s));
     }
-    const unsigned i = (unsigned)(small + (double)((px - xmin) / dx));
-    const unsigned j = (unsigned)(small + (double)((py - ymin) / dy));
-    const unsigned k = (unsigned)(small + (double)((pz - zmin) / dz));
+    const unsigned i = idx_u32(small + (double)((px - xmin) / dx));
+    const unsigned j = idx_u32(small + (double)((py - ymin) / dy));
+    const unsigned k = idx_u32(small + (double)((pz - zmin) / dz));
     s[0] = SN(i, j, k); s[1] = SN(i, j, k + 1); s[2] = SN(i, j + 1, k); s[3] = SN(i, j + 1, k + 1);
     s[4] = SN(i + 1, j, k); s[5] = SN(i + 1, j, k + 1); s[6] = SN(i + 1, j + 1, k); s[7] = SN(i + 1, j + 1, k + 1);
     x[0] = px; y[0] = py; z[0] = pz;
@@ -2904,8 +2911,8 @@ __global__ void fsm_compact_rays(const T* __restrict__ pts, long cap, const long
 template <typename T>
 __device__ __forceinline__ T interp2d_pt(const T* __restrict__ Tn, int ts, int nnx, int nnz, T dx, T dz, T xmin, T zmin, T px, T pz) {
     const double small = 1.e-4;
-    const uint32_t i = (uint32_t)(small + (double)((px - xmin) / dx));
-    const uint32_t j = (uint32_t)(small + (double)((pz - zmin) / dz));
+    const uint32_t i = idx_u32(small + (double)((px - xmin) / dx));
+    const uint32_t j = idx_u32(small + (double)((pz - zmin) / dz));
     auto ab = [](T v) { return v < 0 ? -v : v; };
     const bool onx = (double)ab(px - (xmin + (T)i * dx)) < small;
     const bool onz = (double)ab(pz - (zmin + (T)j * dz)) < small;
@@ -2979,19 +2986,19 @@ __device__ T slowness_at2d(const RayGeom2<T>& g, const T* __restrict__ sn, T px,
     };
     if (onX != -1 && onZ != -1) return sn[(size_t)onX * g.nnz + onZ];
     if (onX != -1) {
-        const unsigned k = (unsigned)(small + (double)((pz - g.zmin) / g.dz));
+        const unsigned k = idx_u32(small + (double)((pz - g.zmin) / g.dz));
         const T s0 = S2(onX, k), s1 = S2(onX, k + 1);
         const T x0 = pz, x1 = g.zmin + (T)k * g.dz, x2 = g.zmin + (T)(k + 1) * g.dz;
         return (s0 * (x2 - x0) + s1 * (x0 - x1)) / (x2 - x1);
     }
     if (onZ != -1) {
-        const unsigned i = (unsigned)(small + (double)((px - g.xmin) / g.dx));
+        const unsigned i = idx_u32(small + (double)((px - g.xmin) / g.dx));
         const T s0 = S2(i, onZ), s1 = S2(i + 1, onZ);
         const T x0 = px, x1 = g.xmin + (T)i * g.dx, x2 = g.xmin + (T)(i + 1) * g.dx;
         return (s0 * (x2 - x0) + s1 * (x0 - x1)) / (x2 - x1);
     }
-    const unsigned i = (unsigned)(small + (double)((px - g.xmin) / g.dx));
-    const unsigned k = (unsigned)(small + (double)((pz - g.zmin) / g.dz));
+    const unsigned i = idx_u32(small + (double)((px - g.xmin) / g.dx));
+    const unsigned k = idx_u32(small + (double)((pz - g.zmin) / g.dz));
     const T s0 = S2(i, k), s1 = S2(i, k + 1), s2 = S2(i + 1, k), s3 = S2(i + 1, k + 1);
     const T x0 = px, z0 = pz, x1 = g.xmin + (T)i * g.dx, z1 = g.zmin + (T)k * g.dz;
     const T x2 = g.xmin + (T)(i + 1) * g.dx, z2 = g.zmin + (T)(k + 1) * g.dz;
@@ -3040,8 +3047,8 @@ __device__ uint32_t cellno2d(const RayGeom2<T>& g, T px, T pz) {
     const double small = 1.e-4;
     const T x = (double)(g.xmax - px) < small ? (T)((double)g.xmax - .5 * (double)g.dx) : px;
     const T z = (double)(g.zmax - pz) < small ? (T)((double)g.zmax - .5 * (double)g.dz) : pz;
-    uint32_t nx = (uint32_t)(small + (double)((x - g.xmin) / g.dx));
-    uint32_t nz = (uint32_t)(small + (double)((z - g.zmin) / g.dz));
+    uint32_t nx = idx_u32(small + (double)((x - g.xmin) / g.dx));
+    uint32_t nz = idx_u32(small + (double)((z - g.zmin) / g.dz));
     // (absolute test above, relative index here: a cell index past the last cell -- dx > 1 -- is clamped, see the oracle)
     nx = nx > (uint32_t)(g.nnx - 2) ? (uint32_t)(g.nnx - 2) : nx;
     nz = nz > (uint32_t)(g.nnz - 2) ? (uint32_t)(g.nnz - 2) : nz;
