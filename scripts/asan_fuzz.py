@@ -63,17 +63,22 @@ while time.time() < t_end:
     caxes = [0.5 * (a[1:] + a[:-1]) for a in axes]
     s = smooth(caxes if cell else axes)
     src = edge_points(axes, dt, 1) if rng.random() < 0.5 else np.array([[rng.uniform(a[0], a[-1]) for a in axes]])
+    if rng.random() < 0.4:   # one or two more points of the same source within a cell of the first: the end game runs once per point
+        more = [np.clip(src[0] + rng.uniform(-0.7, 0.7, dim) * np.array(steps), [a[0] for a in axes], [a[-1] for a in axes])
+                for _ in range(int(rng.integers(1, 3)))]
+        src = np.vstack([src] + more)
     rcv = edge_points(axes, dt, 6)
-    mode = rng.integers(0, 3)   # 0 interpolation, 1 tt_from_rp, 2 return_rays
+    mode = rng.integers(0, 5)   # 0 interpolation, 1 tt_from_rp, 2 return_rays, 3 matrix M / L, 4 the same with the rays
     iv = bool(dim == 3 and rng.random() < 0.3)
     print(f"#{n} dim={dim} {np.dtype(dt).name} nc={nc} dx={dx} dz={dz} org={org} cell={cell} weno={weno} translate={translate} mode={mode} iv={iv}", flush=True)
     try:
         if dim == 3:
             O.solve3d(dt, nc, dx, org, s.flatten('F'), src, rcv=rcv, cell_slowness=cell, translate=translate, weno=weno,
-                      tt_from_rp=mode == 1, return_rays=mode == 2, interp_vel=iv)
+                      tt_from_rp=mode == 1, return_rays=mode in (2, 4), compute_m=mode >= 3 and not cell, interp_vel=iv)
             O.compute_slowness3d(dt, nc, dx, org, s.flatten('F'), np.vstack([rcv, src]), cell, translate, iv)
         else:
-            O.solve2d(dt, nc, dx, dz, org, s.ravel(), src, rcv=rcv, cell_slowness=cell, weno=weno, tt_from_rp=mode == 1, return_rays=mode == 2)
+            O.solve2d(dt, nc, dx, dz, org, s.ravel(), src, rcv=rcv, cell_slowness=cell, weno=weno, tt_from_rp=mode == 1, return_rays=mode in (2, 4),
+                      compute_L=mode >= 3 and cell)
             O.compute_slowness2d(dt, nc, dx, dz, org, s.ravel(), np.vstack([rcv, src]), cell)
         walked += mode > 0
     except RuntimeError as e:   # a point the grid refuses, a ray that leaves the grid or does not end: the reference throws / hangs too
