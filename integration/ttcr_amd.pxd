@@ -54,4 +54,19 @@ cdef extern from "ttcr_amd.h" nogil:
     int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value)
     int ttcr_fsm_rays_size(const ttcr_fsm_grid* g, size_t* n_rays, size_t* n_points)
     int ttcr_fsm_get_rays(const ttcr_fsm_grid* g, long long* offsets, void* pts)
+    # per-slot rays and the matrices M / L (the r_data, m_data and l_data overloads of Grid3D / Grid2D::raytrace)
+    int ttcr_fsm_raytrace_rays(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                               void* tt_out)
+    int ttcr_fsm_slot_rays_size(const ttcr_fsm_grid* g, int slot, size_t* n_rays, size_t* n_points)
+    int ttcr_fsm_get_slot_rays(const ttcr_fsm_grid* g, int slot, long long* offsets, void* pts)
+    int ttcr_fsm_raytrace_m(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                            void* tt_out)
+    int ttcr_fsm_raytrace_rm(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                             void* tt_out)
+    int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz)
+    int ttcr_fsm_get_slot_m(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* j, void* v)
+    int ttcr_fsm_raytrace_l(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
+                            void* tt_out, int with_rays)
+    int ttcr_fsm_slot_l_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz)
+    int ttcr_fsm_get_slot_l(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* cell, void* v)
     int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out)
