@@ -160,3 +160,53 @@ def test_hip_m_matches_golden(mg, name, dt):
         gc.raytrace(np.repeat(src[:1], 2, axis=0), rcv[:2], compute_M=True)
     with pytest.raises(NotImplementedError):
         g.raytrace(np.repeat(src[:1], 2, axis=0), rcv[:2], compute_L=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("both", [False, True], ids=["m_data", "r_data+m_data"])
+def test_hip_m_matches_oracle_medium_grid(oracle, dt, both):
+    """Both overloads on a grid of hundreds of patches (97 x 83 x 91 nodes, rough model), a source of three points within a cell
+    of each other, 48 receivers spread over the grid: HIP (walk kernel + host assembly) against the restatement, entry for entry."""
+    import ttcr_amd
+    from ttcr_amd import _lib
+
+    rng = np.random.default_rng(9)
+    nn = (97, 83, 91)
+    nc = tuple(v - 1 for v in nn)
+    dx = 0.25
+    s = rng.uniform(0.5, 1.0, nn[0] * nn[1] * nn[2])
+    hi = np.array(nc) * dx
+    src = np.array([[11.3, 9.1, 13.2]])
+    src = np.vstack([src, src[0] + np.array([0.11, -0.07, 0.09]), src[0] + np.array([-0.13, 0.05, 0.02])])
+    t0 = np.array([0.25, 0.1, 0.3])
+    rcv = rng.uniform(0.6 * dx, hi - 0.6 * dx, (48, 3))
+    try:
+        o = oracle.solve3d(dt, nc, dx, (0.0, 0.0, 0.0), s, src, t0=t0, rcv=rcv, compute_m=True, return_rays=both)
+    except RuntimeError as e:   # (a walk that leaves the grid: choose other receivers -- none with this seed)
+        pytest.fail(str(e))
+    axes = [np.arange(n) * dx for n in nn]
+    g = ttcr_amd.Grid3d(*axes, n_threads=1, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    g.set_slowness(s.reshape(nn, order="F"))
+    L = _lib.load()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    tx = np.ascontiguousarray(src, dtype=dt); tt0 = np.ascontiguousarray(t0, dtype=dt); rx = np.ascontiguousarray(rcv, dtype=dt)
+    out = np.empty(rx.shape[0], dtype=dt)
+    _lib.check((L.ttcr_fsm_raytrace_rm if both else L.ttcr_fsm_raytrace_m)(g._h, 0, 3, p(tx), p(tt0), rx.shape[0], p(rx), p(out)))
+    np.testing.assert_array_equal(out, o["tt_rcv"])
+    nrow, nnz = C.c_size_t(0), C.c_size_t(0)
+    _lib.check(L.ttcr_fsm_slot_m_size(g._h, 0, C.byref(nrow), C.byref(nnz)))
+    off = np.zeros(nrow.value + 1, dtype=np.int64); jj = np.empty(max(nnz.value, 1), dtype=np.int64); vv = np.empty(max(nnz.value, 1), dtype=dt)
+    _lib.check(L.ttcr_fsm_get_slot_m(g._h, 0, p(off), p(jj), p(vv)))
+    assert nrow.value == rx.shape[0]
+    for n, (j, v) in enumerate(o["m"]):
+        _same_entries(jj[off[n]:off[n + 1]], vv[off[n]:off[n + 1]], j, v)
+    if both:
+        nr, npnt = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(L.ttcr_fsm_slot_rays_size(g._h, 0, C.byref(nr), C.byref(npnt)))
+        roff = np.zeros(nr.value + 1, dtype=np.int64); pts = np.empty((max(npnt.value, 1), 3), dtype=dt)
+        _lib.check(L.ttcr_fsm_get_slot_rays(g._h, 0, p(roff), p(pts)))
+        for n, ray in enumerate(o["rays"]):
+            np.testing.assert_array_equal(pts[roff[n]:roff[n + 1]], ray)
+        # more than one source point at the end of most rays (the end game served several of them)
+        assert sum(len(r) >= 3 and any(np.array_equal(r[-2], q.astype(dt)) for q in src) for r in o["rays"]) >= 1
