@@ -1510,7 +1510,7 @@ class GridT : public GridBase {
     }
 
     // getTraveltimeFromRaypath for the receivers of every source of a batch in ONE launch (one thread per receiver:
-    // a single source's few hundred receivers leave the device empty); errors as in raypath_grid_coords
+    // a single source's few hundred receivers leave the device empty); errors as in raypath_batch_rays
     void raypath_batch(const std::vector<int>& sl, const std::vector<int>& sr, const int* tx_off, const T* tx, const T* t0,
                        const int* rx_off, const T* rx, T* tt_out) {
         const int nc = ncoord();
@@ -1576,17 +1576,46 @@ class GridT : public GridBase {
         }
     }
 
-    // Grid3Drn::getTraveltimeFromRaypath for every receiver of one source (ttcr/Grid3D.h:493-496); with
-    // `record`, Grid3Drn::getRaypath(Tx,t0,Rx,r_data,tt,threadNo) instead (ttcr/Grid3D.h:546-586): the rays are
-    // appended to rays_off / rays_pts (shifted back by the origin of a translated grid, :579-584)
-    void raypath_grid_coords(int slot, int n_tx, const T* txp, const T* t0p, int n, const T* p, T* out, bool record,
-                             std::vector<long long>* ray_len = nullptr, std::vector<T>* ray_pts = nullptr) {
-        if (n <= 0) return;
-        const int nc = ncoord();   // 3-D: Grid3Drn::getRaypath family; 2-D: Grid2Drn (ttcr/Grid2Drn.h:1478-1850)
-        d_rsrc.reserve((size_t)nc * n_tx);
-        d_rt0.reserve(n_tx);
-        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txp, sizeof(T) * nc * n_tx, hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0p, sizeof(T) * n_tx, hipMemcpyHostToDevice, stream));
+    // getRaypath (the r_data overloads, ttcr/Grid3D.h:546-586 / Grid2D) for the receivers of every source of a batch in ONE launch
+    // per chunk of rows: a walk is a chain of dependent loads (≈ 10 ms for ANY number of receivers of a 256^3 source), so one
+    // launch per source made a call with return_rays cost more than its solves.  Rows in batch order; recording rows hold the
+    // length of an ordinary ray, a longer one is traced again alone; the recording buffer stays below rays_buffer_bytes.
+    size_t rays_buffer_bytes = (size_t)4 << 30;
+    void raypath_batch_rays(const std::vector<int>& sl, const std::vector<int>& sr, const int* tx_off, const T* tx, const T* t0,
+                            const int* rx_off, const T* rx, T* tt_out, std::vector<std::vector<long long>>& src_ray_len,
+                            std::vector<std::vector<T>>& src_ray_pts) {
+        const int nc = ncoord();
+        size_t n = 0;
+        for (int s2 : sr) n += (size_t)(rx_off[s2 + 1] - rx_off[s2]);
+        if (n == 0) return;
+        std::vector<T> p(nc * n), o(n), txb, t0b;
+        std::vector<int> so(n), st(n), np(n);
+        std::vector<RaySrc> desc(sl.size());
+        size_t k = 0;
+        for (size_t b = 0; b < sl.size(); ++b) {
+            const int src = sr[b], m = rx_off[src + 1] - rx_off[src];
+            desc[b].tt_off = (long long)(tt_ptr(sl[b]) - d_tt.p);
+            desc[b].tx_off = (int)t0b.size();
+            desc[b].n_tx = tx_off[src + 1] - tx_off[src];
+            txb.insert(txb.end(), tx + (size_t)nc * tx_off[src], tx + (size_t)nc * tx_off[src + 1]);
+            t0b.insert(t0b.end(), t0 + tx_off[src], t0 + tx_off[src + 1]);
+            std::memcpy(p.data() + nc * k, rx + (size_t)nc * rx_off[src], sizeof(T) * nc * m);
+            std::fill(so.begin() + k, so.begin() + k + m, (int)b);
+            k += m;
+        }
+        d_rsrc.reserve(txb.size());
+        d_rt0.reserve(t0b.size());
+        d_rx.reserve(nc * n);
+        d_out.reserve(n);
+        d_rstat.reserve(n);
+        d_rslot.reserve(n);
+        d_raynp.reserve(n);
+        d_rdesc.reserve(desc.size());
+        HIP_CHECK(hipMemcpyAsync(d_rsrc.p, txb.data(), sizeof(T) * txb.size(), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rt0.p, t0b.data(), sizeof(T) * t0b.size(), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rx.p, p.data(), sizeof(T) * nc * n, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rslot.p, so.data(), sizeof(int) * n, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rdesc.p, desc.data(), sizeof(RaySrc) * desc.size(), hipMemcpyHostToDevice, stream));
         RayGeom<T> rg;
         rg.nnx = ncx + 1; rg.nny = ncy + 1; rg.nnz = ncz + 1;
         rg.dx = dx; rg.xmin = xmin; rg.ymin = ymin; rg.zmin = zmin; rg.xmax = xmax; rg.ymax = ymax; rg.zmax = zmax;
@@ -1594,94 +1623,83 @@ class GridT : public GridBase {
         RayGeom2<T> rg2;
         rg2.nnx = ncx + 1; rg2.nnz = ncz + 1;
         rg2.dx = dx; rg2.dz = dz; rg2.xmin = xmin; rg2.zmin = zmin; rg2.xmax = xmax; rg2.zmax = zmax;
-        const T* cell_s = (dim == 2 && cell) ? d_cells.p : nullptr;   // Grid2Drcfs integrates the CELL slowness
-        // The reference's walk has no step limit: next to a corner it can go back and forth between two planes for
-        // tens of thousands of steps before it drifts away (41 512 points for a receiver 1.7e-4 inside the far corner of
-        // a 2-D cell grid, tests/test_parity_gpu.py).  The limit only turns a walk that would never end into an error.
-        // Recording rows hold the length of an ordinary ray; a longer one is traced again with the room it asked for.
+        const T* cell_s = (dim == 2 && cell) ? d_cells.p : nullptr;
+        // The reference's walk has no step limit: next to a corner it can go back and forth between two planes for tens of thousands
+        // of steps before it drifts away (41 512 points for a receiver 1.7e-4 inside the far corner of a 2-D cell grid,
+        // tests/test_parity_gpu.py).  The limit only turns a walk that would never end into an error.
         const long max_steps = walk_step_limit;
-        const long cap = std::min<long>(max_steps, 8L * ((long)ncx + ncy + ncz + 3)) + 3;   // Rx, one point per step, <= two at the source
-        // receivers in chunks: the recording buffer stays below 256 MiB
-        const int chunk = record ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (sizeof(T) * nc * cap))) : n;
-        std::vector<int> st(chunk), np(chunk);
-        std::vector<long long> off(chunk + 1);
-        for (int c0 = 0; c0 < n; c0 += chunk) {
-            const int m = std::min(chunk, n - c0);
-            const T* pc = p + (size_t)nc * c0;
-            d_rx.reserve((size_t)nc * m);
-            d_out.reserve(m);
-            d_rstat.reserve(m);
-            HIP_CHECK(hipMemcpyAsync(d_rx.p, pc, sizeof(T) * nc * m, hipMemcpyHostToDevice, stream));
-            const dim3 rgrid((m + 63) / 64), rblock(64);
-            if (record) {
-                d_raypts.reserve((size_t)m * cap * nc);
-                d_raynp.reserve(m);
-                if (dim == 3)
-                    fsm_raypath3d<T, true><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m,
-                                                                         d_out.p, d_rstat.p, max_steps, d_raypts.p, cap, d_raynp.p);
-                else
-                    fsm_raypath2d<T, true><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, cell_s, rg2, n_tx, d_rsrc.p, d_rt0.p,
-                                                                         d_rx.p, m, d_out.p, d_rstat.p, max_steps, d_raypts.p, cap,
-                                                                         d_raynp.p);
-            } else if (dim == 3) {
-                fsm_raypath3d<T, false><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p, m,
-                                                                      d_out.p, d_rstat.p, max_steps, nullptr, 0, nullptr);
-            } else {
-                fsm_raypath2d<T, false><<<rgrid, rblock, 0, stream>>>(tt_ptr(slot), NS, d_s.p, cell_s, rg2, n_tx, d_rsrc.p, d_rt0.p,
-                                                                      d_rx.p, m, d_out.p, d_rstat.p, max_steps, nullptr, 0, nullptr);
-            }
+        const long cap = std::min<long>(max_steps, 8L * ((long)ncx + ncy + ncz + 3)) + 3;   // Rx, one point per step, <= two per source point
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, rays_buffer_bytes / (sizeof(T) * nc * cap)));
+        auto launch = [&](size_t row0, int m, T* pts, long rcap) {   // rows [row0, row0 + m) of the batch
+            const dim3 rgrid((unsigned)((m + 63) / 64)), rblock(64);
+            if (dim == 3)
+                fsm_raypath3d<T, true><<<rgrid, rblock, 0, stream>>>(d_tt.p, NS, d_s.p, rg, 0, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * row0, m,
+                                                                     d_out.p + row0, d_rstat.p + row0, max_steps, pts, rcap, d_raynp.p + row0,
+                                                                     d_rdesc.p, d_rslot.p + row0);
+            else
+                fsm_raypath2d<T, true><<<rgrid, rblock, 0, stream>>>(d_tt.p, NS, d_s.p, cell_s, rg2, 0, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * row0, m,
+                                                                     d_out.p + row0, d_rstat.p + row0, max_steps, pts, rcap, d_raynp.p + row0,
+                                                                     d_rdesc.p, d_rslot.p + row0);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(out + c0, d_out.p, sizeof(T) * m, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(st.data(), d_rstat.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
-            if (record) HIP_CHECK(hipMemcpyAsync(np.data(), d_raynp.p, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+        };
+        auto compact = [&](const T* pts, long rcap, const long long* d_off, int m) {
+            if (dim == 3)
+                fsm_compact_rays<T><<<m, 128, 0, stream>>>(pts, rcap, d_off, d_raydense.p, shift_rays() ? ox : (T)0, shift_rays() ? oy : (T)0,
+                                                           shift_rays() ? oz : (T)0);
+            else
+                fsm_compact_rays2<T><<<m, 128, 0, stream>>>(pts, rcap, d_off, d_raydense.p);
+            HIP_CHECK(hipGetLastError());
+        };
+        std::vector<long long> off;
+        std::vector<T> dense;
+        for (size_t c0 = 0; c0 < n; c0 += chunk) {
+            const int m = (int)std::min(chunk, n - c0);
+            d_raypts.reserve((size_t)m * cap * nc);
+            launch(c0, m, d_raypts.p, cap);
+            HIP_CHECK(hipMemcpyAsync(o.data() + c0, d_out.p + c0, sizeof(T) * m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(st.data() + c0, d_rstat.p + c0, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(np.data() + c0, d_raynp.p + c0, sizeof(int) * m, hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             for (int q = 0; q < m; ++q)
-                if (st[q] != 0 && st[q] != 3) throw_walk_error(st[q], pc + (size_t)nc * q, txp, max_steps);
-            if (record) {
-                off[0] = 0;
-                for (int q = 0; q < m; ++q) off[q + 1] = off[q] + np[q];
-                const long long tot = off[m];
-                d_rayoff.reserve(m + 1);
-                d_raydense.reserve((size_t)std::max<long long>(tot, 1) * nc);
-                HIP_CHECK(hipMemcpyAsync(d_rayoff.p, off.data(), sizeof(long long) * (m + 1), hipMemcpyHostToDevice, stream));
-                if (dim == 3)
-                    fsm_compact_rays<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p, shift_rays() ? ox : (T)0,
-                                                               shift_rays() ? oy : (T)0, shift_rays() ? oz : (T)0);
-                else
-                    fsm_compact_rays2<T><<<m, 128, 0, stream>>>(d_raypts.p, cap, d_rayoff.p, d_raydense.p);
-                HIP_CHECK(hipGetLastError());
-                for (int q = 0; q < m; ++q) {   // rays longer than a row (status 3): once more, alone, with room
-                    if (st[q] != 3) continue;
-                    const long need = (long)np[q] + 1;
-                    d_raylong.reserve((size_t)need * nc);
-                    const long long off2[2] = {off[q], off[q + 1]};
-                    d_rayoff2.reserve(2);
-                    HIP_CHECK(hipMemcpyAsync(d_rayoff2.p, off2, sizeof(off2), hipMemcpyHostToDevice, stream));
-                    if (dim == 3) {
-                        fsm_raypath3d<T, true><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, rg, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * q, 1,
-                                                                     d_out.p + q, d_rstat.p + q, max_steps, d_raylong.p, need, d_raynp.p + q);
-                        fsm_compact_rays<T><<<1, 128, 0, stream>>>(d_raylong.p, need, d_rayoff2.p, d_raydense.p, shift_rays() ? ox : (T)0,
-                                                                   shift_rays() ? oy : (T)0, shift_rays() ? oz : (T)0);
-                    } else {
-                        fsm_raypath2d<T, true><<<1, 64, 0, stream>>>(tt_ptr(slot), NS, d_s.p, cell_s, rg2, n_tx, d_rsrc.p, d_rt0.p, d_rx.p + (size_t)nc * q,
-                                                                     1, d_out.p + q, d_rstat.p + q, max_steps, d_raylong.p, need, d_raynp.p + q);
-                        fsm_compact_rays2<T><<<1, 128, 0, stream>>>(d_raylong.p, need, d_rayoff2.p, d_raydense.p);
-                    }
-                    HIP_CHECK(hipGetLastError());
-                    int st2 = 0, np2 = 0;
-                    HIP_CHECK(hipMemcpyAsync(&st2, d_rstat.p + q, sizeof(int), hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipMemcpyAsync(&np2, d_raynp.p + q, sizeof(int), hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipStreamSynchronize(stream));   // (also: off2 goes out of scope)
-                    if (st2 != 0 || np2 != np[q]) throw DeviceError("raypath: a long ray did not retrace to the same length");
-                }
-                // the rays of this source, kept apart: raytrace_multi strings the sources together in SOURCE order
-                // once every round is done (the solve order is round-major, i.e. interleaved when n_slots < n_src)
-                const size_t base = ray_pts->size();
-                ray_pts->resize(base + (size_t)tot * nc);
-                HIP_CHECK(hipMemcpyAsync(ray_pts->data() + base, d_raydense.p, sizeof(T) * nc * tot, hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
-                for (int q = 0; q < m; ++q) ray_len->push_back((long long)np[q]);
+                if (st[c0 + q] != 0 && st[c0 + q] != 3)
+                    throw_walk_error(st[c0 + q], p.data() + (size_t)nc * (c0 + q), txb.data() + (size_t)nc * desc[so[c0 + q]].tx_off, max_steps);
+            off.assign((size_t)m + 1, 0);
+            for (int q = 0; q < m; ++q) off[q + 1] = off[q] + np[c0 + q];
+            const long long tot = off[m];
+            d_rayoff.reserve((size_t)m + 1);
+            d_raydense.reserve((size_t)std::max<long long>(tot, 1) * nc);
+            HIP_CHECK(hipMemcpyAsync(d_rayoff.p, off.data(), sizeof(long long) * ((size_t)m + 1), hipMemcpyHostToDevice, stream));
+            compact(d_raypts.p, cap, d_rayoff.p, m);
+            for (int q = 0; q < m; ++q) {   // rays longer than a row (status 3): once more, alone, with room
+                if (st[c0 + q] != 3) continue;
+                const long need = (long)np[c0 + q] + 1;
+                d_raylong.reserve((size_t)need * nc);
+                const long long off2[2] = {off[q], off[q + 1]};
+                d_rayoff2.reserve(2);
+                HIP_CHECK(hipMemcpyAsync(d_rayoff2.p, off2, sizeof(off2), hipMemcpyHostToDevice, stream));
+                launch(c0 + q, 1, d_raylong.p, need);
+                compact(d_raylong.p, need, d_rayoff2.p, 1);
+                int st2 = 0, np2 = 0;
+                HIP_CHECK(hipMemcpyAsync(&st2, d_rstat.p + c0 + q, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(&np2, d_raynp.p + c0 + q, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(o.data() + c0 + q, d_out.p + c0 + q, sizeof(T), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));   // (also: off2 goes out of scope)
+                if (st2 != 0 || np2 != np[c0 + q]) throw DeviceError("raypath: a long ray did not retrace to the same length");
             }
+            dense.resize((size_t)tot * nc);
+            if (tot > 0) HIP_CHECK(hipMemcpyAsync(dense.data(), d_raydense.p, sizeof(T) * nc * tot, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            for (int q = 0; q < m; ++q) {   // hand the rays to their sources (rows of a source are consecutive)
+                const int src = sr[so[c0 + q]];
+                src_ray_len[src].push_back((long long)np[c0 + q]);
+                src_ray_pts[src].insert(src_ray_pts[src].end(), dense.begin() + (size_t)off[q] * nc, dense.begin() + (size_t)off[q + 1] * nc);
+            }
+        }
+        k = 0;
+        for (size_t b = 0; b < sl.size(); ++b) {
+            const int m = rx_off[sr[b] + 1] - rx_off[sr[b]];
+            std::memcpy(tt_out + rx_off[sr[b]], o.data() + k, sizeof(T) * m);
+            k += m;
         }
     }
 
@@ -2138,12 +2156,7 @@ class GridT : public GridBase {
                     raypath_batch(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out);
                     continue;
                 }
-                for (size_t b = 0; b < sl.size(); ++b) {
-                    const int n = sr[b];
-                    raypath_grid_coords(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)nc * tx_off[n], t0 + tx_off[n],
-                                        rx_off[n + 1] - rx_off[n], rx.data() + (size_t)nc * rx_off[n], tt_out + rx_off[n],
-                                        return_rays, &src_ray_len[n], &src_ray_pts[n]);
-                }
+                raypath_batch_rays(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out, src_ray_len, src_ray_pts);
             }
         }
         if (return_rays) {   // one ray per receiver row, in row order (rows of source 0, then source 1, ...)
