@@ -263,6 +263,17 @@ int ttcr_fsm_raytrace_rm(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, c
                          const void* rx, void* tt_out);
 int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz);
 int ttcr_fsm_get_slot_m(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* j, void* v);
+/* Replaces: the multi-source overloads with m_data, Grid3D::raytrace(Tx[], t0[], Rx[], traveltimes[], [r_data[],] m_data[])
+ * (ttcr/Grid3D.h:896-1000), which run the single-source overload per source on host threads -- what ttcrpy reaches with
+ * compute_M and several events (src/ttcrpy/rgrid.pyx:1096-1102).  Sources and receivers laid out like ttcr_fsm_raytrace_multi;
+ * the fields are solved in batches of n_slots sources (one sweep launch per batch and sweep-iteration instead of one chain of
+ * launches per source), the walks follow each batch.  with_rays != 0: the overload with r_data and m_data for every source
+ * (rays: ttcr_fsm_rays_size / ttcr_fsm_get_rays).  Results identical to n_src calls of ttcr_fsm_raytrace_m / _rm.
+ * ttcr_fsm_multi_m_size / ttcr_fsm_get_multi_m: ONE CSR over all receiver rows of the call (row r = receiver row r). */
+int ttcr_fsm_raytrace_multi_m(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
+                              const void* rx, void* tt_out, int with_rays);
+int ttcr_fsm_multi_m_size(const ttcr_fsm_grid* g, size_t* n_rows, size_t* nnz);
+int ttcr_fsm_get_multi_m(const ttcr_fsm_grid* g, long long* row_off, long long* j, void* v);
 
 /* Replaces: Grid2D::raytrace(Tx, t0, Rx, traveltimes, l_data, threadNo) (ttcr/Grid2D.h:616-640) and the overload with r_data
  * AND l_data (:583-614) -> Grid2Drn::getRaypath(Tx, t0, Rx, [r_data,] l_data, tt, threadNo) (ttcr/Grid2Drn.h:1852-2190): what

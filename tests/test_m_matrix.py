@@ -210,3 +210,54 @@ def test_hip_m_matches_oracle_medium_grid(oracle, dt, both):
             np.testing.assert_array_equal(pts[roff[n]:roff[n + 1]], ray)
         # more than one source point at the end of most rays (the end game served several of them)
         assert sum(len(r) >= 3 and any(np.array_equal(r[-2], q.astype(dt)) for q in src) for r in o["rays"]) >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_threads", [1, 3])
+@pytest.mark.parametrize("rays", [False, True], ids=["m_data", "r_data+m_data"])
+def test_hip_m_several_events_in_one_call(oracle, n_threads, rays):
+    """compute_M with several events goes to the device as ONE call (ttcr_fsm_raytrace_multi_m: batched solves, then the walks):
+    the same traveltimes, matrices and rays as event by event -- the restatement's, per event."""
+    import ttcr_amd
+
+    rng = np.random.default_rng(21)
+    dt = np.float32
+    nn = (41, 37, 33)
+    nc = tuple(v - 1 for v in nn)
+    dx = 0.5
+    s = rng.uniform(0.5, 1.0, nn[0] * nn[1] * nn[2])
+    hi = np.array(nc) * dx
+    n_ev = 5
+    ev_src = rng.uniform(1.5 * dx, hi - 1.5 * dx, (n_ev, 3))
+    ev_t0 = rng.uniform(0, 0.5, n_ev).round(3)
+    ev_rcv = [rng.uniform(0.7 * dx, hi - 0.7 * dx, (int(k), 3)) for k in rng.integers(2, 7, n_ev)]
+    # ttcrpy-style rows: (event id, t0, x, y, z) per receiver row -- rows of the events interleaved
+    rows = [(e, k) for e in range(n_ev) for k in range(len(ev_rcv[e]))]
+    order = rng.permutation(len(rows))
+    src = np.array([[ev_t0[rows[i][0]], *ev_src[rows[i][0]]] for i in order])
+    rcv = np.array([ev_rcv[rows[i][0]][rows[i][1]] for i in order])
+    axes = [np.arange(n) * dx for n in nn]
+    g = ttcr_amd.Grid3d(*axes, n_threads=n_threads, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    g.set_slowness(s.reshape(nn, order="F"))
+    out = g.raytrace(src, rcv, compute_M=True, return_rays=rays)
+    tt, M = out[0], out[-1]
+    assert len(M) == n_ev
+    # the events in the order the Python layer finds them (first appearance), each against the restatement
+    seen = []
+    for i in order:
+        if rows[i][0] not in seen:
+            seen.append(rows[i][0])
+    for m_idx, e in enumerate(seen):
+        sel = [q for q, i in enumerate(order) if rows[i][0] == e]
+        o = oracle.solve3d(dt, nc, dx, (0.0, 0.0, 0.0), s, ev_src[e:e + 1], t0=ev_t0[e:e + 1], rcv=rcv[sel], compute_m=True, return_rays=rays)
+        np.testing.assert_array_equal(tt[sel], o["tt_rcv"])
+        assert M[m_idx].shape == (len(sel), nn[0] * nn[1] * nn[2])
+        for r, (j, v) in enumerate(o["m"]):
+            row = M[m_idx].getrow(r)
+            keep = j < nn[0] * nn[1] * nn[2]
+            oo = np.argsort(j[keep], kind="stable")
+            np.testing.assert_array_equal(row.indices, j[keep][oo])
+            np.testing.assert_array_equal(row.data, v[keep][oo].astype(np.float64))
+        if rays:
+            for r, q in enumerate(sel):
+                np.testing.assert_array_equal(out[1][q], o["rays"][r].astype(np.float64))

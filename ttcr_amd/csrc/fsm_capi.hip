@@ -105,6 +105,11 @@ class GridBase {
     virtual void raytrace_m(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool both) = 0;
     virtual void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const = 0;
     virtual void get_slot_m(int slot, long long* row_off, long long* j, void* v) const = 0;
+    // every source of a call at once (batched solves, then the walks); one CSR over all receiver rows of the call
+    virtual void raytrace_multi_m(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off, const void* rx,
+                                  void* tt_out, bool both) = 0;
+    virtual void multi_m_size(size_t* n_rows, size_t* nnz) const = 0;
+    virtual void get_multi_m(long long* row_off, long long* j, void* v) const = 0;
     // the raytrace overloads with l_data (2-D cell grids): ray-projection matrix L, one CSR row per receiver
     virtual void raytrace_l(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool with_rays) = 0;
     virtual void slot_l_size(int slot, size_t* n_rows, size_t* nnz) const = 0;
@@ -1799,27 +1804,9 @@ class GridT : public GridBase {
             HIP_CHECK(hipStreamSynchronize(stream));
         }
     }
-    void raytrace_m(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool both) override {
-        check_slot(slot);
-        if (dim != 3) throw Unsupported("compute_M is implemented for 3-D grids only");
-        if (cell) throw Unsupported("compute_M not defined for grids with slowness defined for cells");
-        if (n_tx < 1) throw ValueError("every source needs at least one point");
-        const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
-        // the field of the source (and, for the overload that keeps them, the rays: the points of that overload are those of
-        // the r_data overload); the receivers' traveltimes are then replaced by those of the m_data walk
-        raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot, nullptr, both);
-        T* tt_out = (T*)tt_out_v;
-        std::vector<T> txs((const T*)tx_v, (const T*)tx_v + 3 * (size_t)n_tx), rxs((const T*)rx_v, (const T*)rx_v + 3 * (size_t)n_rx);
-        if (translate) {
-            for (int q = 0; q < n_tx; ++q) { txs[3 * q] -= ox; txs[3 * q + 1] -= oy; txs[3 * q + 2] -= oz; }
-            for (int q = 0; q < n_rx; ++q) { rxs[3 * q] -= ox; rxs[3 * q + 1] -= oy; rxs[3 * q + 2] -= oz; }
-        }
-        std::vector<long long> seg_off;
-        std::vector<T> segs;
-        walk_m(slot, n_tx, txs.data(), (const T*)t0_v, n_rx, rxs.data(), tt_out, both, seg_off, segs);
-        if (slot_m_off.empty()) { slot_m_off.resize(n_slots); slot_m_j.resize(n_slots); slot_m_v.resize(n_slots); }
-        std::vector<long long>& mo = slot_m_off[slot]; std::vector<long long>& mj = slot_m_j[slot]; std::vector<T>& mv = slot_m_v[slot];
-        mo.assign((size_t)n_rx + 1, 0); mj.clear(); mv.clear();
+    // rows of M from the records of walk_m: appended to (mo, mj, mv); mo ends with the running entry count
+    void assemble_m(int n_rx, const std::vector<long long>& seg_off, const std::vector<T>& segs, std::vector<long long>& mo,
+                    std::vector<long long>& mj, std::vector<T>& mv) const {
         const size_t nnx = ncx + 1, nny = ncy + 1;
         for (int r = 0; r < n_rx; ++r) {
             const size_t row0 = mj.size();
@@ -1843,8 +1830,64 @@ class GridT : public GridBase {
                             if (e == mj.size()) { mj.push_back(j); mv.push_back(v); }
                         }
             }
-            mo[r + 1] = (long long)mj.size();
+            mo.push_back((long long)mj.size());
         }
+    }
+    // the m_data overloads for every source of a call: the fields are solved in batches like raytrace_multi solves them, the walks
+    // follow each batch (Grid3D's multi-source overloads with m_data, ttcr/Grid3D.h:896-1000, which run the single-source overload
+    // per source on host threads).  One CSR over all receiver rows of the call, in row order.
+    bool m_walk_mode = false, m_walk_both = false;
+    std::vector<std::vector<long long>> m_seg_off;
+    std::vector<std::vector<T>> m_segs;
+    std::vector<long long> multi_m_off{0}, multi_m_j;
+    std::vector<T> multi_m_v;
+    void raytrace_multi_m(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off, const void* rx_v,
+                          void* tt_out_v, bool both) override {
+        if (dim != 3) throw Unsupported("compute_M is implemented for 3-D grids only");
+        if (cell) throw Unsupported("compute_M not defined for grids with slowness defined for cells");
+        multi_m_off.assign(1, 0); multi_m_j.clear(); multi_m_v.clear();
+        if (n_src <= 0) return;
+        m_seg_off.assign(n_src, std::vector<long long>{0});
+        m_segs.assign(n_src, std::vector<T>());
+        m_walk_mode = true; m_walk_both = both;
+        try {
+            raytrace_multi(n_src, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, -1, nullptr, both);
+        } catch (...) { m_walk_mode = false; throw; }
+        m_walk_mode = false;
+        for (int n = 0; n < n_src; ++n) {
+            assemble_m(rx_off[n + 1] - rx_off[n], m_seg_off[n], m_segs[n], multi_m_off, multi_m_j, multi_m_v);
+            std::vector<T>().swap(m_segs[n]);
+        }
+    }
+    void multi_m_size(size_t* n_rows, size_t* nnz) const override { *n_rows = multi_m_off.size() - 1; *nnz = multi_m_j.size(); }
+    void get_multi_m(long long* row_off, long long* j, void* v) const override {
+        std::memcpy(row_off, multi_m_off.data(), multi_m_off.size() * sizeof(long long));
+        if (!multi_m_j.empty()) {
+            std::memcpy(j, multi_m_j.data(), multi_m_j.size() * sizeof(long long));
+            std::memcpy(v, multi_m_v.data(), multi_m_v.size() * sizeof(T));
+        }
+    }
+    void raytrace_m(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool both) override {
+        check_slot(slot);
+        if (dim != 3) throw Unsupported("compute_M is implemented for 3-D grids only");
+        if (cell) throw Unsupported("compute_M not defined for grids with slowness defined for cells");
+        if (n_tx < 1) throw ValueError("every source needs at least one point");
+        const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, n_rx};
+        // the field of the source (and, for the overload that keeps them, the rays: the points of that overload are those of
+        // the r_data overload); the receivers' traveltimes are then replaced by those of the m_data walk
+        raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot, nullptr, both);
+        T* tt_out = (T*)tt_out_v;
+        std::vector<T> txs((const T*)tx_v, (const T*)tx_v + 3 * (size_t)n_tx), rxs((const T*)rx_v, (const T*)rx_v + 3 * (size_t)n_rx);
+        if (translate) {
+            for (int q = 0; q < n_tx; ++q) { txs[3 * q] -= ox; txs[3 * q + 1] -= oy; txs[3 * q + 2] -= oz; }
+            for (int q = 0; q < n_rx; ++q) { rxs[3 * q] -= ox; rxs[3 * q + 1] -= oy; rxs[3 * q + 2] -= oz; }
+        }
+        std::vector<long long> seg_off;
+        std::vector<T> segs;
+        walk_m(slot, n_tx, txs.data(), (const T*)t0_v, n_rx, rxs.data(), tt_out, both, seg_off, segs);
+        if (slot_m_off.empty()) { slot_m_off.resize(n_slots); slot_m_j.resize(n_slots); slot_m_v.resize(n_slots); }
+        slot_m_off[slot].assign(1, 0); slot_m_j[slot].clear(); slot_m_v[slot].clear();
+        assemble_m(n_rx, seg_off, segs, slot_m_off[slot], slot_m_j[slot], slot_m_v[slot]);
         // the rays of the overload that keeps them (already shifted back by the origin of a translated grid)
         if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
         if (both) {
@@ -2147,16 +2190,23 @@ class GridT : public GridBase {
                 }
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
                 hp_mark("solve_batch tail");
-                if (!(ttrp || return_rays)) {
+                if (m_walk_mode) {
+                    // the m_data overloads for every source of the call (raytrace_multi_m): the rays of the overload that keeps them,
+                    // then the walk that leaves the terms of M -- its traveltimes are the call's
+                    if (return_rays) raypath_batch_rays(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out, src_ray_len, src_ray_pts);
+                    for (size_t b = 0; b < sl.size(); ++b) {
+                        const int n = sr[b];
+                        walk_m(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)3 * tx_off[n], t0 + tx_off[n], rx_off[n + 1] - rx_off[n],
+                               rx.data() + (size_t)3 * rx_off[n], tt_out + rx_off[n], m_walk_both, m_seg_off[n], m_segs[n]);
+                    }
+                } else if (!(ttrp || return_rays)) {
                     interp_batch(sl, sr, rx_off, rx.data(), tt_out);
                     hp_mark("receivers");
-                    continue;
-                }
-                if (!return_rays) {
+                } else if (!return_rays) {
                     raypath_batch(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out);
-                    continue;
+                } else {
+                    raypath_batch_rays(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out, src_ray_len, src_ray_pts);
                 }
-                raypath_batch_rays(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out, src_ray_len, src_ray_pts);
             }
         }
         if (return_rays) {   // one ray per receiver row, in row order (rows of source 0, then source 1, ...)
@@ -2249,6 +2299,21 @@ class MultiGrid : public GridBase {
         timing = g.timing;
     }
     void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const override { int l; GridBase& g = of(slot, l); g.slot_m_size(l, n_rows, nnz); }
+    // (the batched m_data call runs on the first replica: its walks are a small part of a call, the solves of one device suffice)
+    void raytrace_multi_m(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off, const void* rx, void* tt_out,
+                          bool both) override {
+        GridBase& g = *rep[0];
+        g.raytrace_multi_m(n_src, tx_off, tx, t0, rx_off, rx, tt_out, both);
+        timing = g.timing;
+        size_t nr = 0, np = 0;
+        g.rays_size(&nr, &np);
+        rays_off.assign(nr + 1, 0);
+        rays_pts.resize(np * pt_bytes);
+        if (nr > 0) g.get_rays(rays_off.data(), rays_pts.data());
+        for (int n = 0; n < std::min(n_src, g.n_slots); ++n) { niter[n] = g.niter[n]; niterw[n] = g.niterw[n]; }
+    }
+    void multi_m_size(size_t* n_rows, size_t* nnz) const override { rep[0]->multi_m_size(n_rows, nnz); }
+    void get_multi_m(long long* row_off, long long* j, void* v) const override { rep[0]->get_multi_m(row_off, j, v); }
     void raytrace_l(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool with_rays) override {
         int l; GridBase& g = of(slot, l);
         g.raytrace_l(l, n_tx, tx, t0, n_rx, rx, tt_out, with_rays);
@@ -2723,6 +2788,19 @@ int ttcr_fsm_raytrace_m(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, co
 int ttcr_fsm_raytrace_rm(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx,
                         void* tt_out) {
     return guarded_on(g, [&] { g->impl->raytrace_m(slot, n_tx, tx, t0, n_rx, rx, tt_out, true); });
+}
+int ttcr_fsm_raytrace_multi_m(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
+                              const void* rx, void* tt_out, int with_rays) {
+    return guarded_on(g, [&] { g->impl->raytrace_multi_m(n_src, tx_off, tx, t0, rx_off, rx, tt_out, with_rays != 0); });
+}
+int ttcr_fsm_multi_m_size(const ttcr_fsm_grid* g, size_t* n_rows, size_t* nnz) {
+    return guarded_on(g, [&] {
+        if (!n_rows || !nnz) throw ValueError("null output pointer");
+        g->impl->multi_m_size(n_rows, nnz);
+    });
+}
+int ttcr_fsm_get_multi_m(const ttcr_fsm_grid* g, long long* row_off, long long* j, void* v) {
+    return guarded_on(g, [&] { g->impl->get_multi_m(row_off, j, v); });
 }
 int ttcr_fsm_slot_m_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz) {
     return guarded_on(g, [&] {

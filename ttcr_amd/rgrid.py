@@ -572,6 +572,50 @@ class _Grid3d(_GridBase):
         rays = [[0.0] for _ in range(n_rcv)]
         M = []
         NN = self.get_number_of_nodes()
+
+        def csr(off, jj, vv, r0, nrows):
+            indptr = np.zeros(nrows + 1, dtype=np.int64)
+            ind, val = [], []
+            for i in range(nrows):
+                j, v = jj[off[r0 + i]:off[r0 + i + 1]], vv[off[r0 + i]:off[r0 + i + 1]]
+                keep = j < NN
+                j, v = j[keep], v[keep]
+                o = np.argsort(j, kind='stable')
+                ind.append(j[o]); val.append(v[o].astype(np.float64))
+                indptr[i + 1] = indptr[i] + j.size
+            return sp.csr_matrix((np.concatenate(val) if val else np.zeros(0), np.concatenate(ind) if ind else np.zeros(0, dtype=np.int64),
+                                  indptr), shape=(nrows, NN))
+
+        if len(vTx) > 1:
+            # several events: ONE call -- the fields are solved in batches of n_threads sources, the walks follow each batch
+            # (what Grid3D's multi-source overloads with m_data do with host threads, rgrid.pyx:1096-1102)
+            tx = np.ascontiguousarray(np.vstack(vTx), dtype=dt).reshape(-1, 3)
+            t0 = np.ascontiguousarray(np.concatenate(vt0), dtype=dt)
+            rx = np.ascontiguousarray(np.vstack(vRx), dtype=dt).reshape(-1, 3)
+            tx_off = np.zeros(len(vTx) + 1, dtype=np.int32); rx_off = np.zeros(len(vTx) + 1, dtype=np.int32)
+            tx_off[1:] = np.cumsum([len(t) for t in vTx]); rx_off[1:] = np.cumsum([len(r) for r in vRx])
+            out = np.empty(max(rx.shape[0], 1), dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_raytrace_multi_m(self._h, len(vTx), _ptr(tx_off), _ptr(tx), _ptr(t0), _ptr(rx_off), _ptr(rx),
+                                                           _ptr(out), int(bool(return_rays))))
+            nrow, nnz = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(self._lib.ttcr_fsm_multi_m_size(self._h, C.byref(nrow), C.byref(nnz)))
+            off = np.zeros(nrow.value + 1, dtype=np.int64)
+            jj = np.empty(max(nnz.value, 1), dtype=np.int64)
+            vv = np.empty(max(nnz.value, 1), dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_get_multi_m(self._h, _ptr(off), _ptr(jj), _ptr(vv)))
+            if return_rays:
+                nr, npnt = C.c_size_t(0), C.c_size_t(0)
+                _lib.check(self._lib.ttcr_fsm_rays_size(self._h, C.byref(nr), C.byref(npnt)))
+                roff = np.zeros(nr.value + 1, dtype=np.int64)
+                pts = np.empty((max(npnt.value, 1), 3), dtype=dt)
+                _lib.check(self._lib.ttcr_fsm_get_rays(self._h, _ptr(roff), _ptr(pts)))
+            for n in range(len(vTx)):
+                tt[iRx[n]] = out[rx_off[n]:rx_off[n + 1]]
+                M.append(csr(off, jj, vv, int(rx_off[n]), int(rx_off[n + 1] - rx_off[n])))
+                if return_rays:
+                    for k, row in enumerate(iRx[n]):
+                        rays[row] = np.array(pts[roff[rx_off[n] + k]:roff[rx_off[n] + k + 1]], dtype=np.float64)
+            return (tt, rays, M) if return_rays else (tt, M)
         for n in range(len(vTx)):
             slot = n % self._n_threads
             tx = np.ascontiguousarray(vTx[n], dtype=dt)
@@ -588,17 +632,7 @@ class _Grid3d(_GridBase):
             jj = np.empty(max(nnz.value, 1), dtype=np.int64)
             vv = np.empty(max(nnz.value, 1), dtype=dt)
             _lib.check(self._lib.ttcr_fsm_get_slot_m(self._h, slot, _ptr(off), _ptr(jj), _ptr(vv)))
-            indptr = np.zeros(rx.shape[0] + 1, dtype=np.int64)
-            ind, val = [], []
-            for i in range(rx.shape[0]):
-                j, v = jj[off[i]:off[i + 1]], vv[off[i]:off[i + 1]]
-                keep = j < NN
-                j, v = j[keep], v[keep]
-                o = np.argsort(j, kind='stable')
-                ind.append(j[o]); val.append(v[o].astype(np.float64))
-                indptr[i + 1] = indptr[i] + j.size
-            M.append(sp.csr_matrix((np.concatenate(val) if val else np.zeros(0), np.concatenate(ind) if ind else np.zeros(0, dtype=np.int64),
-                                    indptr), shape=(rx.shape[0], NN)))
+            M.append(csr(off, jj, vv, 0, rx.shape[0]))
             if return_rays:
                 nr, npnt = C.c_size_t(0), C.c_size_t(0)
                 _lib.check(self._lib.ttcr_fsm_slot_rays_size(self._h, slot, C.byref(nr), C.byref(npnt)))
