@@ -293,6 +293,15 @@ int ttcr_fsm_raytrace_l(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, co
                         const void* rx, void* tt_out, int with_rays);
 int ttcr_fsm_slot_l_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz);
 int ttcr_fsm_get_slot_l(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* cell, void* v);
+/* The same for every source of a call -- Grid2D's multi-source overloads with l_data (they run the single-source overload per source
+ * on host threads), what ttcrpy reaches with compute_L and several events.  Sources and receivers laid out like
+ * ttcr_fsm_raytrace_multi; batched solves, the walks follow each batch; results identical to n_src calls of ttcr_fsm_raytrace_l.
+ * ONE CSR over all receiver rows of the call (ttcr_fsm_multi_l_size / ttcr_fsm_get_multi_l); with_rays != 0: the rays of the call
+ * through ttcr_fsm_rays_size / ttcr_fsm_get_rays. */
+int ttcr_fsm_raytrace_multi_l(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
+                              const void* rx, void* tt_out, int with_rays);
+int ttcr_fsm_multi_l_size(const ttcr_fsm_grid* g, size_t* n_rows, size_t* nnz);
+int ttcr_fsm_get_multi_l(const ttcr_fsm_grid* g, long long* row_off, long long* cell, void* v);
 
 typedef struct {
     double sweep_ms;        /* HIP-event time of all sweep launches of the last raytrace call   */

@@ -173,3 +173,56 @@ def test_hip_l_walk_that_leaves_the_grid_raises_like_the_reference():
         g.raytrace(np.repeat(src, 2, axis=0), rcv, compute_L=True)
     except RuntimeError as e:
         assert "going outside grid" in str(e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_threads", [1, 3])
+@pytest.mark.parametrize("rays", [False, True], ids=["l_data", "r_data+l_data"])
+def test_hip_l_several_events_in_one_call(oracle, n_threads, rays):
+    """compute_L with several events goes to the device as ONE call (ttcr_fsm_raytrace_multi_l: batched solves, then the walks):
+    the same traveltimes, rays and matrix rows as the restatement gives event by event."""
+    import ttcr_amd
+
+    rng = np.random.default_rng(31)
+    dt = np.float64
+    nc = (60, 44)
+    dx, dz = 0.5, 0.25
+    nn = (nc[0] + 1, nc[1] + 1)
+    X, Z = np.meshgrid((np.arange(nc[0]) + 0.5) * dx, (np.arange(nc[1]) + 0.5) * dz, indexing="ij")
+    s = 1.0 / (1.0 + 0.05 * Z) * (1.0 + 0.2 * np.exp(-((X - 12) ** 2 + (Z - 5) ** 2) / 10.0))
+    hi = np.array(nc) * np.array([dx, dz])
+    n_ev = 4
+    ev_src = rng.uniform(1.5, hi - 1.5, (n_ev, 2))
+    ev_t0 = rng.uniform(0, 0.5, n_ev).round(3)
+    ev_rcv = [rng.uniform(0.6, hi - 0.6, (int(k), 2)) for k in rng.integers(2, 6, n_ev)]
+    rows = [(e, k) for e in range(n_ev) for k in range(len(ev_rcv[e]))]
+    order = rng.permutation(len(rows))
+    src = np.array([[ev_t0[rows[i][0]], *ev_src[rows[i][0]]] for i in order])
+    rcv = np.array([ev_rcv[rows[i][0]][rows[i][1]] for i in order])
+    axes = [np.arange(nn[0]) * dx, np.arange(nn[1]) * dz]
+    g = ttcr_amd.Grid2d(*axes, n_threads=n_threads, cell_slowness=1, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    g.set_slowness(s)
+    out = g.raytrace(src, rcv, compute_L=True, return_rays=rays)
+    tt, Lm = out[0], out[-1]
+    assert Lm.shape == (len(rows), nc[0] * nc[1])
+    # events in order of first appearance; the reference's Python layer stacks the per-event matrices and takes `tmp[itmp, :]` with
+    # itmp = the receiver rows of the events one after the other (rgrid.pyx:4139-4143) -- row q of L is stacked row itmp[q]
+    seen = []
+    for i in order:
+        if rows[i][0] not in seen:
+            seen.append(rows[i][0])
+    stack, itmp = [], []
+    for e in seen:
+        sel = [q for q, i in enumerate(order) if rows[i][0] == e]
+        o = oracle.solve2d(dt, nc, dx, dz, (0.0, 0.0), s.ravel(), ev_src[e:e + 1], ev_t0[e:e + 1], cell_slowness=True, rcv=rcv[sel],
+                           compute_L=True, return_rays=rays)
+        np.testing.assert_array_equal(tt[sel], o["tt_rcv"])
+        stack += list(o["l"])
+        itmp += sel
+        if rays:
+            for r, q in enumerate(sel):
+                np.testing.assert_array_equal(out[1][q], o["rays"][r].astype(np.float64))
+    for q in range(len(rows)):
+        cells, lens = stack[itmp[q]]
+        row = Lm.getrow(q)
+        _same_up_to_ties(row.indices.astype(np.int64), row.data.astype(dt), cells.astype(np.int64), lens)

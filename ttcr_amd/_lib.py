@@ -64,6 +64,9 @@ SYMBOLS = {
     "ttcr_fsm_raytrace_multi_m": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I]),
     "ttcr_fsm_multi_m_size": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ttcr_fsm_get_multi_m": (_I, [_P, _P, _P, _P]),
+    "ttcr_fsm_raytrace_multi_l": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I]),
+    "ttcr_fsm_multi_l_size": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ttcr_fsm_get_multi_l": (_I, [_P, _P, _P, _P]),
     "ttcr_fsm_slot_m_size": (_I, [_P, _I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ttcr_fsm_get_slot_m": (_I, [_P, _I, _P, _P, _P]),
     "ttcr_fsm_raytrace_l": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I]),

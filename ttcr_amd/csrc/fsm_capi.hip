@@ -114,6 +114,10 @@ class GridBase {
     virtual void raytrace_l(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool with_rays) = 0;
     virtual void slot_l_size(int slot, size_t* n_rows, size_t* nnz) const = 0;
     virtual void get_slot_l(int slot, long long* row_off, long long* cell, void* v) const = 0;
+    virtual void raytrace_multi_l(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off, const void* rx,
+                                  void* tt_out, bool with_rays) = 0;
+    virtual void multi_l_size(size_t* n_rows, size_t* nnz) const = 0;
+    virtual void get_multi_l(long long* row_off, long long* cell, void* v) const = 0;
     virtual void validate_points(int n_tx, const void* tx, int n_rx, const void* rx) = 0;   // throws like raytrace would
     // single-source calls that arrive together (ttcrpy's thread pool: nt host threads, one slot each) are solved together
     struct Request {
@@ -1925,28 +1929,14 @@ class GridT : public GridBase {
     DevBuf<uint32_t> d_lcell;
     DevBuf<T> d_lval;
     DevBuf<int> d_lnum;
-    void raytrace_l(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool with_rays) override {
-        HIP_CHECK(hipSetDevice(device));
-        check_slot(slot);
-        if (dim != 2) throw Unsupported("compute_L defined for the FSM");   // (3-D: ttcrpy itself raises, rgrid.pyx:916-917)
-        if (!cell) throw Unsupported("compute_L defined only for grids with slowness defined for cells");
-        if (n_tx < 1) throw ValueError("every source needs at least one point");
-        // the solve (Grid2D::raytrace(Tx, t0, Rx, threadNo)), without receivers: the walk below gives the traveltimes
-        {
-            const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, 0};
-            const int keep_ttrp = ttrp;
-            ttrp = 0;
-            try { raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot); } catch (...) { ttrp = keep_ttrp; throw; }
-            ttrp = keep_ttrp;
-        }
-        if (slot_l_off.empty()) { slot_l_off.assign(n_slots, std::vector<long long>{0}); slot_l_cell.resize(n_slots); slot_l_val.resize(n_slots); }
-        if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
+    // the walk of the l_data overloads for the receivers of the source whose field lies in `slot`: (cell, length) entries per receiver,
+    // sorted like the reference sorts them; the rays of the overload that keeps them
+    void walk_l(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool with_rays,
+                std::vector<long long>& loff, std::vector<long long>& lcell, std::vector<T>& lval, std::vector<long long>& roff,
+                std::vector<T>& rpts) {
         const int ps = P(slot);
-        std::vector<long long>& loff = slot_l_off[slot];
-        std::vector<long long>& lcell = slot_l_cell[slot];
-        std::vector<T>& lval = slot_l_val[slot];
         loff.assign(1, 0); lcell.clear(); lval.clear();
-        slot_rays_off[slot].assign(1, 0); slot_rays_pts[slot].clear();
+        roff.assign(1, 0); rpts.clear();
         if (n_rx <= 0) return;
         check_pts((const T*)rx_v, n_rx);
         T* tt_out = (T*)tt_out_v;
@@ -2007,10 +1997,73 @@ class GridT : public GridBase {
                 for (const Siv& e : row) { lcell.push_back((long long)e.i); lval.push_back(e.v); }
                 loff.push_back((long long)lcell.size());
                 if (with_rays) {
-                    slot_rays_pts[slot].insert(slot_rays_pts[slot].end(), hp.begin() + (size_t)q * cap * 2, hp.begin() + ((size_t)q * cap + np[q]) * 2);
-                    slot_rays_off[slot].push_back(slot_rays_off[slot].back() + np[q]);
+                    rpts.insert(rpts.end(), hp.begin() + (size_t)q * cap * 2, hp.begin() + ((size_t)q * cap + np[q]) * 2);
+                    roff.push_back(roff.back() + np[q]);
                 }
             }
+        }
+    }
+    void raytrace_l(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool with_rays) override {
+        HIP_CHECK(hipSetDevice(device));
+        check_slot(slot);
+        if (dim != 2) throw Unsupported("compute_L defined for the FSM");   // (3-D: ttcrpy itself raises, rgrid.pyx:916-917)
+        if (!cell) throw Unsupported("compute_L defined only for grids with slowness defined for cells");
+        if (n_tx < 1) throw ValueError("every source needs at least one point");
+        // the solve (Grid2D::raytrace(Tx, t0, Rx, threadNo)), without receivers: the walk below gives the traveltimes
+        {
+            const int tx_off[2] = {0, n_tx}, rx_off[2] = {0, 0};
+            const int keep_ttrp = ttrp;
+            ttrp = 0;
+            try { raytrace_multi(1, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, slot); } catch (...) { ttrp = keep_ttrp; throw; }
+            ttrp = keep_ttrp;
+        }
+        if (slot_l_off.empty()) { slot_l_off.assign(n_slots, std::vector<long long>{0}); slot_l_cell.resize(n_slots); slot_l_val.resize(n_slots); }
+        if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
+        walk_l(slot, n_tx, tx_v, t0_v, n_rx, rx_v, tt_out_v, with_rays, slot_l_off[slot], slot_l_cell[slot], slot_l_val[slot], slot_rays_off[slot],
+               slot_rays_pts[slot]);
+    }
+    // the l_data overloads for every source of a call (Grid2D's multi-source overloads with l_data run the single-source overload per
+    // source on host threads, ttcr/Grid2D.h; ttcrpy: compute_L with several events): batched solves, the walks follow each batch.
+    // One CSR over all receiver rows of the call, in row order; the rays (with_rays) as the rays of the call.
+    bool l_walk_mode = false, l_walk_rays = false;
+    std::vector<std::vector<long long>> l_src_off, l_src_cell, l_src_roff;
+    std::vector<std::vector<T>> l_src_val, l_src_rpts;
+    std::vector<long long> multi_l_off{0}, multi_l_cell;
+    std::vector<T> multi_l_val;
+    void raytrace_multi_l(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off, const void* rx_v,
+                          void* tt_out_v, bool with_rays) override {
+        if (dim != 2) throw Unsupported("compute_L defined for the FSM");
+        if (!cell) throw Unsupported("compute_L defined only for grids with slowness defined for cells");
+        multi_l_off.assign(1, 0); multi_l_cell.clear(); multi_l_val.clear();
+        rays_off.assign(1, 0); rays_pts.clear();
+        if (n_src <= 0) return;
+        l_src_off.assign(n_src, {}); l_src_cell.assign(n_src, {}); l_src_roff.assign(n_src, {}); l_src_val.assign(n_src, {}); l_src_rpts.assign(n_src, {});
+        const int keep_ttrp = ttrp;
+        ttrp = 0;
+        l_walk_mode = true; l_walk_rays = with_rays;
+        try {
+            raytrace_multi(n_src, tx_off, tx_v, t0_v, rx_off, rx_v, tt_out_v, -1);
+        } catch (...) { l_walk_mode = false; ttrp = keep_ttrp; throw; }
+        l_walk_mode = false; ttrp = keep_ttrp;
+        rays_off.assign(1, 0); rays_pts.clear();
+        for (int n = 0; n < n_src; ++n) {
+            const long long lbase = (long long)multi_l_cell.size();
+            for (size_t r = 1; r < l_src_off[n].size(); ++r) multi_l_off.push_back(lbase + l_src_off[n][r]);
+            multi_l_cell.insert(multi_l_cell.end(), l_src_cell[n].begin(), l_src_cell[n].end());
+            multi_l_val.insert(multi_l_val.end(), l_src_val[n].begin(), l_src_val[n].end());
+            if (with_rays) {
+                const long long base = rays_off.back();
+                for (size_t r = 1; r < l_src_roff[n].size(); ++r) rays_off.push_back(base + l_src_roff[n][r]);
+                rays_pts.insert(rays_pts.end(), l_src_rpts[n].begin(), l_src_rpts[n].end());
+            }
+        }
+    }
+    void multi_l_size(size_t* n_rows, size_t* nnz) const override { *n_rows = multi_l_off.size() - 1; *nnz = multi_l_cell.size(); }
+    void get_multi_l(long long* row_off, long long* cellv, void* v) const override {
+        std::memcpy(row_off, multi_l_off.data(), multi_l_off.size() * sizeof(long long));
+        if (!multi_l_cell.empty()) {
+            std::memcpy(cellv, multi_l_cell.data(), multi_l_cell.size() * sizeof(long long));
+            std::memcpy(v, multi_l_val.data(), multi_l_val.size() * sizeof(T));
         }
     }
     void slot_l_size(int slot, size_t* n_rows, size_t* nnz) const override {
@@ -2190,7 +2243,15 @@ class GridT : public GridBase {
                 }
                 solve_batch(sl, sr, tx_off, tx.data(), t0);
                 hp_mark("solve_batch tail");
-                if (m_walk_mode) {
+                if (l_walk_mode) {
+                    // the l_data overloads for every source of the call (raytrace_multi_l): the walk gives traveltimes, entries and rays
+                    for (size_t b = 0; b < sl.size(); ++b) {
+                        const int n = sr[b];
+                        walk_l(sl[b], tx_off[n + 1] - tx_off[n], tx.data() + (size_t)2 * tx_off[n], t0 + tx_off[n], rx_off[n + 1] - rx_off[n],
+                               rx.data() + (size_t)2 * rx_off[n], tt_out + rx_off[n], l_walk_rays, l_src_off[n], l_src_cell[n], l_src_val[n],
+                               l_src_roff[n], l_src_rpts[n]);
+                    }
+                } else if (m_walk_mode) {
                     // the m_data overloads for every source of the call (raytrace_multi_m): the rays of the overload that keeps them,
                     // then the walk that leaves the terms of M -- its traveltimes are the call's
                     if (return_rays) raypath_batch_rays(sl, sr, tx_off, tx.data(), t0, rx_off, rx.data(), tt_out, src_ray_len, src_ray_pts);
@@ -2312,6 +2373,20 @@ class MultiGrid : public GridBase {
         if (nr > 0) g.get_rays(rays_off.data(), rays_pts.data());
         for (int n = 0; n < std::min(n_src, g.n_slots); ++n) { niter[n] = g.niter[n]; niterw[n] = g.niterw[n]; }
     }
+    void raytrace_multi_l(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off, const void* rx, void* tt_out,
+                          bool with_rays) override {
+        GridBase& g = *rep[0];
+        g.raytrace_multi_l(n_src, tx_off, tx, t0, rx_off, rx, tt_out, with_rays);
+        timing = g.timing;
+        size_t nr = 0, np = 0;
+        g.rays_size(&nr, &np);
+        rays_off.assign(nr + 1, 0);
+        rays_pts.resize(np * pt_bytes);
+        if (nr > 0) g.get_rays(rays_off.data(), rays_pts.data());
+        for (int n = 0; n < std::min(n_src, g.n_slots); ++n) { niter[n] = g.niter[n]; niterw[n] = g.niterw[n]; }
+    }
+    void multi_l_size(size_t* n_rows, size_t* nnz) const override { rep[0]->multi_l_size(n_rows, nnz); }
+    void get_multi_l(long long* row_off, long long* cell, void* v) const override { rep[0]->get_multi_l(row_off, cell, v); }
     void multi_m_size(size_t* n_rows, size_t* nnz) const override { rep[0]->multi_m_size(n_rows, nnz); }
     void get_multi_m(long long* row_off, long long* j, void* v) const override { rep[0]->get_multi_m(row_off, j, v); }
     void raytrace_l(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool with_rays) override {
@@ -2792,6 +2867,19 @@ int ttcr_fsm_raytrace_rm(ttcr_fsm_grid* g, int slot, int n_tx, const void* tx, c
 int ttcr_fsm_raytrace_multi_m(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
                               const void* rx, void* tt_out, int with_rays) {
     return guarded_on(g, [&] { g->impl->raytrace_multi_m(n_src, tx_off, tx, t0, rx_off, rx, tt_out, with_rays != 0); });
+}
+int ttcr_fsm_raytrace_multi_l(ttcr_fsm_grid* g, int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off,
+                              const void* rx, void* tt_out, int with_rays) {
+    return guarded_on(g, [&] { g->impl->raytrace_multi_l(n_src, tx_off, tx, t0, rx_off, rx, tt_out, with_rays != 0); });
+}
+int ttcr_fsm_multi_l_size(const ttcr_fsm_grid* g, size_t* n_rows, size_t* nnz) {
+    return guarded_on(g, [&] {
+        if (!n_rows || !nnz) throw ValueError("null output pointer");
+        g->impl->multi_l_size(n_rows, nnz);
+    });
+}
+int ttcr_fsm_get_multi_l(const ttcr_fsm_grid* g, long long* row_off, long long* cell, void* v) {
+    return guarded_on(g, [&] { g->impl->get_multi_l(row_off, cell, v); });
 }
 int ttcr_fsm_multi_m_size(const ttcr_fsm_grid* g, size_t* n_rows, size_t* nnz) {
     return guarded_on(g, [&] {

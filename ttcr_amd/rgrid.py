@@ -868,6 +868,37 @@ class _Grid2d(_GridBase):
         rays = [[0.0] for _ in range(n_rcv)]
         L = []
         NN = self.get_number_of_cells()
+        if len(vTx) > 1:
+            # several events: ONE call -- batched solves, the walks follow each batch (ttcr_fsm_raytrace_multi_l)
+            tx = np.ascontiguousarray(np.vstack(vTx), dtype=dt).reshape(-1, 2)
+            t0 = np.ascontiguousarray(np.concatenate(vt0), dtype=dt)
+            rx = np.ascontiguousarray(np.vstack(vRx), dtype=dt).reshape(-1, 2)
+            tx_off = np.zeros(len(vTx) + 1, dtype=np.int32); rx_off = np.zeros(len(vTx) + 1, dtype=np.int32)
+            tx_off[1:] = np.cumsum([len(t) for t in vTx]); rx_off[1:] = np.cumsum([len(r) for r in vRx])
+            out = np.empty(max(rx.shape[0], 1), dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_raytrace_multi_l(self._h, len(vTx), _ptr(tx_off), _ptr(tx), _ptr(t0), _ptr(rx_off), _ptr(rx),
+                                                           _ptr(out), int(bool(return_rays))))
+            nrow, nnz = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(self._lib.ttcr_fsm_multi_l_size(self._h, C.byref(nrow), C.byref(nnz)))
+            off = np.zeros(nrow.value + 1, dtype=np.int64)
+            jj = np.empty(max(nnz.value, 1), dtype=np.int64)
+            vv = np.empty(max(nnz.value, 1), dtype=dt)
+            _lib.check(self._lib.ttcr_fsm_get_multi_l(self._h, _ptr(off), _ptr(jj), _ptr(vv)))
+            tmp = sp.csr_matrix((vv[:nnz.value].astype(np.float64), jj[:nnz.value], off), shape=(rx.shape[0], NN))
+            if return_rays:
+                nr, npnt = C.c_size_t(0), C.c_size_t(0)
+                _lib.check(self._lib.ttcr_fsm_rays_size(self._h, C.byref(nr), C.byref(npnt)))
+                roff = np.zeros(nr.value + 1, dtype=np.int64)
+                pts = np.empty((max(npnt.value, 1), 2), dtype=dt)
+                _lib.check(self._lib.ttcr_fsm_get_rays(self._h, _ptr(roff), _ptr(pts)))
+            for n in range(len(vTx)):
+                tt[iRx[n]] = out[rx_off[n]:rx_off[n + 1]]
+                if return_rays:
+                    for k, row in enumerate(iRx[n]):
+                        rays[row] = np.array(pts[roff[rx_off[n] + k]:roff[rx_off[n] + k + 1]], dtype=np.float64)
+            itmp = [row for n in range(len(vTx)) for row in iRx[n]]
+            Lm = tmp[itmp, :]
+            return (tt, rays, Lm) if return_rays else (tt, Lm)
         for n in range(len(vTx)):
             slot = n % self._n_threads
             tx = np.ascontiguousarray(vTx[n], dtype=dt)
