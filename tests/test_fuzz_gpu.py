@@ -65,6 +65,50 @@ def test_random_configurations_match_the_oracle(oracle, seed):
                 v = np.nextafter(v, dt(axes[ax][0]))
             rcv[1, ax] = float(v)
         source = np.hstack([t0[:, None], src])
+        # every third configuration without a raypath option: the matrices (M: 3-D node grids, L: 2-D cell grids), with / without rays
+        mat = (not walk) and not rotated and ((dim == 3 and not cell) or (dim == 2 and cell)) and rng.random() < 0.5
+        mat_rays = bool(mat and rng.random() < 0.5)
+        if mat:
+            try:
+                if dim == 3:
+                    o = oracle.solve3d(dt, nc, dx, org, s.flatten("F"), src, t0, translate=translate, compute_m=True, return_rays=mat_rays,
+                                       cell_slowness=cell, rcv=rcv, weno=weno)
+                else:
+                    o = oracle.solve2d(dt, nc, dx, dz, org, s.ravel(), src, t0, compute_L=True, return_rays=mat_rays, cell_slowness=cell,
+                                       rcv=rcv, weno=weno)
+            except RuntimeError:
+                continue
+            if dim == 3:
+                g = ttcr_amd.Grid3d(*axes, cell_slowness=cell, method="FSM", tt_from_rp=0, weno=int(weno), translate_grid=translate, dtype=dt)
+                kwm = dict(compute_M=True)
+            else:
+                g = ttcr_amd.Grid2d(*axes, cell_slowness=cell, method="FSM", tt_from_rp=0, weno=int(weno), dtype=dt)
+                kwm = dict(compute_L=True)
+            try:
+                out = g.raytrace(source, rcv, slowness=s, aggregate_src=True, return_rays=mat_rays, **kwm)
+            except ValueError as e:
+                assert "outside grid" in str(e) and dt == np.float32, (e, dt)
+                continue
+            tagm = ("matrix", dim, np.dtype(dt).name, nc, weno, mat_rays, translate)
+            np.testing.assert_array_equal(out[0], o["tt_rcv"], err_msg=str(tagm))
+            if mat_rays:
+                for a, b in zip(out[1], o["rays"]):
+                    np.testing.assert_array_equal(a, b.astype(np.float64), err_msg=str(tagm))
+            A = out[-1][0] if dim == 3 else out[-1]
+            NN = A.shape[1]
+            for n in range(rcv.shape[0]):
+                row = A.getrow(n)
+                if dim == 3:
+                    j, v = o["m"][n]
+                    keep = j < NN
+                    oo = np.argsort(j[keep], kind="stable")
+                    np.testing.assert_array_equal(row.indices, j[keep][oo], err_msg=str(tagm))
+                    np.testing.assert_array_equal(row.data, v[keep][oo].astype(np.float64), err_msg=str(tagm))
+                else:
+                    cells, lens = o["l"][n]
+                    assert sorted(zip(row.indices.tolist(), row.data.tolist())) == sorted(zip(cells.tolist(), lens.astype(np.float64).tolist())), tagm
+            n_done += 1
+            continue
         # oracle first: cases whose walk leaves the grid / does not end are skipped (the reference throws / hangs)
         kw = dict(cell_slowness=cell, rcv=rcv, weno=weno)
         try:
