@@ -206,6 +206,50 @@ class Grid3Drnfs_amd : public Grid3D<T1, T2> {
         for (size_t n = 0; n < ns; ++n) traveltimes[n].assign(tt.begin() + rx_off[n], tt.begin() + rx_off[n + 1]);
     }
 
+    // ---- the same for the overloads with m_data (ttcr/Grid3D.h:896-1000: Grid3D runs the single-source overload per source on host
+    // threads): ONE call, batched solves, then the walks of each batch.  m_data[n][r] as the single-source overloads fill them;
+    // r_data (optional) selects the overload that keeps the rays -- its terms are another matrix (include/ttcr_amd.h).
+    void raytrace_batch_m(const std::vector<std::vector<sxyz<T1>>>& Tx, const std::vector<std::vector<T1>>& t0,
+                          const std::vector<std::vector<sxyz<T1>>>& Rx, std::vector<std::vector<T1>>& traveltimes,
+                          std::vector<std::vector<std::vector<sijv<T1>>>>& m_data,
+                          std::vector<std::vector<std::vector<sxyz<T1>>>>* r_data = nullptr) const {
+        const size_t ns = Tx.size();
+        if (t0.size() != ns || Rx.size() != ns) throw std::runtime_error("Error: Tx, t0 and Rx of different sizes.");
+        std::vector<int> tx_off(ns + 1, 0), rx_off(ns + 1, 0);
+        std::vector<sxyz<T1>> tx, rx;
+        std::vector<T1> vt0;
+        for (size_t n = 0; n < ns; ++n) {
+            if (t0[n].size() != Tx[n].size()) throw std::runtime_error("Error: Tx and t0 of different sizes.");
+            tx.insert(tx.end(), Tx[n].begin(), Tx[n].end());
+            vt0.insert(vt0.end(), t0[n].begin(), t0[n].end());
+            rx.insert(rx.end(), Rx[n].begin(), Rx[n].end());
+            tx_off[n + 1] = (int)tx.size();
+            rx_off[n + 1] = (int)rx.size();
+        }
+        std::vector<T1> tt(rx.size());
+        std::lock_guard<std::mutex> rays_lock(rays_mu);   // call and fetches are one unit
+        chk(ttcr_fsm_raytrace_multi_m(h, (int)ns, tx_off.data(), tx.data(), vt0.data(), rx_off.data(), rx.data(), tt.data(), r_data ? 1 : 0));
+        size_t nrow = 0, nnz = 0;
+        chk(ttcr_fsm_multi_m_size(h, &nrow, &nnz));
+        std::vector<long long> off(nrow + 1), j(nnz ? nnz : 1);
+        std::vector<T1> v(nnz ? nnz : 1);
+        chk(ttcr_fsm_get_multi_m(h, off.data(), j.data(), v.data()));
+        traveltimes.resize(ns);
+        m_data.assign(ns, std::vector<std::vector<sijv<T1>>>());
+        for (size_t n = 0; n < ns; ++n) {
+            traveltimes[n].assign(tt.begin() + rx_off[n], tt.begin() + rx_off[n + 1]);
+            m_data[n].resize(Rx[n].size());
+            for (size_t r = 0; r < Rx[n].size(); ++r)
+                for (long long e = off[rx_off[n] + r]; e < off[rx_off[n] + r + 1]; ++e) m_data[n][r].push_back(sijv<T1>(r, (size_t)j[e], v[e]));
+        }
+        if (r_data) {
+            std::vector<std::vector<sxyz<T1>>> rays;
+            fetch_rays(rays);
+            r_data->resize(ns);
+            for (size_t n = 0; n < ns; ++n) (*r_data)[n].assign(rays.begin() + rx_off[n], rays.begin() + rx_off[n + 1]);
+        }
+    }
+
     ttcr_fsm_grid* handle() const { return h; }
 
    private:

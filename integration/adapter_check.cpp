@@ -216,6 +216,28 @@ int main() {
             }
             CHECK(okrm, "r_data + m_data overload: rays of the r_data overload, more weighted entries than the m_data-only overload");
             std::printf("rm3_entries %zu %zu nonzero %zu\n", m2[0].size(), m2[1].size(), nz2);
+            // several sources with m_data in ONE call (raytrace_batch_m) against the single-source overload, entry for entry
+            {
+                auto* ga = dynamic_cast<Grid3Drnfs_amd<float, uint32_t>*>(g.get());
+                const std::vector<std::vector<sxyz<float>>> bTx = {Tx, {{8.0f, 2.0f, 4.0f}}}, bRx = {Rm, {{2.0f, 2.0f, 2.0f}, {9.0f, 4.0f, 4.5f}}};
+                const std::vector<std::vector<float>> bt0 = {t0, {0.5f}};
+                std::vector<std::vector<float>> btt;
+                std::vector<std::vector<std::vector<sijv<float>>>> bm;
+                ga->raytrace_batch_m(bTx, bt0, bRx, btt, bm);
+                bool okb = bm.size() == 2 && btt.size() == 2;
+                for (size_t n = 0; n < 2 && okb; ++n) {
+                    std::vector<std::vector<sijv<float>>> m1;
+                    std::vector<float> tt1;
+                    g->raytrace(bTx[n], bt0[n], bRx[n], tt1, m1, 0);
+                    okb = okb && tt1 == btt[n] && m1.size() == bm[n].size();
+                    for (size_t r = 0; r < m1.size() && okb; ++r) {
+                        okb = m1[r].size() == bm[n][r].size();
+                        for (size_t e = 0; e < m1[r].size() && okb; ++e)
+                            okb = m1[r][e].i == bm[n][r][e].i && m1[r][e].j == bm[n][r][e].j && m1[r][e].v == bm[n][r][e].v;
+                    }
+                }
+                CHECK(okb, "raytrace_batch_m: two sources in one call == the m_data overload source by source");
+            }
         }
     }
     {   // ------------------------------------------------ 3-D cell grid, fp64, translated origin (Grid3Drcfs seat)
