@@ -1,28 +1,28 @@
 #!/usr/bin/env python
-"""One-wavefront sweep kernel (fsm_wave_kernels.h) against the four-wave kernel: fields, iteration counts, change history on
-random shapes / models / sources (bit-identical), then the time of a lone 512^3 and 256^3 source per kernel shape.
-  python scripts/wave_check.py [--no-time] [--cases N]"""
-import argparse, os, subprocess, sys, time, json
+"""Slab sweep kernel (fsm_slab_kernels.h) against the four-wave kernel: fields, iteration counts, change history on random
+shapes / models / sources (bit-identical), then the time of a lone 512^3 and 256^3 source with either kernel.
+  python scripts/slab_check.py [--no-time] [--cases N] [--seed S]        (TTCR_FSM_SLAB_SHAPE=2x4 | 1x4 | 2x2 | 4x2)"""
+import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def solve(shape, s, src, wave, n_threads=1, weno=0, fixed=0):
+def solve(shape, s, src, slab, n_threads=1, weno=0, fixed=0):
     import ttcr_amd
     nx, ny, nz = shape
     dx = 0.37
     g = ttcr_amd.Grid3d(np.arange(nx) * dx, np.arange(ny) * dx, np.arange(nz) * dx, n_threads=n_threads, cell_slowness=0,
                         method="FSM", tt_from_rp=0, weno=weno, dtype=np.float32)
-    g.set_option("wave", wave)
+    g.set_option("slab", slab)
     if fixed: g.set_option("fixed_iters", fixed)
     g.set_slowness(s)
     rcv = np.array([[0.0, 0.0, 0.0]])
     out = []
-    tt = g.raytrace(np.repeat(src, 1, axis=0), np.tile(rcv, (src.shape[0], 1)))
+    g.raytrace(np.repeat(src, 1, axis=0), np.tile(rcv, (src.shape[0], 1)))
     for i in range(min(n_threads, src.shape[0])):
         out.append((g.get_grid_traveltimes(i).copy(), g.get_niter(i), tuple(g.get_changes(i)[0])))
-    return out, g.timing()
+    return out, g.timing(), g.last_kernel()
 
 
 def main():
@@ -34,7 +34,9 @@ def main():
     rng = np.random.default_rng(args.seed)
     bad = 0
     for c in range(args.cases):
-        shape = tuple(int(v) for v in rng.integers(5, 70, 3)) if c % 3 else tuple(int(v) for v in rng.choice([16, 17, 32, 33, 48, 64, 65], 3))
+        nx = int(rng.choice([16, 24, 32, 40, 64, 72, 128]))            # (the slab kernel wants NF % 8 == 0)
+        ny, nz = (int(v) for v in rng.integers(5, 150, 2)) if c % 3 else (int(v) for v in rng.choice([8, 16, 17, 63, 64, 65, 128, 129], 2))
+        shape = (nx, ny, nz)
         kind = c % 4
         if kind == 0: s = np.full(shape, 0.4, np.float32)
         elif kind == 1: s = rng.uniform(0.25, 1.0, shape).astype(np.float32)
@@ -46,34 +48,41 @@ def main():
         hi = (np.array(shape) - 1) * 0.37
         src = rng.uniform(0, 1, (nsrc, 3)) * hi
         if c % 7 == 0: src[0] = np.round(src[0] / 0.37) * 0.37     # on a node
+        if c % 11 == 3: src[0] = rng.integers(0, 2, 3) * (np.array(shape) - 2) * 0.37       # in / next to a corner
         weno = 1 if c % 6 == 5 else 0
-        env_pair = os.environ.get("TTCR_FSM_PAIR")
-        ref, _ = solve(shape, s, src, 0, n_threads=nsrc, weno=weno)
-        got, _ = solve(shape, s, src, 1, n_threads=nsrc, weno=weno)
+        ref, _, k0 = solve(shape, s, src, 0, n_threads=nsrc, weno=weno)
+        got, _, k1 = solve(shape, s, src, 1, n_threads=nsrc, weno=weno)
         ok = all(np.array_equal(a[0], b[0]) and a[1] == b[1] for a, b in zip(ref, got))
-        chg = all(np.allclose(a[2], b[2], rtol=1e-6) for a, b in zip(ref, got))
-        print(f"case {c}: shape {shape} model {kind} sources {nsrc} weno {weno} niter {[a[1] for a in ref]} -> {'ok' if ok else 'FIELDS DIFFER'}"
+        chg = all(len(a[2]) == len(b[2]) and np.allclose(a[2], b[2], rtol=1e-6) for a, b in zip(ref, got))
+        print(f"case {c}: shape {shape} model {kind} sources {nsrc} weno {weno} niter {[a[1] for a in ref]} [{k1}] -> {'ok' if ok else 'FIELDS DIFFER'}"
               f"{'' if chg else ' (change history differs: %s vs %s)' % (ref[0][2], got[0][2])}", flush=True)
+        if "slab" not in k1 and not weno:   # (weno: the last kernel launched is the WENO stage's)
+            print("   (the slab kernel did not run)"); bad += 1
         if not ok:
             bad += 1
-            d = np.argwhere(ref[0][0] != got[0][0])
-            print("   first differing nodes:", d[:5].tolist(), "of", len(d), " values", [(float(ref[0][0][tuple(i)]), float(got[0][0][tuple(i)])) for i in d[:3]])
+            for a, b in zip(ref, got):
+                d = np.argwhere(a[0] != b[0])
+                if len(d):
+                    print("   first differing nodes:", d[:5].tolist(), "of", len(d), " values", [(float(a[0][tuple(i)]), float(b[0][tuple(i)])) for i in d[:3]], "niter", a[1], b[1])
     print("cases with differences:", bad)
     if not args.no_time and not bad:
         import cases
         for n in (256, 512):
             z = np.arange(n) * (20.0 / (n - 1))
-            s = np.broadcast_to((1.0 / (1.0 + 0.1 * z)).astype(np.float32), (n, n, n))
-            s = np.ascontiguousarray(s)
+            s = np.ascontiguousarray(np.broadcast_to((1.0 / (1.0 + 0.1 * z)).astype(np.float32), (n, n, n)))
             src = cases.mt_sources(1) * (n - 1) * 0.37 / 20.0
-            for wave in (0, 1):
+            res = {}
+            for slab in (0, 1):
                 best = None
                 for rep in range(4):
-                    _, tm = solve((n, n, n), s, src, wave, fixed=2)
+                    out, tm, kn = solve((n, n, n), s, src, slab, fixed=2)
                     ms = tm["sweep_ms"] / 2
                     best = ms if best is None else min(best, ms)
-                print(f"n={n} wave={wave} shape={os.environ.get('TTCR_FSM_WAVE_SHAPE','default')}: {best:.3f} ms per sweep-iteration "
-                      f"({104.0 * n ** 3 / (best * 1e-3) / 8e12:.3f} of the roofline)", flush=True)
+                res[slab] = out
+                print(f"n={n} slab={slab} [{kn}]: {best:.3f} ms per sweep-iteration ({104.0 * n ** 3 / (best * 1e-3) / 8e12:.3f} of the roofline)", flush=True)
+            same = np.array_equal(res[0][0][0], res[1][0][0])
+            print(f"n={n}: fields {'identical' if same else 'DIFFER'}", flush=True)
+            bad += 0 if same else 1
     sys.exit(1 if bad else 0)
 
 

@@ -3,6 +3,11 @@
 hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED for parity: the local
 solver must round a1 + s*dx (and every other product/sum pair) exactly like the reference,
 which a fused multiply-add would not (ttcr_amd/csrc/fsm_kernels.h header).
+
+Two translation units, compiled to objects under ttcr_amd/csrc/_obj and linked:
+  fsm_capi.hip   the C ABI, the host side and every kernel but one
+  fsm_slab.hip   the slab sweep kernel (fsm_slab_kernels.h), with the max-ILP machine scheduler: its level march holds
+                 independent node updates per lane, which the default scheduler leaves one after the other
 """
 import os
 import shutil
@@ -10,10 +15,17 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libttcr_amd.so")
-SOURCES = ["fsm_capi.hip"]
-DEPS = ["fsm_capi.hip", "fsm_kernels.h", "fsm_wave_kernels.h", "fsm_march_levels.inc", os.path.join("..", "..", "include", "ttcr_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+INC = os.path.join("..", "..", "include", "ttcr_amd.h")
+# source -> (extra flags, files it is compiled from)
+UNITS = {
+    "fsm_capi.hip": ([], ["fsm_capi.hip", "fsm_kernels.h", "fsm_slab_api.h", "fsm_march_levels.inc", INC]),
+    "fsm_slab.hip": (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["fsm_slab.hip", "fsm_slab_kernels.h", "fsm_slab_api.h", "fsm_kernels.h"]),
+}
+SOURCES = list(UNITS)
+DEPS = sorted({d for _, ds in UNITS.values() for d in ds})
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result"]
 
 
@@ -30,25 +42,46 @@ def source_hash():
     import hashlib
 
     h = hashlib.sha256(" ".join(FLAGS).encode())
+    for src in SOURCES:
+        h.update(" ".join(UNITS[src][0]).encode())
     for d in DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+
+
+def needs_build():
+    return _stale(LIB, DEPS)
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    procs = []
+    for src, (extra, deps) in UNITS.items():
+        if force or _stale(_obj(src), deps):
+            cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
     return LIB
 

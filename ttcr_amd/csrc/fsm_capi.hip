@@ -25,7 +25,7 @@
 
 #include "../../include/ttcr_amd.h"
 #include "fsm_kernels.h"
-#include "fsm_wave_kernels.h"
+#include "fsm_slab_api.h"
 
 #ifndef FSM_CHUNK3
 #define FSM_CHUNK3 8
@@ -62,7 +62,7 @@ struct DevBuf {
     size_t n = 0;
     size_t guard = 0;   // elements allocated in front of p and behind p + n (readable, never meaningful)
     void reserve(size_t m, size_t guard_ = 0) {
-        if (m <= n) return;
+        if (m <= n && guard_ <= guard) return;
         release();
         char* raw = nullptr;
         HIP_CHECK(hipMalloc((void**)&raw, (m + 2 * guard_) * sizeof(T)));
@@ -158,7 +158,7 @@ class GridBase {
                                 // per 512^3 field and iteration it is asked for -- 11.7 s instead of 0.32 s for the heterogeneous bench leg)
     long long reference_sums = 0, reference_sums_missed = 0;   // decisions taken with the reference's sum / that would have needed a snapshot
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
-    virtual void set_wave(int) {}   // option "wave" (GridT)
+    virtual void set_slab(int) {}   // option "slab" (GridT)
     // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
     // order stage then WENO stage
     std::vector<std::vector<double>> change_hist, change_histw;
@@ -193,7 +193,7 @@ class GridBase {
         else if (k == "interp_vel") interp_vel = value != 0;
         else if (k == "return_rays") return_rays = value != 0;
         else if (k == "pair_sources") pair_by_distance = value != 0;
-        else if (k == "wave") set_wave((int)value);
+        else if (k == "slab" || k == "wave") set_slab((int)value);   // ("wave": the name of the round-4 kernel this one replaces)
         else if (k == "stopping_rule") stopping_rule = (int)value;
         else throw ValueError("unknown option '" + k + "'");
     }
@@ -270,12 +270,14 @@ class GridT : public GridBase {
     DevBuf<uint32_t> d_order;  // persistent kernel: patches in ticket order (anti-diagonal major)
     DevBuf<uint32_t> d_order_xs[2][2];  // whole-iteration launch, [stage: first order / WENO][0: sweep by sweep, 1: by expected start time]
     DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
-    // one-wavefront units (fsm_wave_kernels.h): first-order 3-D sweeps of fp32 grids that keep one field per slot
-    int wave = -1;             // option "wave" / TTCR_FSM_WAVE: 1 on (where the kernel applies), 0 / -1 off (default: it is slower, profiles/r04/wave_kernel.txt)
-    int wave_pkr = 2, wave_c = 8;   // columns per lane (patch = 16 x 4 pkr columns) and levels per chunk
-    int wave_wgs = 0;          // wavefronts of a launch (each takes units until none is left); 0: 3 per SIMD
-    int wave_npk = 0, wave_patches = 0, wave_built_pkr = 0, wave_built_c = 0;
-    DevBuf<uint32_t> d_order_wave[2];   // ticket order: [0] sweep by sweep, [1] by expected start time
+    // slab kernel (fsm_slab_kernels.h): first-order 3-D sweeps of fp32 grids that keep one field per slot, NF % 8 == 0
+    int slab = -1;             // option "slab" / TTCR_FSM_SLAB: 1 on wherever the kernel applies, 0 off, -1 (default): on for batches of fewer
+                               // than slab_below entries
+    int slab_below = 0;        // (0 until the kernel is validated on the GPU in this round)
+    int slab_pkr = 2, slab_nw = 4;   // rows per wavefront, wavefronts per workgroup (patch = 64 x pkr nw columns)
+    int slab_wgs = 0;          // workgroups of a launch (each takes units until none is left); 0: one per CU
+    int slab_npj = 0, slab_npk = 0, slab_patches = 0, slab_built_pkr = 0, slab_built_nw = 0;
+    DevBuf<uint32_t> d_order_slab[2];   // ticket order: [0] sweep by sweep, [1] by expected start time
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
     DevBuf<int> d_stamp;       // dirty-brick stamps [n_slots][nbf*nbj*nbk]
@@ -351,7 +353,7 @@ class GridT : public GridBase {
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
-        d_s.reserve(n_nodes, 64);   // (guard elements: the 16-byte accesses of fsm_wave_kernels.h overhang a row by up to three)
+        d_s.reserve(n_nodes, 64);
         // source pairs (fields interleaved, marched together) for the first-order 3-D solver only.  The one-wave 2-D
         // patches issue in order, a second source doubles the instructions of a level and buys nothing (4096^2:
         // 16 sources 28.0 -> 20.8 ms, 64 sources 35.8 -> 28.9 ms, 256 sources 112 -> 87 ms unpaired); the WENO stage
@@ -448,9 +450,10 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
-        if (const char* e = std::getenv("TTCR_FSM_WAVE")) wave = std::atoi(e);
-        if (const char* e = std::getenv("TTCR_FSM_WAVE_SHAPE")) { if (std::sscanf(e, "%dx%d", &wave_pkr, &wave_c) != 2) throw ValueError("TTCR_FSM_WAVE_SHAPE=<columns per lane>x<levels per chunk>"); }
-        if (const char* e = std::getenv("TTCR_FSM_WAVE_WGS")) wave_wgs = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_SLAB")) slab = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_SLAB_BELOW")) slab_below = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_SLAB_SHAPE")) { if (std::sscanf(e, "%dx%d", &slab_pkr, &slab_nw) != 2) throw ValueError("TTCR_FSM_SLAB_SHAPE=<rows per wavefront>x<wavefronts per workgroup>"); }
+        if (const char* e = std::getenv("TTCR_FSM_SLAB_WGS")) slab_wgs = std::atoi(e);   // tuning only
     }
 
     // persistent kernel: ticket order = anti-diagonal m = TJ+TK major (a topological order of the
@@ -466,8 +469,8 @@ class GridT : public GridBase {
         // four ticket counters, the abort word, then one progress word per (direction, slot, patch).  The kernels tag every
         // word with the launch epoch: nothing is reset between the launches of a solve (fsm_kernels.h, "launch epoch")
         sync_words = 8 + (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4);
-        if (dim == 3)   // (the one-wavefront units of fsm_wave_kernels.h use finer patches: 16 x 4 columns at the least)
-            sync_words = std::max(sync_words, 8 + (size_t)((geom.NJ + 15) / 16) * ((geom.NK + 3) / 4) * n_slots * 8);
+        if (dim == 3)   // (the slab kernel, fsm_slab_kernels.h: patches of 64 x 8 columns at the least, one word per wavefront and one per patch)
+            sync_words = std::max(sync_words, 8 + (size_t)((geom.NJ + 63) / 64) * ((geom.NK + 7) / 8) * n_slots * 8 * 9);
         d_sync.reserve(sync_words);
         HIP_CHECK(hipMemset(d_sync.p, 0, sync_words * sizeof(int)));
         if (geom.npj >= (1 << 14) || geom.npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
@@ -1012,72 +1015,76 @@ class GridT : public GridBase {
         if (dim == 2 && rotated && !weno && dx == dz) launch_sweep45(batch);
     }
 
-    // ---- one-wavefront units (fsm_wave_kernels.h) ----------------------------------------------------------
-    void set_wave(int v) override { wave = v; }
-    // where they apply: first-order sweeps of a 3-D fp32 grid with one field per slot (a lone slot, grids with weno = 1, or
-    // TTCR_FSM_PAIR=0), whole-iteration launches, byte offsets of a field in 32 bits
-    bool wave_now() const {
-        if (sizeof(T) != 4 || dim != 3 || stage != 0 || NS != 1 || mode != 2 || wave <= 0) return false;   // (opt-in: see the measurements at fsm_wave_kernels.h)
+    // ---- slab kernel (fsm_slab_kernels.h) ---------------------------------------------------------------------
+    void set_slab(int v) override { slab = v; }
+    // where it applies: first-order sweeps of a 3-D fp32 grid with one field per slot (a lone slot, grids with weno = 1, small batches,
+    // TTCR_FSM_PAIR=0), whole-iteration launches, NF a multiple of 8 (aligned pieces in both sweep directions), byte offsets of a
+    // field and of a sheared slowness copy in 32 bits
+    bool slab_now(int batch) const {
+        if (sizeof(T) != 4 || dim != 3 || stage != 0 || NS != 1 || mode != 2 || slab == 0) return false;
+        if (slab < 0 && batch >= slab_below) return false;
         if (skip > 0) return false;                                  // (exact skipping asked for: the kernels that have it)
-        if ((unsigned long long)n_nodes * 4ull > 0xfff00000ull) return false;
+        if (geom.NF % 8 != 0 || geom.NF < 16) return false;
+        if ((unsigned long long)n_nodes * 4ull > 0xfff00000ull || (unsigned long long)ssh_stride * 4ull > 0xfff00000ull) return false;
         return true;
     }
-    void build_wave_lists() {
-        if (wave_built_pkr == wave_pkr && wave_built_c == wave_c) return;
-        const int PJ = 16, PK = 4 * wave_pkr, npj = (geom.NJ + PJ - 1) / PJ;
-        wave_npk = (geom.NK + PK - 1) / PK;
-        wave_patches = npj * wave_npk;
-        if (npj >= (1 << 14) || wave_npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
-        if (8 + (size_t)wave_patches * n_slots * 8 > sync_words) throw std::logic_error("progress words of the wave kernel do not fit");
+    void build_slab_lists() {
+        if (slab_built_pkr == slab_pkr && slab_built_nw == slab_nw) return;
+        const int PJ = 64, PK = slab_pkr * slab_nw;
+        slab_npj = (geom.NJ + PJ - 1) / PJ;
+        slab_npk = (geom.NK + PK - 1) / PK;
+        slab_patches = slab_npj * slab_npk;
+        if (slab_npj >= (1 << 14) || slab_npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
+        if (8 + (size_t)slab_patches * n_slots * 8 * (slab_nw + 1) > sync_words) throw std::logic_error("progress words of the slab kernel do not fit");
         std::vector<uint32_t> order;
-        for (int m = 0; m <= npj + wave_npk - 2; ++m)
-            for (int TK = std::max(0, m - npj + 1); TK <= std::min(m, wave_npk - 1); ++TK) order.push_back((uint32_t)(m - TK) | ((uint32_t)TK << 16));
+        for (int m = 0; m <= slab_npj + slab_npk - 2; ++m)
+            for (int TK = std::max(0, m - slab_npj + 1); TK <= std::min(m, slab_npk - 1); ++TK) order.push_back((uint32_t)(m - TK) | ((uint32_t)TK << 16));
         for (int tm = 0; tm < 2; ++tm) {
-            const std::vector<uint32_t> xs = xs_order_for(order, tm != 0, 1, PJ, PK, wave_c, npj, wave_patches);
-            d_order_wave[tm].reserve(xs.size());
-            HIP_CHECK(hipMemcpy(d_order_wave[tm].p, xs.data(), xs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            const std::vector<uint32_t> xs = xs_order_for(order, tm != 0, 1, PJ, PK, FSM_SLAB_C, slab_npj, slab_patches);
+            d_order_slab[tm].reserve(xs.size());
+            HIP_CHECK(hipMemcpy(d_order_slab[tm].p, xs.data(), xs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
-        wave_built_pkr = wave_pkr;
-        wave_built_c = wave_c;
+        slab_built_pkr = slab_pkr;
+        slab_built_nw = slab_nw;
     }
-    void launch_sweeps_wave(int batch) {
+    void launch_sweeps_slab(int batch) {
         if constexpr (sizeof(T) == 4) {
-            build_wave_lists();
-            WaveArgs wa;
-            wa.tt = (float*)d_tt.p;
-            wa.s = (const float*)d_s.p;
-            wa.frozen = d_mask.p;
-            wa.bbox = d_bbox.p;
-            wa.change = d_change.p;
-            wa.slots = d_slots.p;
-            wa.evals = d_evals.p;
-            wa.order = d_order_wave[batch < time_order_below ? 1 : 0].p;
-            wa.sync = d_sync.p;
-            wa.iter_ptr = d_iter.p;
-            wa.NF = geom.NF; wa.NJ = geom.NJ; wa.NK = geom.NK;
-            wa.npj = (geom.NJ + 15) / 16;
-            wa.npk = wave_npk;
-            wa.n_patches = wave_patches;
-            wa.batch = batch;
-            wa.n_nodes = (uint32_t)n_nodes;
-            wa.mask_words = (uint32_t)mask_words;
-            wa.dx = (float)dx;
-            wa.timeout_ticks = 1000000000ull;   // 10 s: a unit may wait for most of the previous sweep
+            build_slab_lists();
+            SlabArgs sa;
+            sa.tt = (float*)d_tt.p;
+            sa.ssh = (const float*)d_ssh.p;
+            sa.ssh_stride = ssh_stride;
+            sa.frozen = d_mask.p;
+            sa.bbox = d_bbox.p;
+            sa.change = d_change.p;
+            sa.slots = d_slots.p;
+            sa.evals = d_evals.p;
+            sa.order = d_order_slab[batch < time_order_below ? 1 : 0].p;
+            sa.sync = d_sync.p;
+            sa.iter_ptr = d_iter.p;
+            sa.g = geom;
+            sa.npj = slab_npj;
+            sa.npk = slab_npk;
+            sa.n_patches = slab_patches;
+            sa.batch = batch;
+            sa.mask_words = (uint32_t)mask_words;
+            sa.dx = (float)dx;
+            sa.timeout_ticks = 1000000000ull;   // 10 s: a unit may wait for most of the previous sweep
+            const size_t units = (size_t)slab_patches * batch * 8;
+            last_kernel = "fsm_sweep_slab<" + std::to_string(slab_pkr) + "," + std::to_string(slab_nw) + ">";
+            if (!fsm_slab_shape_ok(slab_pkr, slab_nw)) throw ValueError("TTCR_FSM_SLAB_SHAPE: no such instantiation (2x4, 1x4, 2x2, 4x2)");
             int cus = 0;
             HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-            const size_t cap = wave_wgs > 0 ? (size_t)wave_wgs : (size_t)std::max(cus, 1) * 12;
-            const dim3 grid((unsigned)std::min<size_t>((size_t)wave_patches * batch * 8, cap)), block(64);
-            last_kernel = "fsm_sweep_wave<" + std::to_string(wave_pkr) + "," + std::to_string(wave_c) + ">";
-            if (wave_pkr == 2 && wave_c == 8) fsm_sweep_wave<2, 8><<<grid, block, 0, stream>>>(wa);
-            else if (wave_pkr == 1 && wave_c == 8) fsm_sweep_wave<1, 8><<<grid, block, 0, stream>>>(wa);
-            else if (wave_pkr == 4 && wave_c == 8) fsm_sweep_wave<4, 8><<<grid, block, 0, stream>>>(wa);
-            else throw ValueError("TTCR_FSM_WAVE_SHAPE: no such instantiation (1x8, 2x8, 4x8)");
+            const size_t lds = fsm_slab_lds_bytes(slab_pkr, slab_nw);
+            const size_t per_cu = std::max<size_t>(1, (160 * 1024) / (lds + 2048));
+            const size_t cap = slab_wgs > 0 ? (size_t)slab_wgs : (size_t)std::max(cus, 1) * per_cu;
+            HIP_CHECK(fsm_slab_launch(slab_pkr, slab_nw, sa, (unsigned)std::min<size_t>(units, cap), stream, device));
             HIP_CHECK(hipGetLastError());
         }
     }
 
     void issue_sweeps_axis(int batch) {
-        if (wave_now()) { launch_sweeps_wave(batch); return; }
+        if (slab_now(batch)) { launch_sweeps_slab(batch); return; }
         if (stage == 1) {
             if (dim == 3) launch_sweeps_persistent<3, 2>(batch); else launch_sweeps_persistent<2, 2>(batch);
         } else if (mode >= 1) {
@@ -1888,7 +1895,8 @@ class GridT : public GridBase {
         }
         std::vector<long long> seg_off;
         std::vector<T> segs;
-        walk_m(slot, n_tx, txs.data(), (const T*)t0_v, n_rx, rxs.data(), tt_out, both, seg_off, segs);
+        // (the source was solved in the PHYSICAL slot P(slot) -- pair_sources may have permuted the map in an earlier batched call)
+        walk_m(P(slot), n_tx, txs.data(), (const T*)t0_v, n_rx, rxs.data(), tt_out, both, seg_off, segs);
         if (slot_m_off.empty()) { slot_m_off.resize(n_slots); slot_m_j.resize(n_slots); slot_m_v.resize(n_slots); }
         slot_m_off[slot].assign(1, 0); slot_m_j[slot].clear(); slot_m_v[slot].clear();
         assemble_m(n_rx, seg_off, segs, slot_m_off[slot], slot_m_j[slot], slot_m_v[slot]);
@@ -1934,7 +1942,7 @@ class GridT : public GridBase {
     void walk_l(int slot, int n_tx, const void* tx_v, const void* t0_v, int n_rx, const void* rx_v, void* tt_out_v, bool with_rays,
                 std::vector<long long>& loff, std::vector<long long>& lcell, std::vector<T>& lval, std::vector<long long>& roff,
                 std::vector<T>& rpts) {
-        const int ps = P(slot);
+        const int ps = slot;   // (a PHYSICAL slot, like walk_m's: the callers translate)
         loff.assign(1, 0); lcell.clear(); lval.clear();
         roff.assign(1, 0); rpts.clear();
         if (n_rx <= 0) return;
@@ -2019,7 +2027,7 @@ class GridT : public GridBase {
         }
         if (slot_l_off.empty()) { slot_l_off.assign(n_slots, std::vector<long long>{0}); slot_l_cell.resize(n_slots); slot_l_val.resize(n_slots); }
         if (slot_rays_off.empty()) { slot_rays_off.assign(n_slots, std::vector<long long>{0}); slot_rays_pts.resize(n_slots); }
-        walk_l(slot, n_tx, tx_v, t0_v, n_rx, rx_v, tt_out_v, with_rays, slot_l_off[slot], slot_l_cell[slot], slot_l_val[slot], slot_rays_off[slot],
+        walk_l(P(slot), n_tx, tx_v, t0_v, n_rx, rx_v, tt_out_v, with_rays, slot_l_off[slot], slot_l_cell[slot], slot_l_val[slot], slot_rays_off[slot],
                slot_rays_pts[slot]);
     }
     // the l_data overloads for every source of a call (Grid2D's multi-source overloads with l_data run the single-source overload per
