@@ -1070,6 +1070,7 @@ class GridT : public GridBase {
             sa.mask_words = (uint32_t)mask_words;
             sa.dx = (float)dx;
             sa.timeout_ticks = 1000000000ull;   // 10 s: a unit may wait for most of the previous sweep
+            sa.prof = d_prof.p;
             const size_t units = (size_t)slab_patches * batch * 8;
             last_kernel = "fsm_sweep_slab<" + std::to_string(slab_pkr) + "," + std::to_string(slab_nw) + ">";
             if (!fsm_slab_shape_ok(slab_pkr, slab_nw)) throw ValueError("TTCR_FSM_SLAB_SHAPE: no such instantiation (2x4, 1x4, 2x2, 4x2)");

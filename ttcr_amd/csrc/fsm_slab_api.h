@@ -24,6 +24,7 @@ struct SlabArgs {
     uint32_t mask_words;
     float dx;
     unsigned long long timeout_ticks;
+    unsigned long long* prof;   // debug (-DFSM_SLAB_PROF=1 builds, TTCR_FSM_PROF=1): per-phase wall-clock sums, else nullptr
 };
 
 constexpr int FSM_SLAB_DONE = 0x3fffffff;

@@ -30,7 +30,16 @@
 #include "fsm_kernels.h"
 #include "fsm_slab_api.h"
 #ifndef FSM_SLAB_EXP
-#define FSM_SLAB_EXP 0   // TIMING experiments (wrong results): 1: no unit waits for another unit
+#define FSM_SLAB_EXP 0   // TIMING experiments (wrong results): 1: no unit waits for another unit; 2: no wavefront waits for another one of its
+                         // workgroup; 4: no traveltime loads; 8: no traveltime stores; 16: no slowness loads; 32: publish without draining
+#endif
+
+#ifndef FSM_SLAB_PUB
+#define FSM_SLAB_PUB 1   // when a chunk's progress goes out: 1 right behind its write-back (the wavefront sits out the drain of its stores), 0 in the
+                         // middle of the next chunk's march (the drain is hidden, the patches downstream hear of it half a chunk later)
+#endif
+#ifndef FSM_SLAB_PROF
+#define FSM_SLAB_PROF 0   // 1: phase timers (thread 0 of every wavefront; TTCR_FSM_PROF=1 prints them)
 #endif
 
 namespace ttcr_amd {
@@ -185,6 +194,7 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
 
     // bounded waits on an LDS level counter of another wavefront of the workgroup
     auto lds_wait = [&](slab_lds_flag* p_, int want) -> int {
+        if (FSM_SLAB_EXP & 2) return want;
         int v = __builtin_amdgcn_readfirstlane(*p_);
         if (v >= want) return v;
         unsigned long long t0 = wall_clock64();
@@ -239,6 +249,10 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
     // byte offset inside a row of the piece with oriented index po (oriented elements 8 po .. 8 po + 7; NF % 8 == 0)
     auto piece_nat4 = [&](int po) -> int { return (rf ? NF - 8 - 8 * po : 8 * po) * 4; };
     slab_u4 ldv[NIT];
+    if (FSM_SLAB_EXP & 4) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) ldv[it] = slab_u4{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+    }
     int ld_dst[NIT];   // ring address the piece in ldv goes to (the dummy area: no piece)
     // pieces needed from chunk X + C on: the one that holds oriented i' = X + 2C + 1 - csum (everything below is there already; the
     // last level of chunk X + C fetches the old value of the node two levels on, i' = X + 2C + 1 - csum)
@@ -248,7 +262,7 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
             const int t = X + 2 * C + 1 - pc_csum[it];
             const bool ok = (unsigned)t < (unsigned)NF;
             const int n4 = piece_nat4(t >> 3);
-            ldv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsT, ok ? (uint32_t)(pc_rowb[it] + n4) : OOB, 0, 16);   // sc1: another XCD may have written it in this launch
+            if (!(FSM_SLAB_EXP & 4)) ldv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsT, ok ? (uint32_t)(pc_rowb[it] + n4) : OOB, 0, 16);   // sc1: another XCD may have written it in this launch
             ld_dst[it] = ok ? pc_lds[it] + (n4 & 127) : dummy;
         }
     };
@@ -264,7 +278,7 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
             const bool ok = (unsigned)(u - 7) < (unsigned)NF;
             const int n4 = piece_nat4(((u + 1) >> 3) - 1);
             const slab_u4 v = lds4(pc_lds[it] + (ok ? (n4 & 127) : 0));
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsT, ok ? (uint32_t)(pc_rowb[it] + n4) : OOB, 0, 16);
+            if (!(FSM_SLAB_EXP & 8)) __builtin_amdgcn_raw_buffer_store_b128(v, rsT, ok ? (uint32_t)(pc_rowb[it] + n4) : OOB, 0, 16);
         }
     };
 
@@ -285,6 +299,7 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
     // only ever reaches nodes that do not exist); nothing of it in the column: no access
     auto run_load = [&](int rowb4, int ns, bool exists) -> slab_u4 {
         const bool ok = exists && ns + 3 >= 0 && ns < NF;
+        if (FSM_SLAB_EXP & 4) return slab_u4{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
         return __builtin_amdgcn_raw_buffer_load_b128(rsT, ok ? (uint32_t)(rowb4 + ns * 4) : OOB, 0, 16);
     };
     // store of a run: element by element, only nodes of the column (its neighbours in memory are other columns' nodes)
@@ -292,7 +307,7 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool ok = exists && (unsigned)(ns + q) < (unsigned)NF;
-            __builtin_amdgcn_raw_buffer_store_b32(v[q], rsT, ok ? (uint32_t)(rowb4 + (ns + q) * 4) : OOB, 0, 16);
+            if (!(FSM_SLAB_EXP & 8)) __builtin_amdgcn_raw_buffer_store_b32(v[q], rsT, ok ? (uint32_t)(rowb4 + (ns + q) * 4) : OOB, 0, 16);
         }
     };
     // J halos in / J edge out.  Pair p < PKR: row p, upwind halo (column j0 - 1, levels X-1 .. X+6: the i' of column j0 at X .. X+7);
@@ -385,11 +400,19 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
         for (int r = 0; r < PKR; ++r)
 #pragma unroll
             for (int q = 0; q < C; ++q)
-                svn[r][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, (uint32_t)soff[r], shear_soff(X + q, r), 0));
+                svn[r][q] = (FSM_SLAB_EXP & 16) ? 0.05f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, (uint32_t)soff[r], shear_soff(X + q, r), 0));
     };
 
     float dec = 0.f;
     unsigned long long nevals = 0;
+    unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, prof_t = (FSM_SLAB_PROF && a.prof) ? wall_clock64() : 0ull;
+    unsigned pchunks = 0;
+#define SLAB_MARK(slot_)                                                  \
+    if (FSM_SLAB_PROF && a.prof) {                                        \
+        const unsigned long long now_ = wall_clock64();                   \
+        pacc[slot_] += now_ - prof_t;                                     \
+        prof_t = now_;                                                    \
+    }
     int smp = 0;   // lanes 0 / 1: progress words of the J / K upwind slab as sampled during the previous chunk
     const int* smp_ptr = lane == 0 ? up_j : (lane == 1 ? up_k : nullptr);
     auto wait_upwind = [&](int need) {
@@ -435,11 +458,13 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
     unsigned long long chg_prev = 0ull;
     bool first = true;
 
+    SLAB_MARK(5)
     for (; Lc <= Le; Lc += C) {
         const int X = Lc;
         // (1) both upwind slabs (other patches) have published every level <= X + C - 2
         wait_upwind(X + C - 1);
         if (halo_for != X) issue_halo(X);
+        SLAB_MARK(0)
         // (2) the slab below must be done with the ring entries the new pieces replace (up to level X - 16 of our last row, which it
         // reads during its level X - 15)
         if (w < NW - 1) (void)lds_wait(s_wlev + w + 1, X - 2 * C + 1);
@@ -447,6 +472,7 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
         // (3) pieces and halos into the ring
         land_pieces();
         land_halo(X);
+        SLAB_MARK(1)
 #pragma unroll
         for (int r = 0; r < PKR; ++r)
 #pragma unroll
@@ -483,6 +509,7 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
 #pragma unroll
         for (int r = 0; r < PKR; ++r) hv[r] = ldsf(ring_own[r] + hoff + q4[r]);
         kd = ldsf(ring_below + q4[PKR - 1]);
+        SLAB_MARK(2)
 
         auto march = [&](auto masked_tag, auto half_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
@@ -560,25 +587,40 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
             }
         };
         if (plain) march(std::false_type{}, std::integral_constant<int, 0>{}); else march(std::true_type{}, std::integral_constant<int, 0>{});
-        // the write-back of the chunk before has had half a march to drain: its progress goes out
+        SLAB_MARK(3)
+        // the write-back of the chunk before has had half a march to drain: its progress goes out.  Vector memory operations of a
+        // wavefront complete in order on this target (loads and stores count down the one vmcnt alike), so waiting until no more are
+        // outstanding than were issued AFTER those stores -- this chunk's pieces and slowness -- is waiting for the stores.
         if (pending) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(FSM_SLAB_EXP & 32)) {
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT + C * PKR) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (lane == 0) st_prog(my_prog, pending);
             pending = 0;
         }
         if (more) {   // sample the upwind words for the next chunk; its halo runs too when they are there already
             if (smp_ptr) smp = ld_raw(smp_ptr);
         }
+        SLAB_MARK(4)
         if (plain) march(std::false_type{}, std::integral_constant<int, 1>{}); else march(std::true_type{}, std::integral_constant<int, 1>{});
-        if (more) {
+        SLAB_MARK(3)
+        // (5) write back: the columns the neighbour patches read, level-aligned, and the aligned pieces this chunk completed
+        if (chg != 0ull) store_edges(X);
+        if ((chg | chg_prev) != 0ull) store_pieces(X);
+        chg_prev = chg;
+        pending = X + C > Le ? 0 : X + C;
+        if (FSM_SLAB_PUB == 1 && pending) {
+            if (!(FSM_SLAB_EXP & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this chunk's pieces and slowness came in long ago)
+            if (lane == 0) st_prog(my_prog, pending);
+            pending = 0;
+        }
+        if (more) {   // the next chunk's upwind halo runs, when the upwind slabs are known to be far enough
             const bool cov = !smp_ptr || dec_prog(smp) >= X + 2 * C - 1;
             if (__builtin_amdgcn_ballot_w64(!cov) == 0ull) issue_halo(X + C);
         }
-        // (5) write back: the aligned pieces this chunk completed, and the columns the neighbour patches read, level-aligned
-        if ((chg | chg_prev) != 0ull) store_pieces(X);
-        if (chg != 0ull) store_edges(X);
-        chg_prev = chg;
-        pending = X + C > Le ? 0 : X + C;
+        ++pchunks;
+        SLAB_MARK(4)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) st_prog(my_prog, FSM_SLAB_DONE);
@@ -593,7 +635,14 @@ __device__ __forceinline__ void fsm_slab_body(const SlabArgs& a, slab_lds_char* 
     if (lane == 0) {
         if (accd != 0.0) atomicAdd(a.change + slot, accd);
         if (nevals) atomicAdd(a.evals + slot, nevals);
+        if (FSM_SLAB_PROF && a.prof) {
+            SLAB_MARK(5)
+            for (int q = 0; q < 6; ++q) atomicAdd(a.prof + q, pacc[q]);
+            atomicAdd(a.prof + 6, 1ull);
+            atomicAdd(a.prof + 7, (unsigned long long)pchunks);
+        }
     }
+#undef SLAB_MARK
 }
 
 // One work unit.  Returns false when the tickets of the launch have run out (or a unit timed out).
