@@ -173,16 +173,22 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "max_batch"    sources swept concurrently by one launch sequence (default: n_slots)
  *   "use_graph"    1: the tile-per-launch driver (mode 0) replays its launch sequence from a hipGraph, the persistent drivers
  *                  launch their kernels directly (default); 0: no graphs; 2: graphs for every driver
- *   "stopping_rule" 0 (default): an iteration ends the solve when the fp64 sum of the decreases of its nodes is below eps * N --
- *                  the quantity the reference sums sequentially in T1 (ttcr/Grid3Drnfs.h:141-152); at 1.3e8 fp32 nodes the
- *                  reference's sum reads 1-3 % low near the threshold, so the counts can differ when an iteration lands there.
- *                  1: such an iteration (fp64 change within [1/2, 16] x eps * N; fp64 grids: 1e-6 either side) is decided by
- *                  the reference's own sum, computed on the device in node order from a snapshot of the field taken before the
- *                  iteration (taken once an iteration has announced that the next may be the last -- never for the second
- *                  iteration of a stage).  Exact, and slow where it is asked for: the sum is one chain of dependent additions
- *                  (up to 0.5 s per 512^3 field and iteration); tests/test_stopping_rule_gpu.py
- *   "wave"         1: first-order 3-D sweeps of fp32 grids with one field per slot use the one-wavefront kernel
- *                  (fsm_wave_kernels.h; slower at present, see profiles/r04/wave_kernel.txt); default off
+ *   "stopping_rule" 1 (default): the reference ends a solve when `change`, the SEQUENTIAL sum in T1, in node order, of abs(times[n] -
+ *                  T[n]) falls below eps * N (ttcr/Grid3Drnfs.h:141-152; 2-D: ttcr/Grid2Drnfs.h:265-290).  The sweep kernels
+ *                  accumulate the same quantity as an fp64 sum of decreases; at 1.3e8 fp32 nodes the reference's sum reads 1-3 %
+ *                  low near the threshold, so an iteration whose fp64 change lies within [1/2, 16] x eps * N (fp64 grids: 1e-6
+ *                  either side) is decided by the reference's own sum, computed on the device from a snapshot of the field taken
+ *                  before the iteration -- exactly, and in parallel (fsm_refsum_* in fsm_kernels.h: while the running sum stays in
+ *                  one binade an addition is an integer increment that depends on the sum only through its parity; blocks of
+ *                  elements are summarised for either parity and composed in order).  The snapshot is taken whenever the iteration
+ *                  before came within 1e4 windows of the threshold, before the first WENO iteration, and always on grids of up to
+ *                  2^24 nodes; an iteration that lands in the window without one is decided by the fp64 sum and counted
+ *                  (ttcr_fsm_stopping_stats).  0: the fp64 sum alone.  2: as 1 with the sum as ONE chain of additions (the
+ *                  round-4 kernel: 0.5 s per 512^3 field; kept as the checker of the parallel form).  tests/test_stopping_rule_gpu.py
+ *   "slab"         1: first-order 3-D sweeps of fp32 grids with one field per slot and NF % 8 == 0 use the slab kernel
+ *                  (fsm_slab_kernels.h: 64 x 8-column patches, one wavefront per 64 x 2 slab, no barrier in the level march;
+ *                  bit-identical, slower at present, see profiles/r05/slab_kernel.txt); default off.  ("wave": the same option
+ *                  under the name of the round-4 kernel it replaces)
  *   "pair_sources" 1 (default): where the grid keeps its fields in pairs (n_slots x patches of a sweep > 6 144, env
  *                  TTCR_FSM_PAIR_UNITS; TTCR_FSM_PAIR = 1 / 0 forces / forbids the pair layout at grid creation) the sources
  *                  of a batch are paired by distance before they share a workgroup two by two
@@ -314,6 +320,13 @@ typedef struct {
     int n_sources;
 } ttcr_fsm_timing;
 int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out);
+/* Decisions of the stopping rule since the grid was created: iterations decided by the reference's sequential sum, iterations
+ * that landed in the window without a snapshot (decided by the fp64 sum), rounds of the parallel sum.  Any pointer may be NULL. */
+int ttcr_fsm_stopping_stats(const ttcr_fsm_grid* g, long long* reference_sums, long long* reference_sums_missed, long long* rounds);
+/* The reference's `change` (ttcr/Grid3Drnfs.h:141-152) of two fields given on the host, n_nodes values of the grid's type each, node
+ * order: the sum, in node order, in T1, of abs(times[n] - field[n]), into *out (a T1).  parallel != 0: the parallel form the solver
+ * uses; 0: one chain of additions.  Both exact; tests compare them. */
+int ttcr_fsm_reference_change(ttcr_fsm_grid* g, const void* times, const void* field, int parallel, void* out);
 /* Name of the sweep-kernel instantiation the last solve launched (first-order stage of the last batch; no reference
  * equivalent: bench.py reports it beside the roofline figures).  Written into buf (n bytes, NUL terminated). */
 int ttcr_fsm_last_kernel(const ttcr_fsm_grid* g, char* buf, size_t n);

@@ -58,3 +58,42 @@ def test_borderline_iteration_follows_the_reference(oracle, n, seed):
     assert n_rule_ref == o2["niter"]
     assert np.array_equal(f_ref, o2["tt"])
     assert n_rule_64 != o2["niter"], "the fixture is not borderline: both rules agree"
+
+
+def _seq_sum(x):
+    s = x.dtype.type(0)
+    for v in x:
+        s = x.dtype.type(s + v)
+    return s
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_parallel_form_of_the_sequential_sum(dt):
+    """fsm_refsum_* (the reference's `change` in parallel) against the one-chain kernel and, on a small field, a Python loop: fields
+    with ties at every scale (powers of two, multiples of half an ulp of the running sum), sparse changes, changes that take the
+    sum through many binades -- the two device kernels must agree to the bit."""
+    import ttcr_amd
+
+    rng = np.random.default_rng(11)
+    for n, reps in ((24, 6), (160, 5)):
+        x = np.arange(n) * 0.5
+        g = ttcr_amd.Grid3d(x, x, x, n_threads=1, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+        N = n ** 3
+        for rep in range(reps):
+            kind = rep % 6
+            if kind == 0: d = rng.uniform(0, 1e-3, N)
+            elif kind == 1: d = rng.uniform(0, 1, N) * (rng.uniform(0, 1, N) < 0.01)
+            elif kind == 2: d = 2.0 ** rng.integers(-40, 3, N).astype(np.float64)
+            elif kind == 3: d = rng.integers(0, 4, N) * 2.0 ** (-24 if dt == np.float32 else -53) + (rng.uniform(0, 1, N) < 1e-4) * 1.0
+            elif kind == 4: d = np.abs(rng.normal(0, 1, N)) * 10.0 ** rng.integers(-12, 3, N)
+            else: d = np.full(N, 2.0 ** -20)
+            d = d.astype(dt)
+            base = rng.uniform(1.0, 2.0, N).astype(dt)
+            old = (base + d).astype(dt)           # times[n]; the kernels take abs(times - field) in T1 themselves
+            a = g.reference_change(old, base, parallel=True)
+            b = g.reference_change(old, base, parallel=False)
+            assert a == b, (n, rep, kind, a, b)
+            if n <= 24:
+                dd = np.abs(old - base).astype(dt)
+                assert a == _seq_sum(dd), (n, rep, kind, a, _seq_sum(dd))
+        print(n, dt.__name__, g.stopping_stats())

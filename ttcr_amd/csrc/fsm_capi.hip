@@ -153,10 +153,19 @@ class GridBase {
     // point that takes a slot translates.
     std::vector<int> phys;
     int P(int slot) const { return phys.empty() ? slot : phys[slot]; }
-    int stopping_rule = 0;      // option "stopping_rule": 1 the reference's sequential T1 sum decides wherever it could differ from the
+    int stopping_rule = 1;      // option "stopping_rule": 1 (default) the reference's sequential T1 sum decides wherever it could differ from the
                                 // fp64 sum of decreases, 0 the fp64 sum alone (default: the sequential sum is 1.3e8 dependent additions
                                 // per 512^3 field and iteration it is asked for -- 11.7 s instead of 0.32 s for the heterogeneous bench leg)
     long long reference_sums = 0, reference_sums_missed = 0;   // decisions taken with the reference's sum / that would have needed a snapshot
+    long long refsum_rounds = 0;                               // rounds of the parallel form of that sum (fsm_refsum_*)
+    virtual void stopping_stats(long long* sums, long long* missed, long long* rounds) const {
+        if (sums) *sums = reference_sums;
+        if (missed) *missed = reference_sums_missed;
+        if (rounds) *rounds = refsum_rounds;
+    }
+    // the reference's `change` of two fields given on the host (n_nodes values each, node order): sum of abs(times[n] - field[n]) in T1,
+    // in node order; parallel: the exact parallel form, else the one-chain kernel (tests compare the two)
+    virtual void reference_change_host(const void* times, const void* field, bool parallel, void* out) = 0;
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
     virtual void set_slab(int) {}   // option "slab" (GridT)
     // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
@@ -1144,16 +1153,93 @@ class GridT : public GridBase {
     void snapshots_before_iteration(const std::vector<int>& active, int it_next) {
         if (!stopping_rule || fixed_iters > 0) return;
         if ((int)snap_iter.size() != n_groups()) snap_iter.assign(n_groups(), 0);
+        // a snapshot costs a copy of the field(s) of a slot group: taken whenever the iteration may be the last -- the one before
+        // came within 1e4 windows of the threshold (consecutive iterations differ by factors of 4 - 40) --, before the first
+        // iteration of the WENO stage (its `times` is the last first-order field: the change can be anything), and always while
+        // the copy is cheap (fields of up to 2^24 nodes: tens of microseconds)
+        const bool cheap = n_nodes * (size_t)NS <= ((size_t)1 << 24);
         std::vector<char> done(n_groups(), 0);
         for (int s2 : active) {
             const int gi = s2 / NS;
-            if (done[gi] || !(prev_change[s2] < 1e4 * window_hi() * (double)epsilon)) continue;
+            if (done[gi]) continue;
+            if (!(cheap || (stage == 1 && it_next == 1) || prev_change[s2] < 1e4 * window_hi() * (double)epsilon)) continue;
+            if (it_next == 1 && stage == 0) continue;   // (the first iteration of a solve: its change is infinite -- every node comes down from max())
             done[gi] = 1;
             DevBuf<T>& b = snap[gi];
             b.reserve(n_nodes * (size_t)NS);
             HIP_CHECK(hipMemcpyAsync(b.p, d_tt.p + (size_t)gi * n_nodes * NS, n_nodes * (size_t)NS * sizeof(T), hipMemcpyDeviceToDevice, stream));
             snap_iter[gi] = it_next;
         }
+    }
+    // The reference's `change` of one field: sum over the nodes, in order, in T1, of abs(times[n] - T[n]).  stopping_rule = 2: the
+    // one-chain kernel (fsm_reference_change: 1.3e8 dependent additions for a 512^3 field); otherwise the same sum computed in
+    // parallel, exactly (fsm_refsum_*, fsm_kernels.h): rounds of a tile scan over a window of the field + one workgroup that finds
+    // where the running sum leaves its binade; the window follows the distance between such places.
+    DevBuf<RefSumState> d_rs_state;
+    DevBuf<RefSum4> d_rs_tiles;
+    DevBuf<T> d_rc_a, d_rc_b;
+    void reference_change_host(const void* times, const void* field, bool parallel, void* out) override {
+        HIP_CHECK(hipSetDevice(device));
+        d_rc_a.reserve(n_nodes);
+        d_rc_b.reserve(n_nodes);
+        HIP_CHECK(hipMemcpyAsync(d_rc_a.p, field, n_nodes * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rc_b.p, times, n_nodes * sizeof(T), hipMemcpyHostToDevice, stream));
+        *(T*)out = reference_change(d_rc_a.p, d_rc_b.p, 1, !parallel);
+    }
+    T reference_change(const T* cur, const T* old) { return reference_change(cur, old, NS, stopping_rule == 2); }
+    T reference_change(const T* cur, const T* old, int stride, bool one_chain) {
+        T out = 0;
+        if (one_chain) {
+            RefChangeArgs<T> ra;
+            ra.cur = cur;
+            ra.old = old;
+            const size_t zero = 0;
+            d_ref_off.reserve(1);
+            d_ref_out.reserve(1);
+            HIP_CHECK(hipMemcpyAsync(d_ref_off.p, &zero, sizeof(size_t), hipMemcpyHostToDevice, stream));
+            ra.off = d_ref_off.p;
+            ra.out = d_ref_out.p;
+            ra.n_nodes = n_nodes;
+            ra.stride = stride;
+            fsm_reference_change<T><<<1, 256, 0, stream>>>(ra);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(&out, d_ref_out.p, sizeof(T), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            return out;
+        }
+        const unsigned long long wmin = 1ull << 16, wmax = 1ull << 25;
+        d_rs_state.reserve(1);
+        d_rs_tiles.reserve(wmax / FSM_REFSUM_TILE + 1);
+        RefSumState st{0ull, 0ull, ~0ull};
+        HIP_CHECK(hipMemcpyAsync(d_rs_state.p, &st, sizeof st, hipMemcpyHostToDevice, stream));
+        RefSumArgs<T> ra;
+        ra.cur = cur;
+        ra.old = old;
+        ra.n_nodes = n_nodes;
+        ra.stride = stride;
+        ra.st = d_rs_state.p;
+        ra.tiles = d_rs_tiles.p;
+        unsigned long long window = wmin, prev_q = 0;
+        while (st.start < n_nodes) {
+            ra.window = window;
+            const unsigned long long left = std::min<unsigned long long>(window, n_nodes - st.start);
+            const unsigned tiles = (unsigned)((left + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
+            fsm_refsum_tiles<T><<<tiles, 256, 0, stream>>>(ra);
+            fsm_refsum_resolve<T><<<1, 256, 0, stream>>>(ra);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(&st, d_rs_state.p, sizeof st, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            ++refsum_rounds;
+            if (st.last_q != ~0ull) {   // the sum left its binade at element last_q: the next such place is about as far again
+                window = std::min(wmax, std::max(wmin, 2 * (st.last_q + 1 - prev_q)));
+                window = (window + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE * FSM_REFSUM_TILE;   // (whole tiles: a tile is summarised to its end)
+                prev_q = st.last_q + 1;
+            } else {
+                window = std::min(wmax, 2 * window);
+            }
+        }
+        if constexpr (sizeof(T) == 4) { const unsigned b = (unsigned)st.bits; std::memcpy(&out, &b, 4); } else { std::memcpy(&out, &st.bits, 8); }
+        return out;
     }
     // go on after this iteration?  (active slot s2, its fp64 change c, iteration `it` just done)
     std::vector<char> decide_go_on(const std::vector<int>& active, int it) {
@@ -1168,28 +1254,11 @@ class GridT : public GridBase {
             else ++reference_sums_missed;
         }
         if (ask.empty()) return go;
-        std::vector<size_t> off(ask.size());
-        // (snapshots of different groups live in different allocations: one launch per group)
         std::vector<T> res(ask.size());
-        d_ref_off.reserve(1);
-        d_ref_out.reserve(ask.size());
         for (size_t a = 0; a < ask.size(); ++a) {
             const int s2 = active[ask[a]], gi = s2 / NS;
-            RefChangeArgs<T> ra;
-            ra.cur = d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS;
-            ra.old = snap[gi].p + s2 % NS;
-            const size_t zero = 0;
-            HIP_CHECK(hipMemcpyAsync(d_ref_off.p, &zero, sizeof(size_t), hipMemcpyHostToDevice, stream));
-            ra.off = d_ref_off.p;
-            ra.out = d_ref_out.p + a;
-            ra.n_nodes = n_nodes;
-            ra.stride = NS;
-            fsm_reference_change<T><<<1, 256, 0, stream>>>(ra);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipStreamSynchronize(stream));   // (`zero` goes out of scope)
+            res[a] = reference_change(d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS, snap[gi].p + s2 % NS);
         }
-        HIP_CHECK(hipMemcpyAsync(res.data(), d_ref_out.p, sizeof(T) * ask.size(), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
         for (size_t a = 0; a < ask.size(); ++a) {
             go[ask[a]] = res[a] >= epsilon;   // `change >= epsilon`, both T1 (ttcr/Grid3Drnfs.h:153)
             ref_change_last[active[ask[a]]] = (double)res[a];
@@ -2350,6 +2419,14 @@ class MultiGrid : public GridBase {
     void compute_slowness(int n, const void* pts, bool translated, void* out) override { rep[0]->compute_slowness(n, pts, translated, out); }
     void get_niter(int slot, int* it, int* itw) const override { int l; GridBase& g = of(slot, l); g.get_niter(l, it, itw); }
     std::string kernel_name() const override { return rep[0]->kernel_name(); }
+    void stopping_stats(long long* sums, long long* missed, long long* rounds) const override {
+        long long a = 0, b = 0, c = 0;
+        for (const auto& r : rep) { long long x = 0, y = 0, z = 0; r->stopping_stats(&x, &y, &z); a += x; b += y; c += z; }
+        if (sums) *sums = a;
+        if (missed) *missed = b;
+        if (rounds) *rounds = c;
+    }
+    void reference_change_host(const void* times, const void* field, bool parallel, void* out) override { rep[0]->reference_change_host(times, field, parallel, out); }
     void get_changes(int slot, double* first, int n_first, double* wen, int n_weno) const override {
         int l; GridBase& g = of(slot, l); g.get_changes(l, first, n_first, wen, n_weno);
     }
@@ -2991,6 +3068,16 @@ int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out) {
         out->evaluated_updates = t.evaluated_updates;
         out->iterations = t.iterations;
         out->n_sources = t.n_sources;
+    });
+}
+
+int ttcr_fsm_stopping_stats(const ttcr_fsm_grid* g, long long* reference_sums, long long* reference_sums_missed, long long* rounds) {
+    return guarded_on(g, [&] { g->impl->stopping_stats(reference_sums, reference_sums_missed, rounds); });
+}
+int ttcr_fsm_reference_change(ttcr_fsm_grid* g, const void* times, const void* field, int parallel, void* out) {
+    return guarded_on(g, [&] {
+        if (!times || !field || !out) throw ValueError("ttcr_fsm_reference_change: null argument");
+        g->impl->reference_change_host(times, field, parallel != 0, out);
     });
 }
 

@@ -2257,6 +2257,263 @@ __global__ __launch_bounds__(256) void fsm_reference_change(const RefChangeArgs<
     if (tid == 0) a.out[blockIdx.x] = acc;
 }
 
+// ---- the same sum, computed in parallel -- exactly -------------------------------------------------------------------------
+// s_{i+1} = RN(s_i + x_i) with x_i = |times[i] - T[i]| >= 0 is sequential, but while the running sum stays in one binade its ulp u is
+// fixed and every s_i is a multiple S_i u of it, so
+//     RN(s_i + x_i) = (S_i + d_i) u,   d_i = round-to-nearest(x_i / u), a tie (fraction exactly 1/2) resolved so that S_i + d_i is even:
+// the increment depends on the state only through the PARITY of S_i, and only at ties.  An element is therefore a map
+// parity -> (increment, parity'), maps compose associatively, and a block of elements is summarised by two integers (its increment
+// for either parity coming in): blocks are summarised in parallel and the summaries composed in order.  The recurrence changes where
+// the sum reaches the next binade (at most a few dozen times per field: the sum only grows); the element that takes it there is added
+// with the hardware's own T addition and the scan goes on from the element behind it with the new unit.  Exact for float and double
+// (integer arithmetic on the significands; nothing is approximated), tests/test_stopping_rule_gpu.py checks it against the
+// one-chain kernel above on fields with ties at every scale.
+template <typename T> struct refsum_traits;
+template <> struct refsum_traits<float> { static constexpr int P = 24, EMIN = -149; };
+template <> struct refsum_traits<double> { static constexpr int P = 53, EMIN = -1074; };
+// v = M 2^E, M the integer significand (0 for v == 0), exact (v finite, >= 0)
+__device__ __forceinline__ void refsum_split(float v, unsigned long long& M, int& E) {
+    const unsigned b = __float_as_uint(v);
+    const int e = (int)((b >> 23) & 0xffu);
+    const unsigned long long f = b & 0x7fffffu;
+    M = e ? (f | 0x800000ull) : f;
+    E = (e ? e : 1) - 150;
+}
+__device__ __forceinline__ void refsum_split(double v, unsigned long long& M, int& E) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int e = (int)((b >> 52) & 0x7ffull);
+    const unsigned long long f = b & 0xfffffffffffffull;
+    M = e ? (f | 0x10000000000000ull) : f;
+    E = (e ? e : 1) - 1075;
+}
+// element x against the unit 2^k: nn = floor(x / u) (capped at 2^P), cls = 0 / 1 / 2: fraction below / exactly / above one half
+template <typename T>
+__device__ __forceinline__ void refsum_element(T x, int k, unsigned long long& nn, int& cls) {
+    constexpr unsigned long long LIMIT = 1ull << refsum_traits<T>::P;
+    unsigned long long M;
+    int E;
+    refsum_split(x, M, E);
+    cls = 0;
+    if (M == 0ull) { nn = 0ull; return; }
+    if (E >= k) {
+        const int sh = E - k;
+        nn = sh >= 12 ? LIMIT : (M << sh);   // (M < 2^53: no overflow below 12 bits of shift; anything that large is "beyond the binade" anyway)
+    } else {
+        const int sh = k - E;
+        if (sh >= 64) { nn = 0ull; return; }   // (x < u / 2^10: far below half a unit)
+        nn = M >> sh;
+        const unsigned long long rem = M & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+        cls = rem < half ? 0 : (rem == half ? 1 : 2);
+    }
+    nn = nn > LIMIT ? LIMIT : nn;
+}
+// increment of the element for the parity `par` of the running sum in units
+__device__ __forceinline__ unsigned long long refsum_incr(unsigned long long nn, int cls, unsigned par) {
+    return nn + (cls == 2 ? 1ull : (cls == 1 ? ((par + (unsigned)nn) & 1u) : 0ull));
+}
+// Summary of a block of elements for a fixed unit: d[x] = its increment when the sum in front of it has parity x; r[x] = the largest
+// "sum in front of an element + the most that element can add" inside the block, relative to the block's start (0: empty block).
+// An element is taken by the recurrence only while S + nn + (fraction != 0) < 2^P -- the sum provably stays in the binade --; the
+// first element for which that fails ends the round (it is added with a T addition).  With the start state S of a block that is
+// S + r[S & 1] >= 2^P.  Values saturate at 2^(P+1) (far beyond the limit: only "reached" matters from there on).
+struct RefSum4 { unsigned long long d[2], r[2]; };
+template <typename T>
+__device__ __forceinline__ unsigned long long refsum_sat(unsigned long long v) {
+    constexpr unsigned long long CAP = 1ull << (refsum_traits<T>::P + 1);
+    return v > CAP ? CAP : v;
+}
+template <typename T>
+__device__ __forceinline__ void refsum_push(RefSum4& s, unsigned long long nn, int cls) {   // s <- s then one element
+#pragma unroll
+    for (unsigned x = 0; x < 2; ++x) {
+        const unsigned long long reach = refsum_sat<T>(s.d[x] + nn + (cls ? 1ull : 0ull));
+        s.r[x] = s.r[x] > reach ? s.r[x] : reach;
+        s.d[x] = refsum_sat<T>(s.d[x] + refsum_incr(nn, cls, ((unsigned)s.d[x] + x) & 1u));
+    }
+}
+template <typename T>
+__device__ __forceinline__ RefSum4 refsum_then(const RefSum4& A, const RefSum4& B) {        // A then B
+    RefSum4 c;
+#pragma unroll
+    for (unsigned x = 0; x < 2; ++x) {
+        const unsigned y = ((unsigned)A.d[x] + x) & 1u;
+        const unsigned long long reach = refsum_sat<T>(A.d[x] + B.r[y]);
+        c.r[x] = A.r[x] > reach ? A.r[x] : reach;
+        c.d[x] = refsum_sat<T>(A.d[x] + B.d[y]);
+    }
+    return c;
+}
+struct RefSumState {       // device-resident between the rounds of a field
+    unsigned long long start;   // first element not yet added
+    unsigned long long bits;    // the running sum (bit pattern of a T)
+    unsigned long long last_q;  // element that was added with a T addition in the last round (~0: none)
+};
+template <typename T>
+struct RefSumArgs {
+    const T* cur;        // current field (element i at cur[i * stride])
+    const T* old;        // the snapshot, same layout
+    size_t n_nodes;
+    int stride;
+    RefSumState* st;
+    unsigned long long window;   // elements of this round
+    RefSum4* tiles;              // [window / TILE + 1] summaries of the tiles of the window
+};
+constexpr int FSM_REFSUM_TILE = 4096, FSM_REFSUM_PER = FSM_REFSUM_TILE / 256;
+template <typename T>
+__device__ __forceinline__ T refsum_value(unsigned long long bits) {
+    if constexpr (sizeof(T) == 4) return __uint_as_float((unsigned)bits); else return __longlong_as_double((long long)bits);
+}
+template <typename T>
+__device__ __forceinline__ unsigned long long refsum_bits(T v) {
+    if constexpr (sizeof(T) == 4) return __float_as_uint(v); else return (unsigned long long)__double_as_longlong(v);
+}
+// S 2^k as a T (S < 2^P: exact)
+template <typename T>
+__device__ __forceinline__ T refsum_make(unsigned long long S, int k) {
+    if constexpr (sizeof(T) == 4) return __builtin_ldexpf((float)S, k); else return __builtin_ldexp((double)S, k);
+}
+// unit exponent k and integer S of a running sum s = S 2^k (S in [2^(P-1), 2^P) for a normal s; s == 0: the smallest unit, S = 0)
+template <typename T>
+__device__ __forceinline__ void refsum_unit(T s, int& k, unsigned long long& S) {
+    int E;
+    refsum_split(s, S, E);
+    k = S ? E : refsum_traits<T>::EMIN;
+}
+template <typename T>
+__device__ __forceinline__ T refsum_x(const RefSumArgs<T>& a, unsigned long long i) {
+    const T df = a.old[i * a.stride] - a.cur[i * a.stride];   // times[n] - T[n], in T1 (ttcr/Grid3Drnfs.h:145)
+    return df < 0 ? -df : df;
+}
+// summary of the FSM_REFSUM_PER consecutive elements from i0 on
+template <typename T>
+__device__ __forceinline__ RefSum4 refsum_chunk(const RefSumArgs<T>& a, unsigned long long i0, int k) {
+    RefSum4 s = {{0ull, 0ull}, {0ull, 0ull}};
+    for (int q = 0; q < FSM_REFSUM_PER; ++q) {
+        const unsigned long long i = i0 + q;
+        if (i >= a.n_nodes) break;
+        unsigned long long nn;
+        int cls;
+        refsum_element<T>(refsum_x(a, i), k, nn, cls);
+        refsum_push<T>(s, nn, cls);
+    }
+    return s;
+}
+// ordered composition of the 256 summaries in sd[] (thread t holds elements before thread t + 1's): the result is in sd[0]
+template <typename T>
+__device__ __forceinline__ void refsum_tree(RefSum4* sd, int tid) {
+    for (int off = 1; off < 256; off <<= 1) {
+        RefSum4 c = {{0ull, 0ull}, {0ull, 0ull}};
+        const bool act = (tid & (2 * off - 1)) == 0;
+        if (act) c = refsum_then<T>(sd[tid], sd[tid + off]);
+        __syncthreads();
+        if (act) sd[tid] = c;
+        __syncthreads();
+    }
+}
+// round, step 1: every workgroup summarises one tile of the window for the unit of the current sum
+template <typename T>
+__global__ __launch_bounds__(256) void fsm_refsum_tiles(const RefSumArgs<T> a) {
+    __shared__ RefSum4 sd[256];
+    const unsigned long long base = a.st->start + (unsigned long long)blockIdx.x * FSM_REFSUM_TILE;
+    int k;
+    unsigned long long S;
+    refsum_unit<T>(refsum_value<T>(a.st->bits), k, S);
+    const int tid = threadIdx.x;
+    sd[tid] = refsum_chunk<T>(a, base + (unsigned long long)tid * FSM_REFSUM_PER, k);
+    __syncthreads();
+    refsum_tree<T>(sd, tid);
+    if (tid == 0) a.tiles[blockIdx.x] = sd[0];
+}
+// round, step 2 (one workgroup): compose the tile summaries in order up to the first tile in which an element may take the sum out
+// of its binade, find that element, add it with a T addition; or take the whole window.  Writes the next state.
+template <typename T>
+__global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a) {
+    constexpr unsigned long long LIMIT = 1ull << refsum_traits<T>::P;
+    __shared__ RefSum4 sd[256];
+    __shared__ unsigned long long s_S, s_tile;
+    __shared__ int s_found;
+    const int tid = threadIdx.x;
+    const unsigned long long start = a.st->start;
+    int k;
+    unsigned long long S0;
+    refsum_unit<T>(refsum_value<T>(a.st->bits), k, S0);
+    unsigned long long n_left = a.n_nodes - start;
+    n_left = n_left < a.window ? n_left : a.window;
+    const unsigned long long n_tiles = (n_left + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE;
+    // ranges of tiles per thread (their loads overlap across the threads), composed by thread 0
+    const unsigned long long per = (n_tiles + 255) / 256;
+    {
+        RefSum4 s = {{0ull, 0ull}, {0ull, 0ull}};
+        for (unsigned long long t = (unsigned long long)tid * per; t < ((unsigned long long)tid + 1) * per && t < n_tiles; ++t) s = refsum_then<T>(s, a.tiles[t]);
+        sd[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long S = S0;
+        int found = 0;
+        unsigned long long t = 0;
+        for (int c = 0; c < 256 && !found; ++c) {
+            if (S + sd[c].r[S & 1ull] >= LIMIT) {   // in this range: its tiles one by one
+                for (t = (unsigned long long)c * per; t < ((unsigned long long)c + 1) * per && t < n_tiles; ++t) {
+                    const RefSum4 q = a.tiles[t];
+                    if (S + q.r[S & 1ull] >= LIMIT) { found = 1; break; }
+                    S += q.d[S & 1ull];
+                }
+            } else {
+                S += sd[c].d[S & 1ull];
+            }
+        }
+        s_S = S; s_tile = t; s_found = found;
+    }
+    __syncthreads();
+    if (!s_found) {   // the whole window in this binade
+        if (tid == 0) {
+            RefSumState ns;
+            ns.start = start + n_left;
+            ns.bits = refsum_bits<T>(refsum_make<T>(s_S, k));
+            ns.last_q = ~0ull;
+            *a.st = ns;
+        }
+        return;
+    }
+    // inside tile s_tile (state s_S at its start): the chunks of the threads, then the elements of one chunk
+    const unsigned long long tbase = start + s_tile * FSM_REFSUM_TILE;
+    __syncthreads();
+    sd[tid] = refsum_chunk<T>(a, tbase + (unsigned long long)tid * FSM_REFSUM_PER, k);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long S = s_S;
+        int c = 0;
+        for (; c < 256; ++c) {
+            if (S + sd[c].r[S & 1ull] >= LIMIT) break;
+            S += sd[c].d[S & 1ull];
+        }
+        unsigned long long q = tbase + (unsigned long long)c * FSM_REFSUM_PER;
+        const unsigned long long qend = q + FSM_REFSUM_PER;
+        for (; q < qend && q < a.n_nodes; ++q) {
+            unsigned long long nn;
+            int cls;
+            refsum_element<T>(refsum_x(a, q), k, nn, cls);
+            if (S + nn + (cls ? 1ull : 0ull) >= LIMIT) break;
+            S += refsum_incr(nn, cls, (unsigned)S & 1u);
+        }
+        // q: the element that may take the sum out of the binade, S: the state in front of it (c == 256 or q == qend cannot happen --
+        // the summaries said so -- and would only cost a round: any element may be added the reference's way)
+        T v = refsum_make<T>(S, k);
+        RefSumState ns;
+        if (q < a.n_nodes) {
+            v = v + refsum_x(a, q);   // the reference's own addition (ttcr/Grid3Drnfs.h:147)
+            ns.start = q + 1ull;
+            ns.last_q = q;
+        } else {
+            ns.start = a.n_nodes;
+            ns.last_q = ~0ull;
+        }
+        ns.bits = refsum_bits<T>(v);
+        *a.st = ns;
+    }
+}
+
 // de-interleave one source's field for the host (getTT)
 template <typename T>
 __global__ void fsm_gather_field(const T* __restrict__ p, T* __restrict__ out, size_t n, int stride) {

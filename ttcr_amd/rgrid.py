@@ -153,6 +153,26 @@ class _GridBase:
         _lib.check(self._lib.ttcr_fsm_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
+    def stopping_stats(self):
+        """Decisions of the stopping rule since the grid was created (dict): iterations decided by the reference's sequential
+        sum, iterations that landed in its window without a snapshot, rounds of the parallel sum (ttcr_fsm_stopping_stats)."""
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        _lib.check(self._lib.ttcr_fsm_stopping_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"reference_sums": a.value, "reference_sums_missed": b.value, "rounds": c.value}
+
+    def reference_change(self, times, field, parallel=True):
+        """The reference's `change` of two fields (ttcr/Grid3Drnfs.h:141-152): the sequential sum, in node order and in the grid's
+        precision, of abs(times[n] - field[n]).  Flat arrays of get_number_of_nodes() values in node order."""
+        dt = self._dtype
+        a = np.ascontiguousarray(times, dtype=dt).ravel()
+        b = np.ascontiguousarray(field, dtype=dt).ravel()
+        n = self.get_number_of_nodes()
+        if a.size != n or b.size != n:
+            raise ValueError('reference_change: fields of get_number_of_nodes() values expected')
+        out = np.zeros(1, dtype=dt)
+        _lib.check(self._lib.ttcr_fsm_reference_change(self._h, a.ctypes.data, b.ctypes.data, 1 if parallel else 0, out.ctypes.data))
+        return out[0]
+
     def last_kernel(self):
         """Instantiation of the sweep kernel the last solve launched (string)."""
         buf = C.create_string_buffer(256)
