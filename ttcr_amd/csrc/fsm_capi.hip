@@ -1186,59 +1186,69 @@ class GridT : public GridBase {
         HIP_CHECK(hipMemcpyAsync(d_rc_b.p, times, n_nodes * sizeof(T), hipMemcpyHostToDevice, stream));
         *(T*)out = reference_change(d_rc_a.p, d_rc_b.p, 1, !parallel);
     }
-    T reference_change(const T* cur, const T* old) { return reference_change(cur, old, NS, stopping_rule == 2); }
     T reference_change(const T* cur, const T* old, int stride, bool one_chain) {
-        T out = 0;
+        std::vector<const T*> c{cur}, o{old};
+        return reference_changes(c, o, stride, one_chain)[0];
+    }
+    DevBuf<const T*> d_rs_ptrs;
+    // several fields at once: the rounds of all of them run side by side, enqueued in bunches (the state of every field stays on the
+    // device between its rounds: start, sum, window; a field that is done lets its later rounds pass)
+    std::vector<T> reference_changes(const std::vector<const T*>& cur, const std::vector<const T*>& old, int stride, bool one_chain) {
+        const size_t nf = cur.size();
+        std::vector<T> out(nf, (T)0);
         if (one_chain) {
-            RefChangeArgs<T> ra;
-            ra.cur = cur;
-            ra.old = old;
-            const size_t zero = 0;
             d_ref_off.reserve(1);
             d_ref_out.reserve(1);
-            HIP_CHECK(hipMemcpyAsync(d_ref_off.p, &zero, sizeof(size_t), hipMemcpyHostToDevice, stream));
-            ra.off = d_ref_off.p;
-            ra.out = d_ref_out.p;
-            ra.n_nodes = n_nodes;
-            ra.stride = stride;
-            fsm_reference_change<T><<<1, 256, 0, stream>>>(ra);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(&out, d_ref_out.p, sizeof(T), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            for (size_t f = 0; f < nf; ++f) {
+                RefChangeArgs<T> ra;
+                ra.cur = cur[f];
+                ra.old = old[f];
+                const size_t zero = 0;
+                HIP_CHECK(hipMemcpyAsync(d_ref_off.p, &zero, sizeof(size_t), hipMemcpyHostToDevice, stream));
+                ra.off = d_ref_off.p;
+                ra.out = d_ref_out.p;
+                ra.n_nodes = n_nodes;
+                ra.stride = stride;
+                fsm_reference_change<T><<<1, 256, 0, stream>>>(ra);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemcpyAsync(&out[f], d_ref_out.p, sizeof(T), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+            }
             return out;
         }
-        const unsigned long long wmin = 1ull << 16, wmax = 1ull << 25;
-        d_rs_state.reserve(1);
-        d_rs_tiles.reserve(wmax / FSM_REFSUM_TILE + 1);
-        RefSumState st{0ull, 0ull, ~0ull};
-        HIP_CHECK(hipMemcpyAsync(d_rs_state.p, &st, sizeof st, hipMemcpyHostToDevice, stream));
+        const size_t tiles_per_field = FSM_REFSUM_WMAX / FSM_REFSUM_TILE;
+        d_rs_state.reserve(nf);
+        d_rs_tiles.reserve(nf * tiles_per_field);
+        d_rs_ptrs.reserve(2 * nf);
+        std::vector<RefSumState> st(nf, RefSumState{0ull, 0ull, FSM_REFSUM_WMIN, 0ull});
+        std::vector<const T*> ptrs(cur);
+        ptrs.insert(ptrs.end(), old.begin(), old.end());
+        HIP_CHECK(hipMemcpyAsync(d_rs_state.p, st.data(), nf * sizeof(RefSumState), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_rs_ptrs.p, ptrs.data(), 2 * nf * sizeof(const T*), hipMemcpyHostToDevice, stream));
         RefSumArgs<T> ra;
-        ra.cur = cur;
-        ra.old = old;
+        ra.cur = d_rs_ptrs.p;
+        ra.old = d_rs_ptrs.p + nf;
         ra.n_nodes = n_nodes;
         ra.stride = stride;
         ra.st = d_rs_state.p;
         ra.tiles = d_rs_tiles.p;
-        unsigned long long window = wmin, prev_q = 0;
-        while (st.start < n_nodes) {
-            ra.window = window;
-            const unsigned long long left = std::min<unsigned long long>(window, n_nodes - st.start);
-            const unsigned tiles = (unsigned)((left + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
-            fsm_refsum_tiles<T><<<tiles, 256, 0, stream>>>(ra);
-            fsm_refsum_resolve<T><<<1, 256, 0, stream>>>(ra);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(&st, d_rs_state.p, sizeof st, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            ++refsum_rounds;
-            if (st.last_q != ~0ull) {   // the sum left its binade at element last_q: the next such place is about as far again
-                window = std::min(wmax, std::max(wmin, 2 * (st.last_q + 1 - prev_q)));
-                window = (window + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE * FSM_REFSUM_TILE;   // (whole tiles: a tile is summarised to its end)
-                prev_q = st.last_q + 1;
-            } else {
-                window = std::min(wmax, 2 * window);
+        const unsigned max_tiles = (unsigned)std::min<unsigned long long>(tiles_per_field, (n_nodes + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
+        for (;;) {
+            for (int r = 0; r < 24; ++r) {
+                fsm_refsum_tiles<T><<<dim3(max_tiles, (unsigned)nf), 256, 0, stream>>>(ra);
+                fsm_refsum_resolve<T><<<(unsigned)nf, 256, 0, stream>>>(ra);
             }
+            HIP_CHECK(hipGetLastError());
+            refsum_rounds += 24;
+            HIP_CHECK(hipMemcpyAsync(st.data(), d_rs_state.p, nf * sizeof(RefSumState), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            bool done = true;
+            for (const RefSumState& q : st) done = done && q.start >= n_nodes;
+            if (done) break;
         }
-        if constexpr (sizeof(T) == 4) { const unsigned b = (unsigned)st.bits; std::memcpy(&out, &b, 4); } else { std::memcpy(&out, &st.bits, 8); }
+        for (size_t f = 0; f < nf; ++f) {
+            if constexpr (sizeof(T) == 4) { const unsigned b = (unsigned)st[f].bits; std::memcpy(&out[f], &b, 4); } else { std::memcpy(&out[f], &st[f].bits, 8); }
+        }
         return out;
     }
     // go on after this iteration?  (active slot s2, its fp64 change c, iteration `it` just done)
@@ -1254,11 +1264,13 @@ class GridT : public GridBase {
             else ++reference_sums_missed;
         }
         if (ask.empty()) return go;
-        std::vector<T> res(ask.size());
+        std::vector<const T*> curs(ask.size()), olds(ask.size());
         for (size_t a = 0; a < ask.size(); ++a) {
             const int s2 = active[ask[a]], gi = s2 / NS;
-            res[a] = reference_change(d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS, snap[gi].p + s2 % NS);
+            curs[a] = d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS;
+            olds[a] = snap[gi].p + s2 % NS;
         }
+        const std::vector<T> res = reference_changes(curs, olds, NS, stopping_rule == 2);
         for (size_t a = 0; a < ask.size(); ++a) {
             go[ask[a]] = res[a] >= epsilon;   // `change >= epsilon`, both T1 (ttcr/Grid3Drnfs.h:153)
             ref_change_last[active[ask[a]]] = (double)res[a];

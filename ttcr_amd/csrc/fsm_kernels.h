@@ -2346,17 +2346,18 @@ __device__ __forceinline__ RefSum4 refsum_then(const RefSum4& A, const RefSum4& 
 struct RefSumState {       // device-resident between the rounds of a field
     unsigned long long start;   // first element not yet added
     unsigned long long bits;    // the running sum (bit pattern of a T)
-    unsigned long long last_q;  // element that was added with a T addition in the last round (~0: none)
+    unsigned long long window;  // elements of the next round (whole tiles): follows the distance between the places where the sum
+    unsigned long long prev_q;  // left a binade (the element behind the last such place)
 };
+constexpr unsigned long long FSM_REFSUM_WMIN = 1ull << 16, FSM_REFSUM_WMAX = 1ull << 25;
 template <typename T>
 struct RefSumArgs {
-    const T* cur;        // current field (element i at cur[i * stride])
-    const T* old;        // the snapshot, same layout
+    const T* const* cur;   // [field] current field (element i at cur[f][i * stride])
+    const T* const* old;   // [field] the snapshot, same layout
     size_t n_nodes;
     int stride;
-    RefSumState* st;
-    unsigned long long window;   // elements of this round
-    RefSum4* tiles;              // [window / TILE + 1] summaries of the tiles of the window
+    RefSumState* st;       // [field]
+    RefSum4* tiles;        // [field][FSM_REFSUM_WMAX / TILE] summaries of the tiles of the window
 };
 constexpr int FSM_REFSUM_TILE = 4096, FSM_REFSUM_PER = FSM_REFSUM_TILE / 256;
 template <typename T>
@@ -2380,13 +2381,15 @@ __device__ __forceinline__ void refsum_unit(T s, int& k, unsigned long long& S) 
     k = S ? E : refsum_traits<T>::EMIN;
 }
 template <typename T>
-__device__ __forceinline__ T refsum_x(const RefSumArgs<T>& a, unsigned long long i) {
+struct RefSumField { const T* cur; const T* old; size_t n_nodes; int stride; };
+template <typename T>
+__device__ __forceinline__ T refsum_x(const RefSumField<T>& a, unsigned long long i) {
     const T df = a.old[i * a.stride] - a.cur[i * a.stride];   // times[n] - T[n], in T1 (ttcr/Grid3Drnfs.h:145)
     return df < 0 ? -df : df;
 }
 // summary of the FSM_REFSUM_PER consecutive elements from i0 on
 template <typename T>
-__device__ __forceinline__ RefSum4 refsum_chunk(const RefSumArgs<T>& a, unsigned long long i0, int k) {
+__device__ __forceinline__ RefSum4 refsum_chunk(const RefSumField<T>& a, unsigned long long i0, int k) {
     RefSum4 s = {{0ull, 0ull}, {0ull, 0ull}};
     for (int q = 0; q < FSM_REFSUM_PER; ++q) {
         const unsigned long long i = i0 + q;
@@ -2410,21 +2413,28 @@ __device__ __forceinline__ void refsum_tree(RefSum4* sd, int tid) {
         __syncthreads();
     }
 }
-// round, step 1: every workgroup summarises one tile of the window for the unit of the current sum
+// round, step 1: every workgroup summarises one tile of the window for the unit of the current sum (blockIdx.y: field; the launch has
+// the tiles of the largest window, a workgroup beyond this round's window leaves)
 template <typename T>
 __global__ __launch_bounds__(256) void fsm_refsum_tiles(const RefSumArgs<T> a) {
     __shared__ RefSum4 sd[256];
-    const unsigned long long base = a.st->start + (unsigned long long)blockIdx.x * FSM_REFSUM_TILE;
+    const RefSumState st = a.st[blockIdx.y];
+    if (st.start >= a.n_nodes) return;
+    unsigned long long n_left = a.n_nodes - st.start;
+    n_left = n_left < st.window ? n_left : st.window;
+    if ((unsigned long long)blockIdx.x * FSM_REFSUM_TILE >= n_left) return;
+    const RefSumField<T> f = {a.cur[blockIdx.y], a.old[blockIdx.y], a.n_nodes, a.stride};
+    const unsigned long long base = st.start + (unsigned long long)blockIdx.x * FSM_REFSUM_TILE;
     int k;
     unsigned long long S;
-    refsum_unit<T>(refsum_value<T>(a.st->bits), k, S);
+    refsum_unit<T>(refsum_value<T>(st.bits), k, S);
     const int tid = threadIdx.x;
-    sd[tid] = refsum_chunk<T>(a, base + (unsigned long long)tid * FSM_REFSUM_PER, k);
+    sd[tid] = refsum_chunk<T>(f, base + (unsigned long long)tid * FSM_REFSUM_PER, k);
     __syncthreads();
     refsum_tree<T>(sd, tid);
-    if (tid == 0) a.tiles[blockIdx.x] = sd[0];
+    if (tid == 0) a.tiles[(size_t)blockIdx.y * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE) + blockIdx.x] = sd[0];
 }
-// round, step 2 (one workgroup): compose the tile summaries in order up to the first tile in which an element may take the sum out
+// round, step 2 (one workgroup per field): compose the tile summaries in order up to the first tile in which an element may take the sum out
 // of its binade, find that element, add it with a T addition; or take the whole window.  Writes the next state.
 template <typename T>
 __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a) {
@@ -2433,18 +2443,22 @@ __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a)
     __shared__ unsigned long long s_S, s_tile;
     __shared__ int s_found;
     const int tid = threadIdx.x;
-    const unsigned long long start = a.st->start;
+    const RefSumState st = a.st[blockIdx.x];
+    const unsigned long long start = st.start;
+    if (start >= a.n_nodes) return;   // (this field is done: the rounds are enqueued in bunches)
+    const RefSumField<T> f = {a.cur[blockIdx.x], a.old[blockIdx.x], a.n_nodes, a.stride};
+    const RefSum4* __restrict__ tiles = a.tiles + (size_t)blockIdx.x * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE);
     int k;
     unsigned long long S0;
-    refsum_unit<T>(refsum_value<T>(a.st->bits), k, S0);
+    refsum_unit<T>(refsum_value<T>(st.bits), k, S0);
     unsigned long long n_left = a.n_nodes - start;
-    n_left = n_left < a.window ? n_left : a.window;
+    n_left = n_left < st.window ? n_left : st.window;
     const unsigned long long n_tiles = (n_left + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE;
     // ranges of tiles per thread (their loads overlap across the threads), composed by thread 0
     const unsigned long long per = (n_tiles + 255) / 256;
     {
         RefSum4 s = {{0ull, 0ull}, {0ull, 0ull}};
-        for (unsigned long long t = (unsigned long long)tid * per; t < ((unsigned long long)tid + 1) * per && t < n_tiles; ++t) s = refsum_then<T>(s, a.tiles[t]);
+        for (unsigned long long t = (unsigned long long)tid * per; t < ((unsigned long long)tid + 1) * per && t < n_tiles; ++t) s = refsum_then<T>(s, tiles[t]);
         sd[tid] = s;
     }
     __syncthreads();
@@ -2455,7 +2469,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a)
         for (int c = 0; c < 256 && !found; ++c) {
             if (S + sd[c].r[S & 1ull] >= LIMIT) {   // in this range: its tiles one by one
                 for (t = (unsigned long long)c * per; t < ((unsigned long long)c + 1) * per && t < n_tiles; ++t) {
-                    const RefSum4 q = a.tiles[t];
+                    const RefSum4 q = tiles[t];
                     if (S + q.r[S & 1ull] >= LIMIT) { found = 1; break; }
                     S += q.d[S & 1ull];
                 }
@@ -2471,15 +2485,16 @@ __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a)
             RefSumState ns;
             ns.start = start + n_left;
             ns.bits = refsum_bits<T>(refsum_make<T>(s_S, k));
-            ns.last_q = ~0ull;
-            *a.st = ns;
+            ns.window = 2ull * st.window < FSM_REFSUM_WMAX ? 2ull * st.window : FSM_REFSUM_WMAX;
+            ns.prev_q = st.prev_q;
+            a.st[blockIdx.x] = ns;
         }
         return;
     }
     // inside tile s_tile (state s_S at its start): the chunks of the threads, then the elements of one chunk
     const unsigned long long tbase = start + s_tile * FSM_REFSUM_TILE;
     __syncthreads();
-    sd[tid] = refsum_chunk<T>(a, tbase + (unsigned long long)tid * FSM_REFSUM_PER, k);
+    sd[tid] = refsum_chunk<T>(f, tbase + (unsigned long long)tid * FSM_REFSUM_PER, k);
     __syncthreads();
     if (tid == 0) {
         unsigned long long S = s_S;
@@ -2493,7 +2508,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a)
         for (; q < qend && q < a.n_nodes; ++q) {
             unsigned long long nn;
             int cls;
-            refsum_element<T>(refsum_x(a, q), k, nn, cls);
+            refsum_element<T>(refsum_x(f, q), k, nn, cls);
             if (S + nn + (cls ? 1ull : 0ull) >= LIMIT) break;
             S += refsum_incr(nn, cls, (unsigned)S & 1u);
         }
@@ -2501,16 +2516,21 @@ __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a)
         // the summaries said so -- and would only cost a round: any element may be added the reference's way)
         T v = refsum_make<T>(S, k);
         RefSumState ns;
+        ns.window = st.window;
+        ns.prev_q = st.prev_q;
         if (q < a.n_nodes) {
-            v = v + refsum_x(a, q);   // the reference's own addition (ttcr/Grid3Drnfs.h:147)
+            v = v + refsum_x(f, q);   // the reference's own addition (ttcr/Grid3Drnfs.h:147)
             ns.start = q + 1ull;
-            ns.last_q = q;
+            // the sum left its binade here (or nearly): the next such place is about as far again; whole tiles (a tile is summarised to its end)
+            unsigned long long w = 2ull * (q + 1ull - st.prev_q);
+            w = w < FSM_REFSUM_WMIN ? FSM_REFSUM_WMIN : (w > FSM_REFSUM_WMAX ? FSM_REFSUM_WMAX : w);
+            ns.window = (w + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE * FSM_REFSUM_TILE;
+            ns.prev_q = q + 1ull;
         } else {
             ns.start = a.n_nodes;
-            ns.last_q = ~0ull;
         }
         ns.bits = refsum_bits<T>(v);
-        *a.st = ns;
+        a.st[blockIdx.x] = ns;
     }
 }
 
