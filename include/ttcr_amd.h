@@ -181,7 +181,7 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  before the iteration -- exactly, and in parallel (fsm_refsum_* in fsm_kernels.h: while the running sum stays in
  *                  one binade an addition is an integer increment that depends on the sum only through its parity; blocks of
  *                  elements are summarised for either parity and composed in order).  The snapshot is taken whenever the iteration
- *                  before came within 1e4 windows of the threshold, before the first WENO iteration, and always on grids of up to
+ *                  before came within 1e3 windows of the threshold, before the first WENO iteration, and always on grids of up to
  *                  2^24 nodes; an iteration that lands in the window without one is decided by the fp64 sum and counted
  *                  (ttcr_fsm_stopping_stats).  0: the fp64 sum alone.  2: as 1 with the sum as ONE chain of additions (the
  *                  round-4 kernel: 0.5 s per 512^3 field; kept as the checker of the parallel form).  tests/test_stopping_rule_gpu.py

@@ -176,9 +176,9 @@ def test_hip_l_walk_that_leaves_the_grid_raises_like_the_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_threads", [1, 3])
+@pytest.mark.parametrize("n_threads,device", [(1, 0), (3, 0), (4, [0, 0, 0])], ids=["1 slot", "3 slots", "4 slots on 3 replicas"])
 @pytest.mark.parametrize("rays", [False, True], ids=["l_data", "r_data+l_data"])
-def test_hip_l_several_events_in_one_call(oracle, n_threads, rays):
+def test_hip_l_several_events_in_one_call(oracle, n_threads, device, rays):
     """compute_L with several events goes to the device as ONE call (ttcr_fsm_raytrace_multi_l: batched solves, then the walks):
     the same traveltimes, rays and matrix rows as the restatement gives event by event."""
     import ttcr_amd
@@ -200,7 +200,7 @@ def test_hip_l_several_events_in_one_call(oracle, n_threads, rays):
     src = np.array([[ev_t0[rows[i][0]], *ev_src[rows[i][0]]] for i in order])
     rcv = np.array([ev_rcv[rows[i][0]][rows[i][1]] for i in order])
     axes = [np.arange(nn[0]) * dx, np.arange(nn[1]) * dz]
-    g = ttcr_amd.Grid2d(*axes, n_threads=n_threads, cell_slowness=1, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    g = ttcr_amd.Grid2d(*axes, n_threads=n_threads, cell_slowness=1, method="FSM", tt_from_rp=0, weno=0, dtype=dt, device=device)
     g.set_slowness(s)
     out = g.raytrace(src, rcv, compute_L=True, return_rays=rays)
     tt, Lm = out[0], out[-1]

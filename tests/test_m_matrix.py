@@ -213,9 +213,9 @@ def test_hip_m_matches_oracle_medium_grid(oracle, dt, both):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_threads", [1, 3])
+@pytest.mark.parametrize("n_threads,device", [(1, 0), (3, 0), (4, [0, 0, 0]), (5, [0, 0])], ids=["1 slot", "3 slots", "4 slots on 3 replicas", "5 slots on 2 replicas"])
 @pytest.mark.parametrize("rays", [False, True], ids=["m_data", "r_data+m_data"])
-def test_hip_m_several_events_in_one_call(oracle, n_threads, rays):
+def test_hip_m_several_events_in_one_call(oracle, n_threads, device, rays):
     """compute_M with several events goes to the device as ONE call (ttcr_fsm_raytrace_multi_m: batched solves, then the walks):
     the same traveltimes, matrices and rays as event by event -- the restatement's, per event."""
     import ttcr_amd
@@ -237,7 +237,9 @@ def test_hip_m_several_events_in_one_call(oracle, n_threads, rays):
     src = np.array([[ev_t0[rows[i][0]], *ev_src[rows[i][0]]] for i in order])
     rcv = np.array([ev_rcv[rows[i][0]][rows[i][1]] for i in order])
     axes = [np.arange(n) * dx for n in nn]
-    g = ttcr_amd.Grid3d(*axes, n_threads=n_threads, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    # (a device list: one replica of the grid per entry -- the events of the call are shared out among the replicas, their
+    # matrices, rays and traveltimes put together in call order: MultiGrid::sharded_matrix_call)
+    g = ttcr_amd.Grid3d(*axes, n_threads=n_threads, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt, device=device)
     g.set_slowness(s.reshape(nn, order="F"))
     out = g.raytrace(src, rcv, compute_M=True, return_rays=rays)
     tt, M = out[0], out[-1]
@@ -261,3 +263,45 @@ def test_hip_m_several_events_in_one_call(oracle, n_threads, rays):
         if rays:
             for r, q in enumerate(sel):
                 np.testing.assert_array_equal(out[1][q], o["rays"][r].astype(np.float64))
+
+
+@pytest.mark.gpu
+def test_hip_m_single_slot_call_after_a_paired_batch(oracle, monkeypatch):
+    """Round-4 advice: on a grid that keeps its fields in pairs, a batched call pairs its sources by distance and permutes the
+    logical -> physical slot map; a later single-slot m_data call (the adapters' per-thread overload, ttcr_fsm_raytrace_m) solves
+    its source in the PHYSICAL slot and has to walk THAT field.  4 spread sources in one call, then compute_M slot by slot: every
+    slot's traveltimes and matrix are the restatement's."""
+    import ttcr_amd
+    from ttcr_amd import _lib
+
+    monkeypatch.setenv("TTCR_FSM_PAIR", "1")
+    rng = np.random.default_rng(41)
+    dt = np.float32
+    nn = (37, 35, 33)
+    nc = tuple(v - 1 for v in nn)
+    dx = 0.5
+    s = rng.uniform(0.5, 1.0, nn[0] * nn[1] * nn[2])
+    hi = np.array(nc) * dx
+    axes = [np.arange(n) * dx for n in nn]
+    g = ttcr_amd.Grid3d(*axes, n_threads=4, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=dt)
+    g.set_slowness(s.reshape(nn, order="F"))
+    # sources 0 and 2 close to each other, 1 and 3 likewise: the distance pairing swaps slots
+    srcs = np.array([[2.1, 2.3, 2.2], [14.9, 15.2, 13.8], [2.9, 3.1, 2.6], [15.6, 14.4, 14.7]])
+    rcv1 = rng.uniform(0.7 * dx, hi - 0.7 * dx, (5, 3))
+    g.raytrace(np.repeat(srcs, rcv1.shape[0], axis=0), np.tile(rcv1, (4, 1)))
+    L = _lib.load()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for slot in range(4):
+        q = (slot + 1) % 4                                    # another source than the batch left in this slot
+        tx = np.ascontiguousarray(srcs[q:q + 1], dtype=dt); tt0 = np.zeros(1, dtype=dt); rx = np.ascontiguousarray(rcv1, dtype=dt)
+        out = np.empty(rx.shape[0], dtype=dt)
+        _lib.check(L.ttcr_fsm_raytrace_m(g._h, slot, 1, p(tx), p(tt0), rx.shape[0], p(rx), p(out)))
+        o = oracle.solve3d(dt, nc, dx, (0.0, 0.0, 0.0), s, srcs[q:q + 1], rcv=rcv1, compute_m=True)
+        np.testing.assert_array_equal(out, o["tt_rcv"])
+        nrow, nnz = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(L.ttcr_fsm_slot_m_size(g._h, slot, C.byref(nrow), C.byref(nnz)))
+        off = np.zeros(nrow.value + 1, dtype=np.int64); jj = np.empty(max(nnz.value, 1), dtype=np.int64); vv = np.empty(max(nnz.value, 1), dtype=dt)
+        _lib.check(L.ttcr_fsm_get_slot_m(g._h, slot, p(off), p(jj), p(vv)))
+        for n, (j, v) in enumerate(o["m"]):
+            _same_entries(jj[off[n]:off[n + 1]], vv[off[n]:off[n + 1]], j, v)
+        np.testing.assert_array_equal(g.get_grid_traveltimes(slot).flatten("F"), o["tt"])

@@ -1146,6 +1146,7 @@ class GridT : public GridBase {
     std::map<int, DevBuf<T>> snap;            // slot group -> field(s) before the current iteration
     std::vector<int> snap_iter;               // [group] iteration (stage-local, 1-based) the snapshot belongs to, 0: none
     std::vector<double> prev_change;          // [slot] fp64 change of the iteration before (inf: none yet)
+    std::vector<double> prev2_change;         // [slot] ... and of the one before that
     DevBuf<size_t> d_ref_off;
     DevBuf<T> d_ref_out;
     double window_lo() const { return sizeof(T) == 4 ? 0.5 : 1.0 - 1e-6; }
@@ -1153,16 +1154,22 @@ class GridT : public GridBase {
     void snapshots_before_iteration(const std::vector<int>& active, int it_next) {
         if (!stopping_rule || fixed_iters > 0) return;
         if ((int)snap_iter.size() != n_groups()) snap_iter.assign(n_groups(), 0);
-        // a snapshot costs a copy of the field(s) of a slot group: taken whenever the iteration may be the last -- the one before
-        // came within 1e4 windows of the threshold (consecutive iterations differ by factors of 4 - 40) --, before the first
-        // iteration of the WENO stage (its `times` is the last first-order field: the change can be anything), and always while
-        // the copy is cheap (fields of up to 2^24 nodes: tens of microseconds)
+        // a snapshot costs a copy of the field(s) of a slot group: taken whenever the iteration may land in the window -- the change
+        // of the iteration before, continued with the decrease it showed against the one before it (consecutive iterations differ
+        // by factors of 4 - 40, a factor changes by less than 8 from one iteration to the next) comes within the window; with one
+        // iteration to go by, within 1e3 windows --, before the first iteration of the WENO stage (its `times` is the last
+        // first-order field: the change can be anything), and always while the copy is cheap (up to 2^24 nodes)
         const bool cheap = n_nodes * (size_t)NS <= ((size_t)1 << 24);
         std::vector<char> done(n_groups(), 0);
         for (int s2 : active) {
             const int gi = s2 / NS;
             if (done[gi]) continue;
-            if (!(cheap || (stage == 1 && it_next == 1) || prev_change[s2] < 1e4 * window_hi() * (double)epsilon)) continue;
+            bool may = prev_change[s2] < 1e3 * window_hi() * (double)epsilon;
+            if (may && (int)prev2_change.size() == n_slots && std::isfinite(prev2_change[s2]) && prev2_change[s2] > 0) {
+                const double r = std::min(1.0, prev_change[s2] / prev2_change[s2]);
+                may = prev_change[s2] * r / 8.0 <= window_hi() * (double)epsilon;
+            }
+            if (!(cheap || (stage == 1 && it_next == 1) || may)) continue;
             if (it_next == 1 && stage == 0) continue;   // (the first iteration of a solve: its change is infinite -- every node comes down from max())
             done[gi] = 1;
             DevBuf<T>& b = snap[gi];
@@ -1188,12 +1195,14 @@ class GridT : public GridBase {
     }
     T reference_change(const T* cur, const T* old, int stride, bool one_chain) {
         std::vector<const T*> c{cur}, o{old};
-        return reference_changes(c, o, stride, one_chain)[0];
+        return reference_changes(c, o, stride, one_chain, std::numeric_limits<T>::infinity())[0];
     }
     DevBuf<const T*> d_rs_ptrs;
+    DevBuf<unsigned> d_rs_arrived;
     // several fields at once: the rounds of all of them run side by side, enqueued in bunches (the state of every field stays on the
     // device between its rounds: start, sum, window; a field that is done lets its later rounds pass)
-    std::vector<T> reference_changes(const std::vector<const T*>& cur, const std::vector<const T*>& old, int stride, bool one_chain) {
+    // stop_at: a field is done once its running sum has reached this value (the sum only grows; the value returned is then a lower bound)
+    std::vector<T> reference_changes(const std::vector<const T*>& cur, const std::vector<const T*>& old, int stride, bool one_chain, T stop_at) {
         const size_t nf = cur.size();
         std::vector<T> out(nf, (T)0);
         if (one_chain) {
@@ -1220,6 +1229,8 @@ class GridT : public GridBase {
         d_rs_state.reserve(nf);
         d_rs_tiles.reserve(nf * tiles_per_field);
         d_rs_ptrs.reserve(2 * nf);
+        d_rs_arrived.reserve(nf);
+        HIP_CHECK(hipMemsetAsync(d_rs_arrived.p, 0, nf * sizeof(unsigned), stream));
         std::vector<RefSumState> st(nf, RefSumState{0ull, 0ull, FSM_REFSUM_WMIN, 0ull});
         std::vector<const T*> ptrs(cur);
         ptrs.insert(ptrs.end(), old.begin(), old.end());
@@ -1232,14 +1243,13 @@ class GridT : public GridBase {
         ra.stride = stride;
         ra.st = d_rs_state.p;
         ra.tiles = d_rs_tiles.p;
+        ra.arrived = d_rs_arrived.p;
+        ra.stop_at = stop_at;
         const unsigned max_tiles = (unsigned)std::min<unsigned long long>(tiles_per_field, (n_nodes + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
         for (;;) {
-            for (int r = 0; r < 24; ++r) {
-                fsm_refsum_tiles<T><<<dim3(max_tiles, (unsigned)nf), 256, 0, stream>>>(ra);
-                fsm_refsum_resolve<T><<<(unsigned)nf, 256, 0, stream>>>(ra);
-            }
+            for (int r = 0; r < 16; ++r) fsm_refsum_round<T><<<dim3(std::min(max_tiles, 1024u), (unsigned)nf), 256, 0, stream>>>(ra);
             HIP_CHECK(hipGetLastError());
-            refsum_rounds += 24;
+            refsum_rounds += 16;
             HIP_CHECK(hipMemcpyAsync(st.data(), d_rs_state.p, nf * sizeof(RefSumState), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             bool done = true;
@@ -1270,7 +1280,7 @@ class GridT : public GridBase {
             curs[a] = d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS;
             olds[a] = snap[gi].p + s2 % NS;
         }
-        const std::vector<T> res = reference_changes(curs, olds, NS, stopping_rule == 2);
+        const std::vector<T> res = reference_changes(curs, olds, NS, stopping_rule == 2, epsilon);   // (asked: change >= epsilon)
         for (size_t a = 0; a < ask.size(); ++a) {
             go[ask[a]] = res[a] >= epsilon;   // `change >= epsilon`, both T1 (ttcr/Grid3Drnfs.h:153)
             ref_change_last[active[ask[a]]] = (double)res[a];
@@ -1382,6 +1392,7 @@ class GridT : public GridBase {
             std::vector<int> active(slot_ids);
             int it = 0;
             prev_change.assign(n_slots, std::numeric_limits<double>::infinity());   // (the first iteration of a stage always runs: no snapshot)
+            prev2_change.assign(n_slots, std::numeric_limits<double>::infinity());
             snap_iter.assign(n_groups(), 0);
             if ((int)ref_change_last.size() != n_slots) ref_change_last.assign(n_slots, std::nan(""));
             // batch entries: slot groups for the persistent kernel (with a lane mask), slots otherwise
@@ -1407,6 +1418,7 @@ class GridT : public GridBase {
                 HIP_CHECK(hipMemcpyAsync(d_lmask.p, h_lmask, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
                 snapshots_before_iteration(active, it + 1);
+                if (host_prof) { HIP_CHECK(hipStreamSynchronize(stream)); hp_mark("snapshots"); }
                 h_iter[0] = it_total;
                 h_iter[1] = (int)launch_epoch;   // epoch of this iteration's (first) sweep launch
                 launch_epoch += (persistent_now() && mode == 2) ? 1u : (unsigned)ndir;
@@ -1425,11 +1437,13 @@ class GridT : public GridBase {
                 ++it_total;
                 std::vector<int> next;
                 const std::vector<char> go = fixed_iters > 0 ? std::vector<char>(active.size(), 1) : decide_go_on(active, it);
+                hp_mark("stopping rule");
                 for (size_t q = 0; q < active.size(); ++q) {
                     const int s2 = active[q];
                     (stage == 0 ? niter : niterw)[s2] = it;
                     (stage == 0 ? change_hist : change_histw)[s2].push_back(h_change[s2]);
                     timing.node_updates += (long long)n_nodes * ndir;
+                    prev2_change[s2] = prev_change[s2];
                     prev_change[s2] = h_change[s2];
                     if (go[q]) next.push_back(s2);
                 }
@@ -2458,35 +2472,114 @@ class MultiGrid : public GridBase {
         timing = g.timing;
     }
     void slot_m_size(int slot, size_t* n_rows, size_t* nnz) const override { int l; GridBase& g = of(slot, l); g.slot_m_size(l, n_rows, nnz); }
-    // (the batched m_data call runs on the first replica: its walks are a small part of a call, the solves of one device suffice)
+    // The batched m_data / l_data calls (Grid3D::raytrace with m_data, Grid2D::raytrace with l_data, for every event of a call): the
+    // sources go to the replicas in contiguous blocks, in proportion to their slots (every replica then distributes its block over
+    // its own slots like a one-device grid), the replicas work side by side, and the CSR rows, rays and traveltimes of the blocks are
+    // put together in source order.
+    std::vector<long long> mm_off{0}, mm_idx;
+    std::vector<char> mm_val;
+    template <typename Call, typename Size, typename Get>
+    void sharded_matrix_call(int n_src, const int* tx_off, const void* tx_v, const void* t0_v, const int* rx_off, const void* rx_v, void* tt_out_v,
+                             Call&& call, Size&& size_of, Get&& get_of) {
+        const auto wall0 = std::chrono::steady_clock::now();
+        timing = Timing();
+        timing.n_sources = n_src;
+        mm_off.assign(1, 0); mm_idx.clear(); mm_val.clear();
+        rays_off.assign(1, 0); rays_pts.clear();
+        if (n_src <= 0) return;
+        const char* tx = (const char*)tx_v; const char* t0 = (const char*)t0_v; const char* rx = (const char*)rx_v;
+        char* tt_out = (char*)tt_out_v;
+        const int nd = (int)rep.size();
+        std::vector<int> first(nd + 1, 0);   // sources [first[d], first[d+1]) go to replica d
+        {
+            long long before = 0;
+            for (int d = 0; d < nd; ++d) {
+                first[d] = (int)((long long)n_src * before / n_slots);
+                before += rep[d]->n_slots;
+            }
+            first[nd] = n_src;
+        }
+        struct Part { std::vector<long long> off, idx, roff; std::vector<char> val, rpts; Timing t; };
+        std::vector<Part> part(nd);
+        std::vector<std::exception_ptr> errs(nd);
+        auto work = [&](int d) {
+            try {
+                const int s0 = first[d], m = first[d + 1] - first[d];
+                if (m <= 0) return;
+                GridBase& g = *rep[d];
+                std::vector<int> to(m + 1), ro(m + 1);
+                for (int q = 0; q <= m; ++q) { to[q] = tx_off[s0 + q] - tx_off[s0]; ro[q] = rx_off[s0 + q] - rx_off[s0]; }
+                std::vector<char> stt(elem_size * (size_t)std::max(ro[m], 1));
+                call(g, m, to.data(), tx + pt_bytes * tx_off[s0], t0 + elem_size * tx_off[s0], ro.data(), rx + pt_bytes * rx_off[s0], stt.data());
+                std::memcpy(tt_out + elem_size * rx_off[s0], stt.data(), elem_size * (size_t)ro[m]);
+                Part& p = part[d];
+                p.t = g.timing;
+                size_t nr = 0, nnz = 0;
+                size_of(g, &nr, &nnz);
+                p.off.assign(nr + 1, 0); p.idx.resize(nnz); p.val.resize(nnz * elem_size);
+                if (nr > 0) get_of(g, p.off.data(), p.idx.data(), p.val.data());
+                size_t rr = 0, rp = 0;
+                g.rays_size(&rr, &rp);
+                p.roff.assign(rr + 1, 0); p.rpts.resize(rp * pt_bytes);
+                if (rr > 0) g.get_rays(p.roff.data(), p.rpts.data());
+            } catch (...) { errs[d] = std::current_exception(); }
+        };
+        std::vector<std::thread> th;
+        for (int d = 1; d < nd; ++d) th.emplace_back(work, d);
+        work(0);
+        for (auto& t : th) t.join();
+        for (auto& e : errs)
+            if (e) std::rethrow_exception(e);
+        for (int d = 0; d < nd; ++d) {
+            const Part& p = part[d];
+            if (p.off.empty()) continue;
+            const long long base = mm_off.back();
+            for (size_t r = 1; r < p.off.size(); ++r) mm_off.push_back(base + p.off[r]);
+            mm_idx.insert(mm_idx.end(), p.idx.begin(), p.idx.end());
+            mm_val.insert(mm_val.end(), p.val.begin(), p.val.end());
+            const long long rbase = rays_off.back();
+            for (size_t r = 1; r < p.roff.size(); ++r) rays_off.push_back(rbase + p.roff[r]);
+            rays_pts.insert(rays_pts.end(), p.rpts.begin(), p.rpts.end());
+            timing.sweep_ms = std::max(timing.sweep_ms, p.t.sweep_ms);   // (the devices run side by side)
+            timing.launches += p.t.launches;
+            timing.node_updates += p.t.node_updates;
+            timing.evaluated_updates += p.t.evaluated_updates;
+            timing.iterations = std::max(timing.iterations, p.t.iterations);
+        }
+        // iteration counts: per slot, as after any call (the last source a slot solved)
+        for (int s2 = 0; s2 < n_slots; ++s2) { int l; GridBase& g = of(s2, l); g.get_niter(l, &niter[s2], &niterw[s2]); }
+        timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
     void raytrace_multi_m(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off, const void* rx, void* tt_out,
                           bool both) override {
-        GridBase& g = *rep[0];
-        g.raytrace_multi_m(n_src, tx_off, tx, t0, rx_off, rx, tt_out, both);
-        timing = g.timing;
-        size_t nr = 0, np = 0;
-        g.rays_size(&nr, &np);
-        rays_off.assign(nr + 1, 0);
-        rays_pts.resize(np * pt_bytes);
-        if (nr > 0) g.get_rays(rays_off.data(), rays_pts.data());
-        for (int n = 0; n < std::min(n_src, g.n_slots); ++n) { niter[n] = g.niter[n]; niterw[n] = g.niterw[n]; }
+        sharded_matrix_call(
+            n_src, tx_off, tx, t0, rx_off, rx, tt_out,
+            [&](GridBase& g, int m, const int* to, const void* stx, const void* st0, const int* ro, const void* srx, void* stt) {
+                g.raytrace_multi_m(m, to, stx, st0, ro, srx, stt, both);
+            },
+            [](GridBase& g, size_t* nr, size_t* nnz) { g.multi_m_size(nr, nnz); },
+            [](GridBase& g, long long* off, long long* idx, void* v) { g.get_multi_m(off, idx, v); });
     }
     void raytrace_multi_l(int n_src, const int* tx_off, const void* tx, const void* t0, const int* rx_off, const void* rx, void* tt_out,
                           bool with_rays) override {
-        GridBase& g = *rep[0];
-        g.raytrace_multi_l(n_src, tx_off, tx, t0, rx_off, rx, tt_out, with_rays);
-        timing = g.timing;
-        size_t nr = 0, np = 0;
-        g.rays_size(&nr, &np);
-        rays_off.assign(nr + 1, 0);
-        rays_pts.resize(np * pt_bytes);
-        if (nr > 0) g.get_rays(rays_off.data(), rays_pts.data());
-        for (int n = 0; n < std::min(n_src, g.n_slots); ++n) { niter[n] = g.niter[n]; niterw[n] = g.niterw[n]; }
+        sharded_matrix_call(
+            n_src, tx_off, tx, t0, rx_off, rx, tt_out,
+            [&](GridBase& g, int m, const int* to, const void* stx, const void* st0, const int* ro, const void* srx, void* stt) {
+                g.raytrace_multi_l(m, to, stx, st0, ro, srx, stt, with_rays);
+            },
+            [](GridBase& g, size_t* nr, size_t* nnz) { g.multi_l_size(nr, nnz); },
+            [](GridBase& g, long long* off, long long* idx, void* v) { g.get_multi_l(off, idx, v); });
     }
-    void multi_l_size(size_t* n_rows, size_t* nnz) const override { rep[0]->multi_l_size(n_rows, nnz); }
-    void get_multi_l(long long* row_off, long long* cell, void* v) const override { rep[0]->get_multi_l(row_off, cell, v); }
-    void multi_m_size(size_t* n_rows, size_t* nnz) const override { rep[0]->multi_m_size(n_rows, nnz); }
-    void get_multi_m(long long* row_off, long long* j, void* v) const override { rep[0]->get_multi_m(row_off, j, v); }
+    void multi_l_size(size_t* n_rows, size_t* nnz) const override { *n_rows = mm_off.size() - 1; *nnz = mm_idx.size(); }
+    void get_multi_l(long long* row_off, long long* cell, void* v) const override { get_multi_m(row_off, cell, v); }
+    void multi_m_size(size_t* n_rows, size_t* nnz) const override { *n_rows = mm_off.size() - 1; *nnz = mm_idx.size(); }
+    void get_multi_m(long long* row_off, long long* j, void* v) const override {
+        std::memcpy(row_off, mm_off.data(), mm_off.size() * sizeof(long long));
+        if (!mm_idx.empty()) {
+            std::memcpy(j, mm_idx.data(), mm_idx.size() * sizeof(long long));
+            std::memcpy(v, mm_val.data(), mm_val.size());
+        }
+    }
     void raytrace_l(int slot, int n_tx, const void* tx, const void* t0, int n_rx, const void* rx, void* tt_out, bool with_rays) override {
         int l; GridBase& g = of(slot, l);
         g.raytrace_l(l, n_tx, tx, t0, n_rx, rx, tt_out, with_rays);

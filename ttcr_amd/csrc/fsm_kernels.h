@@ -2358,6 +2358,9 @@ struct RefSumArgs {
     int stride;
     RefSumState* st;       // [field]
     RefSum4* tiles;        // [field][FSM_REFSUM_WMAX / TILE] summaries of the tiles of the window
+    unsigned* arrived;     // [field] workgroups of the round that are done with their tiles (zero between rounds)
+    T stop_at;             // the sum only grows: a field whose running sum has reached this value is done (what the caller asks is
+                           // `change >= epsilon`); infinity: the whole sum
 };
 constexpr int FSM_REFSUM_TILE = 4096, FSM_REFSUM_PER = FSM_REFSUM_TILE / 256;
 template <typename T>
@@ -2413,47 +2416,69 @@ __device__ __forceinline__ void refsum_tree(RefSum4* sd, int tid) {
         __syncthreads();
     }
 }
-// round, step 1: every workgroup summarises one tile of the window for the unit of the current sum (blockIdx.y: field; the launch has
-// the tiles of the largest window, a workgroup beyond this round's window leaves)
+// One round of a field (blockIdx.y): the workgroups summarise the tiles of the window for the unit of the current sum (grid stride);
+// the one that finishes last composes the summaries in order up to the first tile in which an element may take the sum out of its
+// binade, finds that element and adds it with a T addition -- or takes the whole window -- and writes the next state.
 template <typename T>
-__global__ __launch_bounds__(256) void fsm_refsum_tiles(const RefSumArgs<T> a) {
-    __shared__ RefSum4 sd[256];
-    const RefSumState st = a.st[blockIdx.y];
-    if (st.start >= a.n_nodes) return;
-    unsigned long long n_left = a.n_nodes - st.start;
-    n_left = n_left < st.window ? n_left : st.window;
-    if ((unsigned long long)blockIdx.x * FSM_REFSUM_TILE >= n_left) return;
-    const RefSumField<T> f = {a.cur[blockIdx.y], a.old[blockIdx.y], a.n_nodes, a.stride};
-    const unsigned long long base = st.start + (unsigned long long)blockIdx.x * FSM_REFSUM_TILE;
-    int k;
-    unsigned long long S;
-    refsum_unit<T>(refsum_value<T>(st.bits), k, S);
-    const int tid = threadIdx.x;
-    sd[tid] = refsum_chunk<T>(f, base + (unsigned long long)tid * FSM_REFSUM_PER, k);
-    __syncthreads();
-    refsum_tree<T>(sd, tid);
-    if (tid == 0) a.tiles[(size_t)blockIdx.y * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE) + blockIdx.x] = sd[0];
-}
-// round, step 2 (one workgroup per field): compose the tile summaries in order up to the first tile in which an element may take the sum out
-// of its binade, find that element, add it with a T addition; or take the whole window.  Writes the next state.
-template <typename T>
-__global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a) {
+__global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
     constexpr unsigned long long LIMIT = 1ull << refsum_traits<T>::P;
     __shared__ RefSum4 sd[256];
     __shared__ unsigned long long s_S, s_tile;
-    __shared__ int s_found;
+    __shared__ int s_found, s_last;
     const int tid = threadIdx.x;
-    const RefSumState st = a.st[blockIdx.x];
+    const int fi = blockIdx.y;
+    const RefSumState st = a.st[fi];
     const unsigned long long start = st.start;
     if (start >= a.n_nodes) return;   // (this field is done: the rounds are enqueued in bunches)
-    const RefSumField<T> f = {a.cur[blockIdx.x], a.old[blockIdx.x], a.n_nodes, a.stride};
-    const RefSum4* __restrict__ tiles = a.tiles + (size_t)blockIdx.x * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE);
+    const RefSumField<T> f = {a.cur[fi], a.old[fi], a.n_nodes, a.stride};
+    RefSum4* __restrict__ tiles = a.tiles + (size_t)fi * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE);
     int k;
     unsigned long long S0;
     refsum_unit<T>(refsum_value<T>(st.bits), k, S0);
     unsigned long long n_left = a.n_nodes - start;
     n_left = n_left < st.window ? n_left : st.window;
     const unsigned long long n_tiles = (n_left + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE;
+    if (blockIdx.x >= n_tiles) return;   // (no tile for this workgroup in this round: it is not counted either)
+    const unsigned n_part = (unsigned)(n_tiles < (unsigned long long)gridDim.x ? n_tiles : (unsigned long long)gridDim.x);
+    // the elements of a tile come in coalesced (thread t: elements t, t + 256, ...) and go through LDS to the threads that walk them
+    // in order, 16 consecutive ones each (17 words per 16 elements: the walks of a wavefront hit different banks)
+    __shared__ T xs[FSM_REFSUM_TILE + FSM_REFSUM_TILE / FSM_REFSUM_PER];
+    for (unsigned long long b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+        const unsigned long long tb = start + b * FSM_REFSUM_TILE;
+#pragma unroll 4
+        for (int q = 0; q < FSM_REFSUM_PER; ++q) {
+            const int e = q * 256 + tid;
+            const unsigned long long i = tb + e;
+            xs[e + e / FSM_REFSUM_PER] = i < a.n_nodes ? refsum_x(f, i) : (T)0;   // (beyond the field: zeros add nothing)
+        }
+        __syncthreads();
+        RefSum4 c = {{0ull, 0ull}, {0ull, 0ull}};
+#pragma unroll 4
+        for (int q = 0; q < FSM_REFSUM_PER; ++q) {
+            unsigned long long nn;
+            int cls;
+            refsum_element<T>(xs[tid * (FSM_REFSUM_PER + 1) + q], k, nn, cls);
+            refsum_push<T>(c, nn, cls);
+        }
+        sd[tid] = c;
+        __syncthreads();
+        refsum_tree<T>(sd, tid);
+        if (tid == 0) tiles[b] = sd[0];
+        __syncthreads();
+    }
+    // the last workgroup to get here goes on (release of the summaries before the arrival, acquire after it: one lane each)
+    if (tid == 0) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the write-back of the release is complete before the arrival: MI355X guide, compiler hazard)
+        s_last = atomicAdd(a.arrived + fi, 1u) == n_part - 1u;
+        if (s_last) {
+            __threadfence();
+            a.arrived[fi] = 0u;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+
     // ranges of tiles per thread (their loads overlap across the threads), composed by thread 0
     const unsigned long long per = (n_tiles + 255) / 256;
     {
@@ -2487,7 +2512,8 @@ __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a)
             ns.bits = refsum_bits<T>(refsum_make<T>(s_S, k));
             ns.window = 2ull * st.window < FSM_REFSUM_WMAX ? 2ull * st.window : FSM_REFSUM_WMAX;
             ns.prev_q = st.prev_q;
-            a.st[blockIdx.x] = ns;
+            if (refsum_value<T>(ns.bits) >= a.stop_at) ns.start = a.n_nodes;
+            a.st[fi] = ns;
         }
         return;
     }
@@ -2530,7 +2556,8 @@ __global__ __launch_bounds__(256) void fsm_refsum_resolve(const RefSumArgs<T> a)
             ns.start = a.n_nodes;
         }
         ns.bits = refsum_bits<T>(v);
-        a.st[blockIdx.x] = ns;
+        if (v >= a.stop_at) ns.start = a.n_nodes;
+        a.st[fi] = ns;
     }
 }
 
