@@ -185,10 +185,15 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  2^24 nodes; an iteration that lands in the window without one is decided by the fp64 sum and counted
  *                  (ttcr_fsm_stopping_stats).  0: the fp64 sum alone.  2: as 1 with the sum as ONE chain of additions (the
  *                  round-4 kernel: 0.5 s per 512^3 field; kept as the checker of the parallel form).  tests/test_stopping_rule_gpu.py
- *   "slab"         1: first-order 3-D sweeps of fp32 grids with one field per slot and NF % 8 == 0 use the slab kernel
- *                  (fsm_slab_kernels.h: 64 x 8-column patches, one wavefront per 64 x 2 slab, no barrier in the level march;
- *                  bit-identical, slower at present, see profiles/r05/slab_kernel.txt); default off.  ("wave": the same option
- *                  under the name of the round-4 kernel it replaces)
+ *   "piped"        1: first-order 3-D sweeps of fp32 grids with one field per slot that evaluate every chunk (lone sources, small batches
+ *                  without exact skipping) use the pipelined kernel (fsm_piped_kernels.h: four march wavefronts + one staging wavefront
+ *                  per patch, two LDS tiles, 16-byte buffer accesses; bit-identical; 8.0 against 7.25 ms per sweep-iteration for a lone
+ *                  512^3 source at present, profiles/r05/piped_kernel.txt); default off.  env TTCR_FSM_PIPED.  tests/test_piped_kernel_gpu.py
+ *   "prefill"      a second set of traveltime fields: while a call that restarted every slot runs, a low-priority side stream fills the
+ *                  other set with max() (the reference's reinit, ttcr/Grid3Drnfs.h:92-94), and the next call that restarts every
+ *                  slot swaps the sets instead of writing n_slots x n_nodes values in front of its first sweep (512^3 x 64: 32 GB,
+ *                  6.8 ms).  Calls that restart some slots fill those in place.  1 on, 0 off, -1 (default): on when the fields take
+ *                  >= 64 MiB and twice that is at most half the device memory.  env TTCR_FSM_PREFILL.  tests/test_prefill_gpu.py
  *   "pair_sources" 1 (default): where the grid keeps its fields in pairs (n_slots x patches of a sweep > 6 144, env
  *                  TTCR_FSM_PAIR_UNITS; TTCR_FSM_PAIR = 1 / 0 forces / forbids the pair layout at grid creation) the sources
  *                  of a batch are paired by distance before they share a workgroup two by two
@@ -323,6 +328,9 @@ int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out);
 /* Decisions of the stopping rule since the grid was created: iterations decided by the reference's sequential sum, iterations
  * that landed in the window without a snapshot (decided by the fp64 sum), rounds of the parallel sum.  Any pointer may be NULL. */
 int ttcr_fsm_stopping_stats(const ttcr_fsm_grid* g, long long* reference_sums, long long* reference_sums_missed, long long* rounds);
+/* Calls (solve batches) that found their traveltime fields initialised by the side stream instead of filling them (option "prefill";
+ * the fill it replaces: `reinit` of every node, ttcr/Grid3Drnfs.h:92-94).  No reference equivalent: tests and bench.py read it. */
+int ttcr_fsm_prefill_swaps(const ttcr_fsm_grid* g, long long* swaps);
 /* The reference's `change` (ttcr/Grid3Drnfs.h:141-152) of two fields given on the host, n_nodes values of the grid's type each, node
  * order: the sum, in node order, in T1, of abs(times[n] - field[n]), into *out (a T1).  parallel != 0: the parallel form the solver
  * uses; 0: one chain of additions.  Both exact; tests compare them. */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""time of a batch of sources per sweep-iteration with the slab kernel (or not): python scripts/slab_time.py [n=512] [reps=4] [sources=1]
-(environment: TTCR_AMD_LIB, TTCR_FSM_SLAB, TTCR_FSM_SLAB_SHAPE, TTCR_FSM_SLAB_WGS, TTCR_FSM_PAIR)"""
+"""time of a batch of sources per sweep-iteration (two fixed iterations): python scripts/lone_time.py [n=512] [reps=4] [sources=1]
+(environment: TTCR_AMD_LIB, TTCR_FSM_SKIP, TTCR_FSM_PAIR, TTCR_FSM_WGS)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,5 @@ for _ in range(reps):
     g.raytrace(np.repeat(src, 1, axis=0), np.tile(rcv, (nsrc, 1)))
     ms = g.timing()["sweep_ms"] / 2
     best = ms if best is None else min(best, ms)
-print(f"n={n} sources={nsrc} lib={os.path.basename(os.environ.get('TTCR_AMD_LIB', 'libttcr_amd.so'))} slab={os.environ.get('TTCR_FSM_SLAB', 'auto')} "
-      f"shape={os.environ.get('TTCR_FSM_SLAB_SHAPE', '2x4')} wgs={os.environ.get('TTCR_FSM_SLAB_WGS', 'default')} pair={os.environ.get('TTCR_FSM_PAIR','default')} "
+print(f"n={n} sources={nsrc} lib={os.path.basename(os.environ.get('TTCR_AMD_LIB', 'libttcr_amd.so'))} skip={os.environ.get('TTCR_FSM_SKIP', 'auto')} pair={os.environ.get('TTCR_FSM_PAIR','default')} "
       f"[{g.last_kernel()}]: {best:.3f} ms per sweep-iteration ({104.0 * n ** 3 * nsrc / (best * 1e-3) / 8e12:.3f} of the roofline)", flush=True)

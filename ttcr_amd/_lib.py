@@ -55,6 +55,7 @@ SYMBOLS = {
     "ttcr_fsm_last_timing": (_I, [_P, C.POINTER(Timing)]),
     "ttcr_fsm_last_kernel": (_I, [_P, C.c_char_p, C.c_size_t]),
     "ttcr_fsm_stopping_stats": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "ttcr_fsm_prefill_swaps": (_I, [_P, C.POINTER(C.c_longlong)]),
     "ttcr_fsm_reference_change": (_I, [_P, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ttcr_fsm_rays_size": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ttcr_fsm_get_rays": (_I, [_P, _P, _P]),

@@ -5,9 +5,8 @@ solver must round a1 + s*dx (and every other product/sum pair) exactly like the 
 which a fused multiply-add would not (ttcr_amd/csrc/fsm_kernels.h header).
 
 Two translation units, compiled to objects under ttcr_amd/csrc/_obj and linked:
-  fsm_capi.hip   the C ABI, the host side and every kernel but one
-  fsm_slab.hip   the slab sweep kernel (fsm_slab_kernels.h), with the max-ILP machine scheduler: its level march holds
-                 independent node updates per lane, which the default scheduler leaves one after the other
+  fsm_capi.hip    the C ABI, the host side and every kernel but one
+  fsm_piped.hip   the pipelined sweep kernel (fsm_piped_kernels.h)
 """
 import os
 import shutil
@@ -20,8 +19,8 @@ LIB = os.path.join(HERE, "libttcr_amd.so")
 INC = os.path.join("..", "..", "include", "ttcr_amd.h")
 # source -> (extra flags, files it is compiled from)
 UNITS = {
-    "fsm_capi.hip": ([], ["fsm_capi.hip", "fsm_kernels.h", "fsm_slab_api.h", "fsm_march_levels.inc", INC]),
-    "fsm_slab.hip": (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["fsm_slab.hip", "fsm_slab_kernels.h", "fsm_slab_api.h", "fsm_kernels.h"]),
+    "fsm_capi.hip": ([], ["fsm_capi.hip", "fsm_kernels.h", "fsm_piped_api.h", "fsm_march_levels.inc", INC]),
+    "fsm_piped.hip": ([], ["fsm_piped.hip", "fsm_piped_kernels.h", "fsm_piped_api.h", "fsm_kernels.h"]),
 }
 SOURCES = list(UNITS)
 DEPS = sorted({d for _, ds in UNITS.values() for d in ds})

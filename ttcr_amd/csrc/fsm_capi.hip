@@ -25,7 +25,7 @@
 
 #include "../../include/ttcr_amd.h"
 #include "fsm_kernels.h"
-#include "fsm_slab_api.h"
+#include "fsm_piped_api.h"
 
 #ifndef FSM_CHUNK3
 #define FSM_CHUNK3 8
@@ -167,7 +167,13 @@ class GridBase {
     // in node order; parallel: the exact parallel form, else the one-chain kernel (tests compare the two)
     virtual void reference_change_host(const void* times, const void* field, bool parallel, void* out) = 0;
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
-    virtual void set_slab(int) {}   // option "slab" (GridT)
+    virtual long long prefill_swap_count() const { return 0; }   // calls that took fields initialised on the side stream (ttcr_fsm_prefill_swaps)
+    int piped = -1;     // option "piped" / TTCR_FSM_PIPED: the pipelined sweep kernel (fsm_piped_kernels.h) wherever it applies (first-order
+                        // 3-D sweeps of fp32 grids with one field per slot, whole-iteration launches, no exact skipping); 1 on, 0 off,
+                        // -1 (default): GridT::piped_now
+    int prefill = -1;   // option "prefill" / TTCR_FSM_PREFILL: a second set of traveltime fields, re-initialised on a side stream while a
+                        // solve runs, which the next call that restarts EVERY slot swaps in instead of filling (GridT::solve_batch);
+                        // 1 on, 0 off, -1 (default): on when the fields take at least 64 MiB and twice that is at most half the device memory
     // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
     // order stage then WENO stage
     std::vector<std::vector<double>> change_hist, change_histw;
@@ -202,8 +208,9 @@ class GridBase {
         else if (k == "interp_vel") interp_vel = value != 0;
         else if (k == "return_rays") return_rays = value != 0;
         else if (k == "pair_sources") pair_by_distance = value != 0;
-        else if (k == "slab" || k == "wave") set_slab((int)value);   // ("wave": the name of the round-4 kernel this one replaces)
         else if (k == "stopping_rule") stopping_rule = (int)value;
+        else if (k == "prefill") prefill = (int)value;
+        else if (k == "piped") piped = (int)value;
         else throw ValueError("unknown option '" + k + "'");
     }
     virtual void get_niter(int slot, int* it, int* itw) const {
@@ -248,6 +255,18 @@ class GridT : public GridBase {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf<T> d_s, d_cells, d_tt, d_rx, d_out;
+    // Re-initialisation off the path of a call (reinit, ttcr/Grid3Drnfs.h:92-94: T = max() everywhere -- 32 GB of stores for 64 fields
+    // of 512^3 nodes, 6.8 ms at the write bandwidth of the device).  d_tt_alt is a second set of fields: while a solve that restarted
+    // every slot runs in d_tt, a low-priority side stream fills d_tt_alt; the next call that restarts every slot swaps the two and
+    // finds its fields initialised.  A call that restarts only some slots fills them in place as before (the other slots keep their
+    // fields, as the reference's per-thread grids do).  Nothing outside the grid sees the swap except device views, which are valid
+    // "until the next raytrace call that solves a source for that slot" (include/ttcr_amd.h).
+    DevBuf<T> d_tt_alt;
+    bool alt_filled = false;        // a fill of d_tt_alt has been issued on fill_stream (ev_fill marks its end)
+    hipStream_t fill_stream = nullptr;
+    hipEvent_t ev_fill = nullptr;
+    long long prefill_swaps = 0;    // calls that found their fields initialised
+    long long prefill_swap_count() const override { return prefill_swaps; }
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // pair layout: slot groups from which the 3-D WENO stage uses chunks of 4 levels
@@ -267,7 +286,7 @@ class GridT : public GridBase {
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
     DevBuf<int> d_rstat;
     DevBuf<T> d_ssh;         // sheared copies of the node slowness, one per direction family
-    size_t ssh_stride = 0;   // elements per copy: NK * (M/2) * SR (3-D), NK * M * NJ (2-D)
+    size_t ssh_stride = 0;   // elements per copy: NK planes of shear_plane(geom) elements
     DevBuf<uint32_t> d_mask;
     DevBuf<int> d_bbox, d_slots, d_lmask;
     int* h_lmask = nullptr;  // pinned
@@ -279,14 +298,7 @@ class GridT : public GridBase {
     DevBuf<uint32_t> d_order;  // persistent kernel: patches in ticket order (anti-diagonal major)
     DevBuf<uint32_t> d_order_xs[2][2];  // whole-iteration launch, [stage: first order / WENO][0: sweep by sweep, 1: by expected start time]
     DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
-    // slab kernel (fsm_slab_kernels.h): first-order 3-D sweeps of fp32 grids that keep one field per slot, NF % 8 == 0
-    int slab = -1;             // option "slab" / TTCR_FSM_SLAB: 1 on wherever the kernel applies, 0 off, -1 (default): on for batches of fewer
-                               // than slab_below entries
-    int slab_below = 0;        // (0 until the kernel is validated on the GPU in this round)
-    int slab_pkr = 2, slab_nw = 4;   // rows per wavefront, wavefronts per workgroup (patch = 64 x pkr nw columns)
-    int slab_wgs = 0;          // workgroups of a launch (each takes units until none is left); 0: one per CU
-    int slab_npj = 0, slab_npk = 0, slab_patches = 0, slab_built_pkr = 0, slab_built_nw = 0;
-    DevBuf<uint32_t> d_order_slab[2];   // ticket order: [0] sweep by sweep, [1] by expected start time
+    size_t piped_lds = 40 * 1024;   // unused dynamic LDS of a workgroup of the pipelined kernel: two workgroups per CU (as for the four-wave kernel of a lone slot)
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
     DevBuf<int> d_stamp;       // dirty-brick stamps [n_slots][nbf*nbj*nbk]
@@ -420,9 +432,14 @@ class GridT : public GridBase {
         }
         geom.n_nodes = (uint32_t)n_nodes;
         geom.M = (std::max(geom.NF, geom.NJ) + 1) & ~1;
+        geom.MP = geom.M + FSM_XPAD;
         geom.SR = dim == 3 ? ((geom.NJ + 15) / 16) * 32 : 0;   // 2-D: plain rows (fsm_kernels.h, shear_index)
-        ssh_stride = geom.SR ? (size_t)geom.NK * (geom.M / 2) * geom.SR : (size_t)geom.NK * geom.M * geom.NJ;
+        ssh_stride = (size_t)geom.NK * shear_plane(geom);
+        // (the sweep kernels address a thread's plane of a copy with a 32-bit byte offset from the plane of its patch's first row)
+        if ((double)(dim == 3 ? 16 : 1) * (double)shear_plane(geom) * sizeof(T) >= 4294967296.0)
+            throw ValueError("grid too large for the slowness offsets of the sweep kernel (16 planes of max(nx, ny) x ny nodes must stay below 4 GiB)");
         d_ssh.reserve(ssh_stride * (dim == 3 ? 4 : 2));
+        HIP_CHECK(hipMemsetAsync(d_ssh.p, 0, ssh_stride * (dim == 3 ? 4 : 2) * sizeof(T), stream));   // (entries without a node are read, never used)
         if (dim == 3) build_tile_lists(TileCfg<T, 3>::PJ, TileCfg<T, 3>::PK, TileCfg<T, 3>::BL);
         else build_tile_lists(TileCfg<T, 2>::PJ, TileCfg<T, 2>::PK, TileCfg<T, 2>::BL);
         build_persistent_lists();
@@ -459,10 +476,9 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
-        if (const char* e = std::getenv("TTCR_FSM_SLAB")) slab = std::atoi(e);
-        if (const char* e = std::getenv("TTCR_FSM_SLAB_BELOW")) slab_below = std::atoi(e);   // tuning only
-        if (const char* e = std::getenv("TTCR_FSM_SLAB_SHAPE")) { if (std::sscanf(e, "%dx%d", &slab_pkr, &slab_nw) != 2) throw ValueError("TTCR_FSM_SLAB_SHAPE=<rows per wavefront>x<wavefronts per workgroup>"); }
-        if (const char* e = std::getenv("TTCR_FSM_SLAB_WGS")) slab_wgs = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_PREFILL")) prefill = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_PIPED")) piped = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_PIPED_LDS")) piped_lds = (size_t)std::atol(e);   // tuning only
     }
 
     // persistent kernel: ticket order = anti-diagonal m = TJ+TK major (a topological order of the
@@ -478,8 +494,6 @@ class GridT : public GridBase {
         // four ticket counters, the abort word, then one progress word per (direction, slot, patch).  The kernels tag every
         // word with the launch epoch: nothing is reset between the launches of a solve (fsm_kernels.h, "launch epoch")
         sync_words = 8 + (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4);
-        if (dim == 3)   // (the slab kernel, fsm_slab_kernels.h: patches of 64 x 8 columns at the least, one word per wavefront and one per patch)
-            sync_words = std::max(sync_words, 8 + (size_t)((geom.NJ + 63) / 64) * ((geom.NK + 7) / 8) * n_slots * 8 * 9);
         d_sync.reserve(sync_words);
         HIP_CHECK(hipMemset(d_sync.p, 0, sync_words * sizeof(int)));
         if (geom.npj >= (1 << 14) || geom.npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
@@ -639,6 +653,13 @@ class GridT : public GridBase {
             const dim3 gridx((unsigned)std::min<size_t>((size_t)n_patches * batch * ndir, wg_cap));
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             const bool pre = DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0;   // counters sampled one chunk ahead (template PRE)
+            if constexpr (std::is_same<T, float>::value && DIM == 3 && H == 1 && NSV == 1 && CH == 8 && C::PJ == 16 && C::PK == 16) {
+                if (piped_now(batch)) {
+                    last_kernel = "fsm_sweep_piped";
+                    HIP_CHECK(fsm_piped_launch(pa, gridx.x, piped_lds, stream, device));
+                    return;
+                }
+            }
             if (skip_now(batch) && pre)
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
             else if (skip_now(batch))
@@ -715,6 +736,8 @@ class GridT : public GridBase {
         if (h_evals) (void)hipHostFree(h_evals);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (fill_stream) { (void)hipStreamSynchronize(fill_stream); (void)hipStreamDestroy(fill_stream); }
+        if (ev_fill) (void)hipEventDestroy(ev_fill);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -756,7 +779,7 @@ class GridT : public GridBase {
         // J (2-D) not flipped; a direction and its opposite share one copy
         {
             const int nfam = dim == 3 ? 4 : 2;
-            const dim3 grid((geom.M + 15) / 16, (geom.NJ + 15) / 16, geom.NK);
+            const dim3 grid((geom.MP + 15) / 16, (geom.NJ + 15) / 16, geom.NK);
             const bool lines = grid.y <= 65535 && grid.z <= 65535 && !std::getenv("TTCR_FSM_SHEAR_SCATTER");
             const int blocks = (int)std::min<size_t>((n_nodes + 255) / 256, 8192);
             for (int f = 0; f < nfam; ++f) {
@@ -962,6 +985,22 @@ class GridT : public GridBase {
     int NS = 1;
     int n_groups() const { return (n_slots + NS - 1) / NS; }
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
+    // the pipelined kernel (fsm_piped_kernels.h): first-order sweeps of a 3-D fp32 grid with one field per slot, whole-iteration
+    // launches, every chunk evaluated, byte offsets of a field in 32 bits
+    bool piped_now(int batch) const {
+        if (sizeof(T) != 4 || dim != 3 || stage != 0 || NS != 1 || mode != 2 || piped == 0) return false;
+        if (skip_now(batch)) return false;
+        if (((unsigned long long)n_nodes + 64ull) * 4ull > 0xfff00000ull) return false;
+        return piped > 0;
+    }
+    bool prefill_on() const {
+        if (prefill >= 0) return prefill != 0;
+        const size_t bytes = n_nodes * (size_t)n_groups() * NS * sizeof(T);
+        if (bytes < ((size_t)64 << 20)) return false;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+        return d_tt_alt.p || (2 * bytes <= total_b / 2 && bytes + ((size_t)1 << 30) <= free_b);
+    }
 
     int stage = 0;  // 0: first-order sweeps, 1: WENO3 sweeps (persistent kernel only)
     // Exact skipping of chunks / units / sweeps that cannot change a node: on wherever it was measured to pay
@@ -1024,77 +1063,7 @@ class GridT : public GridBase {
         if (dim == 2 && rotated && !weno && dx == dz) launch_sweep45(batch);
     }
 
-    // ---- slab kernel (fsm_slab_kernels.h) ---------------------------------------------------------------------
-    void set_slab(int v) override { slab = v; }
-    // where it applies: first-order sweeps of a 3-D fp32 grid with one field per slot (a lone slot, grids with weno = 1, small batches,
-    // TTCR_FSM_PAIR=0), whole-iteration launches, NF a multiple of 8 (aligned pieces in both sweep directions), byte offsets of a
-    // field and of a sheared slowness copy in 32 bits
-    bool slab_now(int batch) const {
-        if (sizeof(T) != 4 || dim != 3 || stage != 0 || NS != 1 || mode != 2 || slab == 0) return false;
-        if (slab < 0 && batch >= slab_below) return false;
-        if (skip > 0) return false;                                  // (exact skipping asked for: the kernels that have it)
-        if (geom.NF % 8 != 0 || geom.NF < 16) return false;
-        if ((unsigned long long)n_nodes * 4ull > 0xfff00000ull || (unsigned long long)ssh_stride * 4ull > 0xfff00000ull) return false;
-        return true;
-    }
-    void build_slab_lists() {
-        if (slab_built_pkr == slab_pkr && slab_built_nw == slab_nw) return;
-        const int PJ = 64, PK = slab_pkr * slab_nw;
-        slab_npj = (geom.NJ + PJ - 1) / PJ;
-        slab_npk = (geom.NK + PK - 1) / PK;
-        slab_patches = slab_npj * slab_npk;
-        if (slab_npj >= (1 << 14) || slab_npk >= (1 << 14)) throw ValueError("grid too large for the patch index of the sweep kernel");
-        if (8 + (size_t)slab_patches * n_slots * 8 * (slab_nw + 1) > sync_words) throw std::logic_error("progress words of the slab kernel do not fit");
-        std::vector<uint32_t> order;
-        for (int m = 0; m <= slab_npj + slab_npk - 2; ++m)
-            for (int TK = std::max(0, m - slab_npj + 1); TK <= std::min(m, slab_npk - 1); ++TK) order.push_back((uint32_t)(m - TK) | ((uint32_t)TK << 16));
-        for (int tm = 0; tm < 2; ++tm) {
-            const std::vector<uint32_t> xs = xs_order_for(order, tm != 0, 1, PJ, PK, FSM_SLAB_C, slab_npj, slab_patches);
-            d_order_slab[tm].reserve(xs.size());
-            HIP_CHECK(hipMemcpy(d_order_slab[tm].p, xs.data(), xs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        }
-        slab_built_pkr = slab_pkr;
-        slab_built_nw = slab_nw;
-    }
-    void launch_sweeps_slab(int batch) {
-        if constexpr (sizeof(T) == 4) {
-            build_slab_lists();
-            SlabArgs sa;
-            sa.tt = (float*)d_tt.p;
-            sa.ssh = (const float*)d_ssh.p;
-            sa.ssh_stride = ssh_stride;
-            sa.frozen = d_mask.p;
-            sa.bbox = d_bbox.p;
-            sa.change = d_change.p;
-            sa.slots = d_slots.p;
-            sa.evals = d_evals.p;
-            sa.order = d_order_slab[batch < time_order_below ? 1 : 0].p;
-            sa.sync = d_sync.p;
-            sa.iter_ptr = d_iter.p;
-            sa.g = geom;
-            sa.npj = slab_npj;
-            sa.npk = slab_npk;
-            sa.n_patches = slab_patches;
-            sa.batch = batch;
-            sa.mask_words = (uint32_t)mask_words;
-            sa.dx = (float)dx;
-            sa.timeout_ticks = 1000000000ull;   // 10 s: a unit may wait for most of the previous sweep
-            sa.prof = d_prof.p;
-            const size_t units = (size_t)slab_patches * batch * 8;
-            last_kernel = "fsm_sweep_slab<" + std::to_string(slab_pkr) + "," + std::to_string(slab_nw) + ">";
-            if (!fsm_slab_shape_ok(slab_pkr, slab_nw)) throw ValueError("TTCR_FSM_SLAB_SHAPE: no such instantiation (2x4, 1x4, 2x2, 4x2)");
-            int cus = 0;
-            HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-            const size_t lds = fsm_slab_lds_bytes(slab_pkr, slab_nw);
-            const size_t per_cu = std::max<size_t>(1, (160 * 1024) / (lds + 2048));
-            const size_t cap = slab_wgs > 0 ? (size_t)slab_wgs : (size_t)std::max(cus, 1) * per_cu;
-            HIP_CHECK(fsm_slab_launch(slab_pkr, slab_nw, sa, (unsigned)std::min<size_t>(units, cap), stream, device));
-            HIP_CHECK(hipGetLastError());
-        }
-    }
-
     void issue_sweeps_axis(int batch) {
-        if (slab_now(batch)) { launch_sweeps_slab(batch); return; }
         if (stage == 1) {
             if (dim == 3) launch_sweeps_persistent<3, 2>(batch); else launch_sweeps_persistent<2, 2>(batch);
         } else if (mode >= 1) {
@@ -1323,6 +1292,18 @@ class GridT : public GridBase {
         // (re)started in this batch the group is one contiguous fill (full-line stores) instead of NS
         // strided passes.
         std::vector<char> group_filled(n_groups(), 0);
+        // every slot of the grid restarted by this batch: take the fields the side stream has initialised since the last such call
+        const bool all_slots = nb == n_slots && prefill_on();
+        if (all_slots && alt_filled) {
+            HIP_CHECK(hipStreamWaitEvent(stream, ev_fill, 0));
+            std::swap(d_tt.p, d_tt_alt.p);
+            std::swap(d_tt.n, d_tt_alt.n);
+            std::swap(d_tt.guard, d_tt_alt.guard);
+            alt_filled = false;
+            ++prefill_swaps;
+            graph_batches[0] = graph_batches[1] = -1;   // (captured launches hold the field pointer)
+            std::fill(group_filled.begin(), group_filled.end(), 1);
+        }
         if (NS > 1) {
             std::vector<int> cnt(n_groups(), 0);
             for (int b = 0; b < nb; ++b) cnt[slot_ids[b] / NS] += 1;
@@ -1470,6 +1451,26 @@ class GridT : public GridBase {
         stage = 0;
         sync_clean = true;
         HIP_CHECK(hipEventRecord(ev1, stream));
+        if (all_slots) {
+            // the other set of fields -- fresh, or the results of the call before this one, which nothing enqueued after the swap reads --
+            // is initialised for the next call BEHIND this call's sweeps (the event just recorded): beside them the fill took
+            // workgroup slots and bandwidth from the sweep kernel and was not done when the next call came (512^3 x 64 back to back:
+            // 191.8 ms per step instead of 185.7, profiles/r05/README.md); behind them it runs beside the receiver interpolation and
+            // whatever the caller does between two calls, and a call that comes at once waits for what is left of it
+            const size_t n_el = n_nodes * (size_t)n_groups() * NS;
+            if (!fill_stream) {
+                int lo = 0, hi = 0;
+                HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIP_CHECK(hipStreamCreateWithPriority(&fill_stream, hipStreamNonBlocking, lo));
+                HIP_CHECK(hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming));
+            }
+            d_tt_alt.reserve(n_el, 64);
+            HIP_CHECK(hipStreamWaitEvent(fill_stream, ev1, 0));
+            const int blocks = (int)std::min<size_t>((n_el + 255) / 256, 16384);
+            fsm_fill<T><<<blocks, 256, 0, fill_stream>>>(d_tt_alt.p, n_el, real_traits<T>::max(), 1);
+            HIP_CHECK(hipEventRecord(ev_fill, fill_stream));
+            alt_filled = true;
+        }
         HIP_CHECK(hipEventSynchronize(ev1));
         if (d_prof.p) {
             unsigned long long h[8];
@@ -2445,6 +2446,7 @@ class MultiGrid : public GridBase {
     void compute_slowness(int n, const void* pts, bool translated, void* out) override { rep[0]->compute_slowness(n, pts, translated, out); }
     void get_niter(int slot, int* it, int* itw) const override { int l; GridBase& g = of(slot, l); g.get_niter(l, it, itw); }
     std::string kernel_name() const override { return rep[0]->kernel_name(); }
+    long long prefill_swap_count() const override { long long a = 0; for (const auto& r : rep) a += r->prefill_swap_count(); return a; }
     void stopping_stats(long long* sums, long long* missed, long long* rounds) const override {
         long long a = 0, b = 0, c = 0;
         for (const auto& r : rep) { long long x = 0, y = 0, z = 0; r->stopping_stats(&x, &y, &z); a += x; b += y; c += z; }
@@ -3178,6 +3180,9 @@ int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out) {
 
 int ttcr_fsm_stopping_stats(const ttcr_fsm_grid* g, long long* reference_sums, long long* reference_sums_missed, long long* rounds) {
     return guarded_on(g, [&] { g->impl->stopping_stats(reference_sums, reference_sums_missed, rounds); });
+}
+int ttcr_fsm_prefill_swaps(const ttcr_fsm_grid* g, long long* swaps) {
+    return guarded_on(g, [&] { if (swaps) *swaps = g->impl->prefill_swap_count(); });
 }
 int ttcr_fsm_reference_change(ttcr_fsm_grid* g, const void* times, const void* field, int parallel, void* out) {
     return guarded_on(g, [&] {

@@ -236,26 +236,36 @@ struct SweepGeom {
     int NF, NJ, NK;        // node counts
     int npj, npk;          // patches along J and K
     int M;                 // shear modulus: max(NF, NJ) rounded up to an even number
+    int MP;                // rows of a k plane of a sheared copy: M + FSM_XPAD (the first FSM_XPAD rows once more behind the last one)
     int SR;                // sheared slowness copies: pitch of a PAIR of rows, ceil(NJ/16) blocks of 2 levels x 16 columns;
                            // 0: plain rows of NJ elements
     uint32_t n_nodes;      // NF*NJ*NK
 };
+constexpr int FSM_XPAD = 16;   // >= the longest chunk - 1: the rows of a chunk are read without a wrap
 
 // Sheared slowness.  A thread marches along F but a wavefront is laid out along J, so at a given
 // level the 64 lanes of a wave read nodes that are NF-1 elements apart in the natural layout.
-// set_slowness therefore keeps, per direction family, a copy indexed by (k', x = (i'+j') mod M, j')
-// (oriented indices) in which the nodes of one level and one k' are contiguous in j': the per-level slowness
+// set_slowness therefore keeps, per direction family, a copy indexed by (k, x = (i'+j'+k) mod M, j') -- i', j' oriented like the
+// family, k natural -- in which the nodes of one level and one k are contiguous in j': the per-level slowness
 // load of a wave is a coalesced row read straight into registers (no LDS staging, no transposition).
-// Element order: A[k'][x / 2][j' / 16][x % 2][j' % 16] -- one 128-byte line holds TWO consecutive levels of the 16
-// columns a patch row covers.  With plain rows A[k'][x][j'] the 64 bytes a patch row needs per level were half of a
+// x is the LEVEL of the node modulo M (round 5; until then (i'+j') mod M): at one level every thread of a workgroup reads row
+// x = L mod M of its k plane, so the row part of a load address is a scalar -- the sweep kernels compute it once per level on
+// the scalar unit and a load is one instruction (uniform base + per-thread 32-bit offset), where each of the C loads of a chunk
+// used to cost ~20 vector instructions of walking x with its wrap and its in-range test (issue_static).  Rows M .. M+FSM_XPAD-1
+// repeat rows 0 .. FSM_XPAD-1: the C consecutive rows of a chunk never wrap.
+// Element order: A[k][x / 2][j' / 16][x % 2][j' % 16] -- one 128-byte line holds TWO consecutive levels of the 16
+// columns a patch row covers.  With plain rows A[k][x][j'] the 64 bytes a patch row needs per level were half of a
 // line whose other half belongs to the neighbouring patch (another workgroup, another time): every line was fetched
 // twice.  Now the second half is the same lanes' next level, a fraction of a microsecond later.
 // A direction and its opposite traverse the same array backwards, so 4 (3-D) / 2 (2-D) copies.
 // (3-D grids.  The 64-column rows of the one-wave 2-D patches fill whole lines as plain rows A[x][j'] and are 3 % slower
 // with the paired form -- four half lines per load instead of two full ones --, so 2-D grids keep plain rows: SR == 0.)
+__host__ __device__ __forceinline__ size_t shear_plane(const SweepGeom& g) {   // elements of a k plane
+    return g.SR == 0 ? (size_t)g.MP * (size_t)g.NJ : (size_t)(g.MP >> 1) * (size_t)g.SR;
+}
 __host__ __device__ __forceinline__ size_t shear_index(const SweepGeom& g, int kx, int x, int jx) {
-    if (g.SR == 0) return ((size_t)kx * (size_t)g.M + (size_t)x) * (size_t)g.NJ + (size_t)jx;
-    return ((size_t)kx * (size_t)(g.M >> 1) + (size_t)(x >> 1)) * (size_t)g.SR + (size_t)((jx >> 4) * 32 + (x & 1) * 16 + (jx & 15));
+    if (g.SR == 0) return ((size_t)kx * (size_t)g.MP + (size_t)x) * (size_t)g.NJ + (size_t)jx;
+    return ((size_t)kx * (size_t)(g.MP >> 1) + (size_t)(x >> 1)) * (size_t)g.SR + (size_t)((jx >> 4) * 32 + (x & 1) * 16 + (jx & 15));
 }
 template <typename T>
 __global__ void fsm_shear_slowness(const T* __restrict__ s, T* __restrict__ out, SweepGeom g, int rf, int rj) {
@@ -263,27 +273,27 @@ __global__ void fsm_shear_slowness(const T* __restrict__ s, T* __restrict__ out,
     for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < N; n += (size_t)gridDim.x * blockDim.x) {
         const int i = n % g.NF, j = (n / g.NF) % g.NJ, k = n / ((size_t)g.NF * g.NJ);
         const int ip = rf ? g.NF - 1 - i : i, jp = rj ? g.NJ - 1 - j : j;
-        int x = ip + jp;
-        x = x >= g.M ? x - g.M : x;
-        out[shear_index(g, k, x, jp)] = s[n];
+        const int x = (ip + jp + k) % g.M;
+        for (int xr = x; xr < g.MP; xr += g.M) out[shear_index(g, k, xr, jp)] = s[n];   // (rows M and above: the first rows again)
     }
 }
 
-// The same copy written a line at a time: a workgroup produces 16 consecutive x of one 16-column block of one k' plane,
+// The same copy written a line at a time: a workgroup produces 16 consecutive x of one 16-column block of one k plane,
 // lanes ordered (x, j') like the copy itself, so that a wavefront stores whole 128-byte lines (fsm_shear_slowness above walks
 // the natural array and scatters 4-byte stores over as many lines: the fabric counted 8x the payload in write requests,
 // profiles/r02/traffic.json).  The loads walk 16 rows of the natural array along an anti-diagonal band -- a compact region
-// that stays in the caches across the workgroup.
+// that stays in the caches across the workgroup.  (Rows M and above: the copies of rows 0 ..)
 template <typename T>
 __global__ __launch_bounds__(256) void fsm_shear_slowness_lines(const T* __restrict__ s, T* __restrict__ out, SweepGeom g, int rf, int rj) {
     const int jj = threadIdx.x & 15, xx = threadIdx.x >> 4;
-    const int x = blockIdx.x * 16 + xx, jp = blockIdx.y * 16 + jj, k = blockIdx.z;
-    if (x >= g.M || jp >= g.NJ) return;
-    int ip = x - jp;
+    const int xrow = blockIdx.x * 16 + xx, jp = blockIdx.y * 16 + jj, k = blockIdx.z;
+    if (xrow >= g.MP || jp >= g.NJ) return;
+    const int x = xrow % g.M;
+    int ip = (x - jp - k) % g.M;
     ip = ip < 0 ? ip + g.M : ip;
-    if (ip >= g.NF) return;   // (no node with this i' + j': the entry is never read)
+    if (ip >= g.NF) return;   // (no node at this level in this column: the entry is read -- rows are loaded whole -- and never used)
     const int i = rf ? g.NF - 1 - ip : ip, j = rj ? g.NJ - 1 - jp : jp;
-    out[shear_index(g, k, x, jp)] = s[((size_t)k * g.NJ + j) * g.NF + i];
+    out[shear_index(g, k, xrow, jp)] = s[((size_t)k * g.NJ + j) * g.NF + i];
 }
 
 template <typename T>
@@ -376,9 +386,9 @@ __global__ __launch_bounds__(PJ* PK) void fsm_sweep_tile(const SweepArgs<T> a) {
         const int kx = a.rev ? NK - 1 - kp : kp;
 #pragma unroll
         for (int q = 1; q <= BL; ++q) {
-            int x = L0 - 1 + q - kp;  // i' + j' at this level
-            x = a.rev ? NF + NJ - 2 - x : x;
-            x = x >= M ? x - M : x;
+            int x = L0 - 1 + q;  // the level: i' + j' + k' (oriented like this sweep)
+            x = (a.rev ? NF + NJ + NK - 3 - x : x) % M;   // ... like the family of the copy
+            x = x < 0 ? x + M : x;
             T v = 0;
             if (q >= qa && q <= qb) v = Sg[shear_index(a.g, kx, x, jx)];
             sv[q - 1] = v;
@@ -897,6 +907,7 @@ __device__ __forceinline__ void st_sc1(Pack<double, 2>* p, Pack<double, 2> x) {
 // Which instantiations keep their workgroups for more than one unit: the first-order 3-D kernels (see fsm_sweep_persistent).
 __host__ __device__ constexpr bool fsm_looped(bool is3d, int h) { return is3d && h == 1; }
 
+__device__ __forceinline__ int kmaxp_of(int k0, int NK, int PK) { return (k0 + PK < NK ? k0 + PK : NK) - 1; }
 // One work unit: the body of fsm_sweep_persistent below.  Returns false when the tickets of the launch have run out.
 template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE>
 __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
@@ -915,6 +926,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     constexpr int NHI = (NDH + RPI - 1) / RPI;   // passes over the downwind halo columns
     constexpr int NUPI = (NUP + RPI - 1) / RPI;  // passes over the upwind halo columns
     static_assert(NT % C == 0 && (IS3D || PK == 1) && C <= FSM_BRICK && (H == 1 || H == 2), "tile shape");
+    static_assert(C - 1 <= FSM_XPAD, "the rows of a chunk are read from the sheared copies without a wrap");
     // (the early publish would let a unit's final progress value go out before its brick stamps: round-3 advice)
     static_assert(!(SKIP && FSM_EARLY_PUB > 0), "FSM_EARLY_PUB is a tuning option of the kernels without exact skipping");
     const SweepArgs<T>& a = pa.s;
@@ -1174,7 +1186,16 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     const uint32_t* __restrict__ Fz = a.frozen + (size_t)grp * NS * a.mask_words;   // + l * mask_words
     const int* bb = a.bbox + 6 * grp * NS;                                           // + 6 * l
     const int M = a.g.M;
-    const size_t sbase = shear_index(a.g, rev ? NK - 1 - kp : kp, 0, rev ? NJ - 1 - jp : jp);   // + the (x) part, see issue_static
+    // sheared slowness copy: uniform base of the unit (the k plane of its first row in the copy's orientation) + this thread's
+    // byte offset inside it (32 bits: the host refuses grids whose planes are too far apart) + the row of the level, a scalar
+    // (issue_static).  Threads without a column read the nearest one (their values are never used).
+    const int skx_min = rev ? NK - 1 - kmaxp_of(k0, NK, PK) : k0;
+    uint32_t stoff;
+    {
+        int kc = kp < NK ? kp : NK - 1, jc = jp < NJ ? jp : NJ - 1;
+        const int kx = rev ? NK - 1 - kc : kc, jx = rev ? NJ - 1 - jc : jc;
+        stoff = (uint32_t)(((size_t)(kx - skx_min) * shear_plane(a.g) + (IS3D ? (size_t)((jx >> 4) * 32 + (jx & 15)) : (size_t)jx)) * sizeof(T));
+    }
 
     // LDS row (without the level) of the column at patch-relative (cj, ck), halo included
     auto lds_row = [&](int cj, int ck) { return (IS3D ? (ck + H) * RJ + cj + H : cj + H) * RS; };
@@ -1276,42 +1297,52 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
     P tv[NOWN + NHI];
     int xs_next = 0, xs_level = -(1 << 30);
     auto issue_static = [&](int L) {
-        const int eoff = jp + kp - L;  // e at which i' == 0
-        const int ea = col_ok ? (eoff > 0 ? eoff : 0) : C;
-        const int eb = eoff + NF - 1 < C - 1 ? eoff + NF - 1 : C - 1;
-        // position in the sheared copy, (i' + j') mod M (backwards for the opposite direction).  Consecutive
-        // chunks continue the walk where the previous call stopped; only a fresh start pays the modulo.
+        // row of the sheared copy at level L: x = L mod M in the orientation of the copy's family (the opposite direction walks it
+        // backwards) -- the same for every thread of the workgroup, so all of this is scalar arithmetic.  Consecutive chunks
+        // continue the walk where the previous call stopped; only a fresh start pays the modulo.  The C rows of the chunk are read
+        // upwards from the lowest one, through the repeated rows behind row M - 1 where they would wrap.
         int x;
         if (L == xs_level) {
             x = xs_next;
         } else {
-            x = L - kp;  // i' + j' at level L
-            x = rev ? NF + NJ - 2 - x : x;
-            x %= M;  // levels before the column starts give x < 0; keep the walk inside [0, M)
+            x = (rev ? NF + NJ + NK - 3 - L : L) % M;   // levels before the column starts give x < 0; keep the walk inside [0, M)
             x = x < 0 ? x + M : x;
         }
-        // walk x by +-1 modulo M without a branch or a multiply per element: xo = offset of (x) in the copy alongside
-        // (rows come in pairs: even x -> (x/2) SR, odd x -> (x/2) SR + 16)
-        const T* __restrict__ Sp = Sg + sbase;
-        const int step = rev ? -1 : 1, x_edge = rev ? -1 : M, x_reset = rev ? M - 1 : 0;
-        const uint32_t SR = (uint32_t)a.g.SR;
+        x = __builtin_amdgcn_readfirstlane(x);
+        int xlo = rev ? x - (C - 1) : x;
+        if (xlo < 0) { xlo %= M; xlo = xlo < 0 ? xlo + M : xlo; }   // (M may be smaller than a chunk)
+        // sv[] holds the rows in ascending order (the march reads it backwards for a walk that goes down the copy).  A load is one
+        // instruction: the row pointer stays on the scalar side (the empty asm keeps the compiler from folding it into the thread's
+        // 64-bit address again), the thread's part is a 32-bit register offset, the half of a row pair an immediate
         constexpr bool paired = IS3D;   // (the host sets SR accordingly: 3-D paired rows, 2-D plain rows)
-        const uint32_t xo_reset = !rev ? 0u : (paired ? (uint32_t)((M >> 1) - 1) * SR + 16u : (uint32_t)(M - 1) * (uint32_t)NJ);
-        // paired rows, step +1: even -> odd +16, odd -> even +(SR-16);  step -1: odd -> even -16, even -> odd -(SR-16)
-        const uint32_t d_even = paired ? (rev ? 0u - (SR - 16u) : 16u) : (uint32_t)(step * NJ);
-        const uint32_t d_odd = paired ? (rev ? 0u - 16u : SR - 16u) : (uint32_t)(step * NJ);
-        uint32_t xo = paired ? (uint32_t)(x >> 1) * SR + (uint32_t)(x & 1) * 16u : (uint32_t)x * (uint32_t)NJ;
+        const uint32_t SRB = (paired ? (uint32_t)a.g.SR : (uint32_t)NJ) * (uint32_t)sizeof(T);   // bytes from a row (pair) to the next
+        const char* rowp = reinterpret_cast<const char*>(Sg + (size_t)skx_min * shear_plane(a.g)) + (size_t)(paired ? (uint32_t)xlo >> 1 : (uint32_t)xlo) * SRB;
+        auto ld_row = [&](int half) -> T {
+            asm volatile("" : "+s"(rowp));
+            return *reinterpret_cast<const T*>(rowp + half * 16 * (int)sizeof(T) + stoff);
+        };
+        if constexpr (paired) {
+            if ((xlo & 1) == 0) {
 #pragma unroll
-        for (int q = 0; q < C; ++q) {
-            T v = 0;
-            if (q >= ea && q <= eb) v = Sp[xo];
-            sv[q] = v;
-            const uint32_t dx_ = (paired && (x & 1)) ? d_odd : d_even;
-            x += step;
-            const bool wrap = x == x_edge;
-            x = wrap ? x_reset : x;
-            xo = wrap ? xo_reset : xo + dx_;
+                for (int q = 0; q < C; ++q) {
+                    sv[q] = ld_row(q & 1);
+                    if (q & 1) rowp += SRB;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < C; ++q) {
+                    if (!(q & 1)) { sv[q] = ld_row(1); rowp += SRB; } else sv[q] = ld_row(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                sv[q] = ld_row(0);
+                rowp += SRB;
+            }
         }
+        x = rev ? x - C : x + C;
+        if (x < 0 || x >= M) { x %= M; x = x < 0 ? x + M : x; }
         xs_next = x;
         xs_level = L + C;
         const int sL = sf * L;
@@ -1718,7 +1749,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
         for (int q = 2 * H; q < NQ; ++q) own[q] = Tt[row * RS + q];
         T sc[C];
 #pragma unroll
-        for (int q = 0; q < C; ++q) sc[q] = sv[q];
+        for (int q = 0; q < C; ++q) sc[q] = rev ? sv[C - 1 - q] : sv[q];   // (issue_static: rows in ascending order)
         FSM_PMARK(2)
 
         // (4) prefetch the next chunk's static inputs; they land during the march

@@ -160,6 +160,12 @@ class _GridBase:
         _lib.check(self._lib.ttcr_fsm_stopping_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"reference_sums": a.value, "reference_sums_missed": b.value, "rounds": c.value}
 
+    def prefill_swaps(self):
+        """Calls that took traveltime fields initialised on the side stream (option "prefill", ttcr_fsm_prefill_swaps)."""
+        a = C.c_longlong(0)
+        _lib.check(self._lib.ttcr_fsm_prefill_swaps(self._h, C.byref(a)))
+        return a.value
+
     def reference_change(self, times, field, parallel=True):
         """The reference's `change` of two fields (ttcr/Grid3Drnfs.h:141-152): the sequential sum, in node order and in the grid's
         precision, of abs(times[n] - field[n]).  Flat arrays of get_number_of_nodes() values in node order."""
