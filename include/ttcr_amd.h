@@ -186,8 +186,8 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  (ttcr_fsm_stopping_stats).  0: the fp64 sum alone.  2: as 1 with the sum as ONE chain of additions (the
  *                  round-4 kernel: 0.5 s per 512^3 field; kept as the checker of the parallel form).  tests/test_stopping_rule_gpu.py
  *   "piped"        1: first-order 3-D sweeps of fp32 grids with one field per slot that evaluate every chunk (lone sources, small batches
- *                  without exact skipping) use the pipelined kernel (fsm_piped_kernels.h: four march wavefronts + one staging wavefront
- *                  per patch, two LDS tiles, 16-byte buffer accesses; bit-identical; 8.0 against 7.25 ms per sweep-iteration for a lone
+ *                  without exact skipping) use the pipelined kernel (fsm_piped_kernels.h: four march wavefronts + two staging wavefronts
+ *                  per patch, two LDS tiles, 16-byte buffer accesses; bit-identical; 7.9-8.0 against 7.2 ms per sweep-iteration for a lone
  *                  512^3 source at present, profiles/r05/piped_kernel.txt); default off.  env TTCR_FSM_PIPED.  tests/test_piped_kernel_gpu.py
  *   "prefill"      a second set of traveltime fields: while a call that restarted every slot runs, a low-priority side stream fills the
  *                  other set with max() (the reference's reinit, ttcr/Grid3Drnfs.h:92-94), and the next call that restarts every

@@ -1,4 +1,4 @@
-"""Pipelined sweep kernel (ttcr_amd/csrc/fsm_piped_kernels.h, option "piped" = 1: four march wavefronts + one staging wavefront per
+"""Pipelined sweep kernel (ttcr_amd/csrc/fsm_piped_kernels.h, option "piped" = 1: four march wavefronts + two staging wavefronts per
 patch, two LDS tiles): bit-identical to the default kernel -- fields, iteration counts, change history.
 Reference semantics: Grid3Drn::sweep / update_node, ttcr/Grid3Drn.h:2816-2959 (the default kernel is pinned to the oracle by
 test_parity_gpu.py)."""

@@ -10,9 +10,11 @@ import cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dt,weno", [(np.float32, 0), (np.float32, 1), (np.float64, 0)])
-def test_prefill_swaps_fields_and_keeps_results(oracle, dt, weno):
+@pytest.mark.parametrize("dt,weno,pair", [(np.float32, 0, 0), (np.float32, 0, 1), (np.float32, 1, 0), (np.float64, 0, 0)])
+def test_prefill_swaps_fields_and_keeps_results(oracle, dt, weno, pair, monkeypatch):
     import ttcr_amd
+
+    if pair: monkeypatch.setenv("TTCR_FSM_PAIR", "1")   # (fields of two slots interleaved: the layout of the big batches)
 
     n, dx, S = 33, 0.4, 4
     x = np.arange(n) * dx

@@ -1308,7 +1308,7 @@ class GridT : public GridBase {
             std::vector<int> cnt(n_groups(), 0);
             for (int b = 0; b < nb; ++b) cnt[slot_ids[b] / NS] += 1;
             for (int gi = 0; gi < n_groups(); ++gi) {
-                if (cnt[gi] != NS) continue;
+                if (cnt[gi] != NS || group_filled[gi]) continue;   // (group_filled: the fields came initialised from the side stream)
                 const size_t n_el = n_nodes * (size_t)NS;
                 const int blocks = (int)std::min<size_t>((n_el + 255) / 256, 16384);
                 fsm_fill<T><<<blocks, 256, 0, stream>>>(d_tt.p + (size_t)gi * n_el, n_el, real_traits<T>::max(), 1);
@@ -1742,7 +1742,11 @@ class GridT : public GridBase {
         // tests/test_parity_gpu.py).  The limit only turns a walk that would never end into an error.
         const long max_steps = walk_step_limit;
         const long cap = std::min<long>(max_steps, 8L * ((long)ncx + ncy + ncz + 3)) + 3;   // Rx, one point per step, <= two per source point
-        const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, rays_buffer_bytes / (sizeof(T) * nc * cap)));
+        // (the recording rows of a launch: at most rays_buffer_bytes, and at most a quarter of what the device has free -- a replica that is
+        // full of slots, or a smaller device, records in more launches instead of failing its allocation)
+        size_t rays_budget = rays_buffer_bytes, free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) rays_budget = std::min(rays_budget, std::max<size_t>(free_b / 4, (size_t)64 << 20));
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, rays_budget / (sizeof(T) * nc * cap)));
         auto launch = [&](size_t row0, int m, T* pts, long rcap) {   // rows [row0, row0 + m) of the batch
             const dim3 rgrid((unsigned)((m + 63) / 64)), rblock(64);
             if (dim == 3)

@@ -2518,24 +2518,42 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
         sd[tid] = s;
     }
     __syncthreads();
+    // (everything thread 0 walks below sits in LDS by then: a walk over values it had to fetch itself was a chain of memory round trips,
+    // 60-100 us per round, 2-6 ms per sum of a 512^3 field; profiles/r05/README.md)
+    __shared__ int s_range;
     if (tid == 0) {
         unsigned long long S = S0;
-        int found = 0;
-        unsigned long long t = 0;
-        for (int c = 0; c < 256 && !found; ++c) {
-            if (S + sd[c].r[S & 1ull] >= LIMIT) {   // in this range: its tiles one by one
-                for (t = (unsigned long long)c * per; t < ((unsigned long long)c + 1) * per && t < n_tiles; ++t) {
-                    const RefSum4 q = tiles[t];
-                    if (S + q.r[S & 1ull] >= LIMIT) { found = 1; break; }
-                    S += q.d[S & 1ull];
-                }
-            } else {
-                S += sd[c].d[S & 1ull];
-            }
+        int c = 0;
+        for (; c < 256; ++c) {
+            if (S + sd[c].r[S & 1ull] >= LIMIT) break;   // in this range
+            S += sd[c].d[S & 1ull];
         }
-        s_S = S; s_tile = t; s_found = found;
+        s_S = S; s_range = c; s_found = c < 256;
     }
     __syncthreads();
+    if (s_found) {   // the tiles of that range, one by one
+        const unsigned long long t0 = (unsigned long long)s_range * per;
+        __syncthreads();
+        for (unsigned long long q = tid; q < per; q += 256) {
+            // (per <= WMAX / TILE / 256 = 32 tiles: one pass)
+            if (q < 256) sd[q] = t0 + q < n_tiles ? tiles[t0 + q] : RefSum4{{0ull, 0ull}, {0ull, 0ull}};
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long S = s_S, t = t0;
+            int found = 0;
+            for (unsigned long long q = 0; q < per && q < 256 && t0 + q < n_tiles; ++q) {
+                t = t0 + q;
+                if (S + sd[q].r[S & 1ull] >= LIMIT) { found = 1; break; }
+                S += sd[q].d[S & 1ull];
+            }
+            // (found == 0 cannot happen -- the summary of the range said so; the walk then stands at the end of the range with the
+            // exact state: go on from the next tile, or the window is over)
+            if (!found) { t = t0 + per; found = t < n_tiles; }
+            s_S = S; s_tile = t; s_found = found;
+        }
+        __syncthreads();
+    }
     if (!s_found) {   // the whole window in this binade
         if (tid == 0) {
             RefSumState ns;
@@ -2560,12 +2578,24 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
             if (S + sd[c].r[S & 1ull] >= LIMIT) break;
             S += sd[c].d[S & 1ull];
         }
+        s_S = S; s_range = c;
+    }
+    __syncthreads();
+    __shared__ T s_x[FSM_REFSUM_PER + 1];
+    {
+        const unsigned long long q0 = tbase + (unsigned long long)s_range * FSM_REFSUM_PER;
+        if (tid <= FSM_REFSUM_PER) s_x[tid] = q0 + tid < a.n_nodes ? refsum_x(f, q0 + tid) : (T)0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long S = s_S;
+        const int c = s_range;
         unsigned long long q = tbase + (unsigned long long)c * FSM_REFSUM_PER;
-        const unsigned long long qend = q + FSM_REFSUM_PER;
+        const unsigned long long q0 = q, qend = q + FSM_REFSUM_PER;
         for (; q < qend && q < a.n_nodes; ++q) {
             unsigned long long nn;
             int cls;
-            refsum_element<T>(refsum_x(f, q), k, nn, cls);
+            refsum_element<T>(s_x[q - q0], k, nn, cls);
             if (S + nn + (cls ? 1ull : 0ull) >= LIMIT) break;
             S += refsum_incr(nn, cls, (unsigned)S & 1u);
         }
@@ -2576,7 +2606,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
         ns.window = st.window;
         ns.prev_q = st.prev_q;
         if (q < a.n_nodes) {
-            v = v + refsum_x(f, q);   // the reference's own addition (ttcr/Grid3Drnfs.h:147)
+            v = v + s_x[q - q0];   // the reference's own addition (ttcr/Grid3Drnfs.h:147)
             ns.start = q + 1ull;
             // the sum left its binade here (or nearly): the next such place is about as far again; whole tiles (a tile is summarised to its end)
             unsigned long long w = 2ull * (q + 1ull - st.prev_q);

@@ -1,6 +1,6 @@
 // ttcr_amd/csrc/fsm_piped_kernels.h -- first-order 3-D sweeps of fp32 grids (one field per slot) with the staging OFF the march:
 // a workgroup is four MARCH wavefronts (the 16 x 16 columns of a patch, one column per lane, exactly the level march of
-// fsm_sweep_persistent) and one STAGING wavefront that moves everything between HBM and the LDS tile -- the not-yet-swept
+// fsm_sweep_persistent) and two STAGING wavefronts that move everything between HBM and the LDS tile -- the not-yet-swept
 // values of the next chunk, its upwind halo, the write-back of the previous chunk, the progress word, the polls.
 //
 // What it computes: Grid3Drn::sweep + update_node (ttcr/Grid3Drn.h:2816-2959) -- the same partial order (level L = i' + j' + k'
@@ -9,19 +9,25 @@
 // patches of the previous sweep) as fsm_sweep_persistent<float,16,16,8,true,false,1,1,true,...>: any linear extension of the
 // sweep's partial order gives the serial Gauss-Seidel result bit for bit.
 //
-// Why (profiles/r05/lone_source_chunk_ramp.txt, DESIGN.md 8e): on the critical path of a lone source a chunk of the four-wave
+// Why (profiles/r05/lone_source_chunk_ramp.txt, DESIGN.md 4c, 8e): on the critical path of a lone source a chunk of the four-wave
 // kernel takes 4.5 us of which 2.9 us are the march: between two marches every wavefront waits for the upwind progress word
 // (poll round trip 0.5-0.8 us), stages (LDS writes of the prefetched values, upwind halo loads and their latency, barrier: 0.6-0.8 us)
 // and writes back (0.3 us), and the progress of a chunk only goes out behind the NEXT chunk's wait and staging (1.2 us after its
 // march).  A hop of the patch wavefront is three such chunks: 13.7-15 us where 16 levels of march are 5.8 us.  Here two tiles
-// alternate: while the march wavefronts work on tile b, the staging wavefront writes back tile b^1 (the chunk before), publishes
-// it, polls for the chunk after, loads it and fills tile b^1 -- between two marches only the carry of the own columns (two LDS
+// alternate: while the march wavefronts work on tile b, the staging wavefronts write back tile b^1 (the chunk before), publish
+// it, poll for the chunk after, load it and fill tile b^1 -- between two marches only the carry of the own columns (two LDS
 // writes), one barrier and the reload of the column registers are left.
 //
-// Synchronisation inside the workgroup: s_barrier counts every wavefront of the workgroup, so the staging wavefront takes part in
-// the barrier of every level: per chunk all five wavefronts pass exactly FSM_PIPED_BARRIERS barriers, and the staging work is cut
-// into the phases between them (none of which waits for memory that was requested in the same phase, except where the march
-// would have to wait anyway: the upwind patch is behind).
+// Synchronisation inside the workgroup: s_barrier counts every wavefront of the workgroup, so the staging wavefronts take part in
+// the barrier of every level: per chunk all six wavefronts pass exactly nine barriers, and the staging work is cut into the phases
+// between them (none of which should wait for memory that was requested in the same or the previous phases, except where the
+// march would have to wait anyway: the upwind patch is behind).
+//
+// Where it stands (profiles/r05/piped_kernel.txt): bit-identical, 7.9-8.0 ms per sweep-iteration for the lone 512^3 source against
+// 7.2 ms of the four-wave kernel -- opt-in (option "piped").  What keeps it there: a staging wavefront is ONE instruction stream
+// (6-8 cycles per instruction), the compiler waits for ALL outstanding accesses (vmcnt(0)) wherever a loaded value is used behind a
+// branch, and the write-through stores of the write-back take ~1 us to be acknowledged: a poll of the upwind progress two levels
+// behind the stores sits out their acknowledgement, and the march wavefronts sit at the level's barrier with it.
 #pragma once
 #include "fsm_kernels.h"
 
@@ -50,8 +56,11 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
     constexpr int RJ = PJ + 2, NROWS = RJ * (PK + 2), NQ = C + 2, RS = NQ | 1;
     constexpr int NSTAT = NM + PJ + PK;         // columns with not-yet-swept values: own + downwind halo
     constexpr int NPIECE = 2 * NSTAT;           // pieces of four levels
-    constexpr int NPASS = (NPIECE + 63) / 64;   // passes of the staging wavefront over them (9)
-    constexpr int NWB = 2 * NM / 64;            // write-back passes (8): the pieces of the own columns one level lower
+    constexpr int NSW = 2;                      // staging wavefronts: lanes 0 .. 127, half of the pieces each
+    constexpr int NOWNP = 2 * NM / (64 * NSW);  // passes of a staging lane over the pieces of the own columns (4)
+    constexpr int NPASS = NOWNP + 1;            // ... + one over the downwind halo (first staging wavefront) (5)
+    constexpr int NWB = NOWNP;                  // write-back passes (4): the pieces of the own columns one level lower
+    static_assert(NPIECE <= 64 * (NSW * NOWNP + 1), "pieces fit the passes");
     const SweepArgs<T>& a = pa.s;
     const unsigned epoch = (unsigned)pa.iter_ptr[1];
     const int e2 = (int)(epoch % 3u) + 1;
@@ -63,7 +72,8 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
 
     __shared__ float Tt[2][NROWS * RS];
     __shared__ int s_ticket, s_abort;
-    __shared__ int s_chg[2];    // tile b: some node of its chunk was accepted (set by the march wavefronts, read and cleared by the staging one)
+    __shared__ int s_chg[2];    // tile b: some node of its chunk was accepted (set by the march wavefronts, read and cleared by the staging ones)
+    __shared__ int s_pubcnt;    // staging wavefronts whose write-back stores of the chunk to publish have drained (the last one publishes)
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // (nothing derived from it is carried from unit to unit, see fsm_sweep_persistent)
@@ -76,7 +86,7 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
         const int t_ = atomicAdd(pa.sync + (epoch & 3u), 1);
         if (t_ == 0) __hip_atomic_store(pa.sync + ((epoch + 2u) & 3u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_ticket = t_;
-        s_chg[0] = 0; s_chg[1] = 0;
+        s_chg[0] = 0; s_chg[1] = 0; s_pubcnt = 0;
     }
     if (tid == NM + 1) s_abort = __hip_atomic_load(pa.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -136,6 +146,9 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
         }
     }
 
+    // (the wavefronts that did not poll: nothing of this unit is read from the field before the previous sweep is done with its columns)
+    if (!(FSM_PIPED_EXP & 1) && dir > 0) __syncthreads();
+
     // =====================================================================================================================
     if (stager) {
         // ---- the staging wavefront ----------------------------------------------------------------------------------------
@@ -146,37 +159,38 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
         // piece p = lane + 64 it of a chunk that starts at level L0: column c = p / 2 (own columns first, then the downwind halo), levels
         // L0 + 1 + 4 (p % 2) + t, t = 0 .. 3  <->  tile q = 2 + 4 (p % 2) + t;  i' = level - j' - k'.  Own columns (it < 8): the lane
         // keeps its j' and walks k' in steps of two, so everything about a piece is affine in `it` (three registers, not 3 x 9)
+        constexpr int KS = 2 * NSW;   // k' step of a lane from pass to pass (the 128 lanes cover 4 rows of 16 columns x 2 halves)
+        const int sw = sl >> 6, sll = sl & 63;   // staging wavefront, lane in it
         const int ph = sl & 1, pcj = (sl >> 1) & 15, pck0 = sl >> 5;
         const int pjq = j0 + pcj, pkq0 = k0 + pck0;
-        const int pb0 = 1 + 4 * ph - pjq - pkq0;                     // i' of t = 0 minus L0 at it = 0; - 2 per it
+        const int pb0 = 1 + 4 * ph - pjq - pkq0;                     // i' of t = 0 minus L0 at it = 0; - KS per it
         const uint32_t prow0 = nat_row(pjq < NJ ? pjq : NJ - 1, pkq0 < NK ? pkq0 : NK - 1);
-        const uint32_t prstep = (uint32_t)((rk ? -2 : 2) * NJ) * (uint32_t)NF;   // natural index of node i = 0 of the column: + prstep per it
-        const int plds0 = lds_row(pcj, pck0) + 2 + 4 * ph;           // tile index of t = 0; + 2 RJ RS per it
-        auto pc_valid = [&](int it) { return pjq < NJ && pkq0 + 2 * it < NK; };
-        // ... and the 32 downwind halo columns (it = 8): j' = j0 + 16 (16 rows), then k' = k0 + 16 (16 columns)
+        const uint32_t prstep = (uint32_t)((rk ? -KS : KS) * NJ) * (uint32_t)NF;   // natural index of node i = 0 of the column: + prstep per it
+        const int plds0 = lds_row(pcj, pck0) + 2 + 4 * ph;           // tile index of t = 0; + KS RJ RS per it
+        auto pc_valid = [&](int it) { return pjq < NJ && pkq0 + KS * it < NK; };
+        // ... and the 32 downwind halo columns (the last pass of the FIRST staging wavefront): j' = j0 + 16 (16 rows), then k' = k0 + 16 (16 columns)
         int ph_b; uint32_t ph_row; int ph_lds;
         {
-            const int c = sl >> 1;
+            const int c = sll >> 1;
             const int cj = c < PK ? PJ : c - PK, ck = c < PK ? c : PK;
             const int jq = j0 + cj, kq = k0 + ck;
-            const bool ok = jq < NJ && kq < NK;
+            const bool ok = sw == 0 && jq < NJ && kq < NK;
             ph_b = ok ? 1 + 4 * ph - jq - kq : -(1 << 29);
             ph_row = ok ? nat_row(jq, kq) : 0u;
             ph_lds = lds_row(cj, ck) + 2 + 4 * ph;
         }
-        auto pc_b = [&](int it) { return it < 8 ? (pc_valid(it) ? pb0 - 2 * it : -(1 << 29)) : ph_b; };
-        auto pc_row = [&](int it) { return it < 8 ? prow0 + (uint32_t)it * prstep : ph_row; };
-        auto pc_lds = [&](int it) { return it < 8 ? plds0 + it * (2 * RJ * RS) : ph_lds; };
-        static_assert(NPASS == 9, "eight passes over the own columns, one over the downwind halo");
+        auto pc_b = [&](int it) { return it < NOWNP ? (pc_valid(it) ? pb0 - KS * it : -(1 << 29)) : ph_b; };
+        auto pc_row = [&](int it) { return it < NOWNP ? prow0 + (uint32_t)it * prstep : ph_row; };
+        auto pc_lds = [&](int it) { return it < NOWNP ? plds0 + it * (KS * RJ * RS) : ph_lds; };
         // upwind halo: 32 columns (j' = j0 - 1: 16 rows; k' = k0 - 1: 16 columns) x levels L0 - 1 + t  <->  tile q = t, t = 0 .. 7: a piece
         // of four per lane
-        int hu_b; uint32_t hu_row; int hu_lds;
+        int hu_b; uint32_t hu_row; int hu_lds;   // (the SECOND staging wavefront's: it is the one that follows the upwind progress)
         {
-            const int c = sl >> 1, h = sl & 1;
+            const int c = sll >> 1, h = sll & 1;
             int cj, ck;
             if (c < PK) { cj = -1; ck = c; } else { cj = c - PK; ck = -1; }
             const int jq = j0 + cj, kq = k0 + ck;
-            const bool ok = jq >= 0 && jq < NJ && kq >= 0 && kq < NK;
+            const bool ok = sw == NSW - 1 && jq >= 0 && jq < NJ && kq >= 0 && kq < NK;
             hu_b = ok ? -1 + 4 * h - jq - kq : -(1 << 29);
             hu_row = ok ? nat_row(jq, kq) : 0u;
             hu_lds = lds_row(cj, ck) + 4 * h;
@@ -211,11 +225,11 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
             if (FSM_PIPED_EXP & 4) return;
 #pragma unroll
             for (int it = 0; it < NPASS; ++it)
-                if (it >= it0 && it < it1) raw[it] = piece_issue(pc_row(it), L0 + pc_b(it));
+                if (it >= it0 && it < it1 && (it < NOWNP || sw == 0)) raw[it] = piece_issue(pc_row(it), L0 + pc_b(it));
         };
         // ... and the upwind halo (once both upwind patches have published it)
         auto issue_halo = [&](int L0) {
-            if (FSM_PIPED_EXP & 4) return;
+            if ((FSM_PIPED_EXP & 4) || sw != NSW - 1) return;
             hraw = piece_issue(hu_row, L0 + hu_b);
         };
         // ... and from there into tile b
@@ -223,7 +237,7 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
             if (FSM_PIPED_EXP & 12) return;
 #pragma unroll
             for (int it = 0; it < NPASS; ++it) {
-                if (it < it0 || it >= it1) continue;
+                if (it < it0 || it >= it1 || (it == NOWNP && sw != 0)) continue;
                 float v[4];
                 piece_take(raw[it], L0 + pc_b(it), v);
 #pragma unroll
@@ -231,22 +245,25 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
             }
         };
         auto fill_halo = [&](int b, int L0) {
-            if (FSM_PIPED_EXP & 12) return;
+            if ((FSM_PIPED_EXP & 12) || sw != NSW - 1) return;
             float v[4];
             piece_take(hraw, L0 + hu_b, v);
 #pragma unroll
             for (int t = 0; t < 4; ++t) Tt[b][hu_lds + t] = v[t];
         };
         // upwind progress for the chunk that starts at L0: both patches have published every level <= L0 + C - 2
-        int seen_j = up_j ? 0 : 0x3fffffff, seen_k = up_k ? 0 : 0x3fffffff;   // newest values lanes 0 / 1 have seen (progress only grows)
+        // (lanes 0 / 1 of the storer; the words stay raw in their register until they are looked at -- a decode where they are loaded would be a
+        // wait for the load where it is issued)
+        int smp = 0, seen = ((sll == 0 && up_j) || (sll == 1 && up_k)) ? 0 : 0x3fffffff;   // newest value seen (progress only grows)
+        const int* smp_ptr = sll == 0 ? up_j : (sll == 1 ? up_k : nullptr);
         auto sample = [&]() {
-            if (sl == 0 && up_j) seen_j = ld_prog(up_j);
-            if (sl == 1 && up_k) seen_k = ld_prog(up_k);
+            if (sw == NSW - 1 && smp_ptr) smp = __hip_atomic_load(smp_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto covered = [&](int L0) -> bool {
+            if (sw != NSW - 1) return true;   // (the loader has nothing to wait for)
             const int need = L0 + C - 1;
-            const bool ok = sl == 0 ? seen_j >= need : (sl == 1 ? seen_k >= need : true);
-            return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+            if (smp_ptr) { const int v = dec_prog(smp); seen = v > seen ? v : seen; }
+            return __builtin_amdgcn_ballot_w64(seen < need) == 0ull;
         };
         auto wait_upwind = [&](int L0) {   // blocking
             unsigned long long t0 = 0;
@@ -259,7 +276,7 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
                 if ((++spins & 63) == 0) {
                     if (__hip_atomic_load(pa.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                     if (wall_clock64() - t0 > pa.timeout_ticks) {
-                        if (sl == 0) __hip_atomic_store(pa.sync + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sll == 0) __hip_atomic_store(pa.sync + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
@@ -271,9 +288,9 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
 #pragma unroll
             for (int it = 0; it < NWB; ++it) {
                 if (it < it0 || it >= it1 || !pc_valid(it)) continue;
-                const int ip0 = L0 + pb0 - 1 - 2 * it;                // level L0 + 4 h  (one level below the staging piece of the same lane)
+                const int ip0 = L0 + pb0 - 1 - KS * it;               // level L0 + 4 h  (one level below the staging piece of the same lane)
                 if (ip0 + 3 < 0 || ip0 >= NF) continue;
-                const int lo = plds0 - 1 + it * (2 * RJ * RS);
+                const int lo = plds0 - 1 + it * (KS * RJ * RS);
                 const float f0 = Tt[b][lo], f1 = Tt[b][lo + 1], f2 = Tt[b][lo + 2], f3 = Tt[b][lo + 3];
                 const uint32_t rowbase = prow0 + (uint32_t)it * prstep;
                 if (ip0 >= 0 && ip0 + 3 < NF) {
@@ -298,12 +315,12 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
 #define FSM_PIPED_DBG 0   // bisecting builds: 1: no fast path; 2: every load waited for at once; 4: write-back never fast; 8: staging never fast
 #endif
         auto is_fast = [&](int Lc_) { return !(FSM_PIPED_DBG & 1) && patch_full && Lc_ + 1 - (s_jk + PJ + PK - 1) >= 0 && Lc_ + 8 - s_jk <= NF - 1; };
-        const int fstep = (rk ? -2 : 2) * NJ * NF + (rf ? 2 : -2);   // elements from the piece of pass `it` to that of it + 1
+        const int fstep = (rk ? -KS : KS) * NJ * NF + (rf ? KS : -KS);   // elements from the piece of pass `it` to that of it + 1
         const uint32_t fstepB = (uint32_t)(fstep < 0 ? -fstep : fstep) * (uint32_t)sizeof(T);
-        // element of the lowest address of the lane's own piece at pass 0 (fstep > 0) or pass 7 (fstep < 0), for the chunk that starts at 0
-        const int fit0 = fstep < 0 ? 7 : 0;
-        const uint32_t fbase = rf ? prow0 + (uint32_t)fit0 * prstep + (uint32_t)(NF - 4 - (pb0 - 2 * fit0)) : prow0 + (uint32_t)fit0 * prstep + (uint32_t)(pb0 - 2 * fit0);
-        auto fsoff = [&](int it) -> uint32_t { return (uint32_t)(fstep < 0 ? 7 - it : it) * fstepB; };   // (uniform)
+        // element of the lowest address of the lane's own piece at pass 0 (fstep > 0) or the last pass (fstep < 0), for the chunk that starts at 0
+        const int fit0 = fstep < 0 ? NOWNP - 1 : 0;
+        const uint32_t fbase = rf ? prow0 + (uint32_t)fit0 * prstep + (uint32_t)(NF - 4 - (pb0 - KS * fit0)) : prow0 + (uint32_t)fit0 * prstep + (uint32_t)(pb0 - KS * fit0);
+        auto fsoff = [&](int it) -> uint32_t { return (uint32_t)(fstep < 0 ? NOWNP - 1 - it : it) * fstepB; };   // (uniform)
         auto fvoff = [&](uint32_t base_, int Lc_) -> uint32_t { return (rf ? base_ - (uint32_t)Lc_ : base_ + (uint32_t)Lc_) * (uint32_t)sizeof(T) + FSM_PIPED_GUARD * (uint32_t)sizeof(T); };
         const uint32_t fbase_hd = rf ? ph_row + (uint32_t)(NF - 4 - ph_b) : ph_row + (uint32_t)ph_b;   // downwind halo piece (pass 8)
         const uint32_t fbase_hu = rf ? hu_row + (uint32_t)(NF - 4 - hu_b) : hu_row + (uint32_t)hu_b;   // upwind halo piece
@@ -311,12 +328,12 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
             if (FSM_PIPED_EXP & 4) return;
             const uint32_t vo = fvoff(fbase, Lc_);
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
+            for (int it = 0; it < NOWNP; ++it)
                 if (it >= it0 && it < it1) raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsT, vo, fsoff(it), 16);
-            if (it1 > 8) raw[8] = __builtin_amdgcn_raw_buffer_load_b128(rsT, fvoff(fbase_hd, Lc_), 0, 16);
+            if (it1 > NOWNP && sw == 0) raw[NOWNP] = __builtin_amdgcn_raw_buffer_load_b128(rsT, fvoff(fbase_hd, Lc_), 0, 16);
         };
         auto issue_halo_fast = [&](int Lc_) {
-            if (FSM_PIPED_EXP & 4) return;
+            if ((FSM_PIPED_EXP & 4) || sw != NSW - 1) return;
             hraw = __builtin_amdgcn_raw_buffer_load_b128(rsT, fvoff(fbase_hu, Lc_), 0, 16);
         };
         auto put4 = [&](int b, int idx, const piped_u4& w) {   // four consecutive levels of a column into the tile
@@ -329,12 +346,12 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
             if (FSM_PIPED_EXP & 12) return;
 #pragma unroll
             for (int it = 0; it < NPASS; ++it) {
-                if (it < it0 || it >= it1) continue;
-                put4(b, it < 8 ? plds0 + it * (2 * RJ * RS) : ph_lds, raw[it]);
+                if (it < it0 || it >= it1 || (it == NOWNP && sw != 0)) continue;
+                put4(b, it < NOWNP ? plds0 + it * (KS * RJ * RS) : ph_lds, raw[it]);
             }
         };
         auto fill_halo_fast = [&](int b) {
-            if (FSM_PIPED_EXP & 12) return;
+            if ((FSM_PIPED_EXP & 12) || sw != NSW - 1) return;
             put4(b, hu_lds, hraw);
         };
         auto write_back_fast = [&](int b, int Lc_, int it0, int it1) {   // (the pieces of the own columns one level lower)
@@ -342,7 +359,7 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
 #pragma unroll
             for (int it = 0; it < NWB; ++it) {
                 if (it < it0 || it >= it1) continue;
-                const int lo = plds0 - 1 + it * (2 * RJ * RS);
+                const int lo = plds0 - 1 + it * (KS * RJ * RS);
                 const float f0 = Tt[b][lo], f1 = Tt[b][lo + 1], f2 = Tt[b][lo + 2], f3 = Tt[b][lo + 3];
                 piped_u4 w;
                 w.x = __float_as_uint(rf ? f3 : f0); w.y = __float_as_uint(rf ? f2 : f1); w.z = __float_as_uint(rf ? f1 : f2); w.w = __float_as_uint(rf ? f0 : f3);
@@ -361,10 +378,10 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
         issue_halo(L0);
         {
             // (addresses clamped into the column instead of branches around the loads, for the same reason as above)
-            float v0[NM / 64], v1[NM / 64];
+            float v0[NM / (64 * NSW)], v1[NM / (64 * NSW)];
 #pragma unroll
-            for (int it = 0; it < NM / 64; ++it) {
-                const int c = sl + 64 * it, cj = c % PJ, ck = c / PJ;
+            for (int it = 0; it < NM / (64 * NSW); ++it) {
+                const int c = sl + 64 * NSW * it, cj = c % PJ, ck = c / PJ;
                 const int jq = j0 + cj < NJ ? j0 + cj : NJ - 1, kq = k0 + ck < NK ? k0 + ck : NK - 1;
                 const int ip = L0 - 1 - jq - kq;
                 const int ia = ip < 0 ? 0 : (ip > NF - 1 ? NF - 1 : ip), ib = ip + 1 < 0 ? 0 : (ip + 1 > NF - 1 ? NF - 1 : ip + 1);
@@ -373,8 +390,8 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
                 v1[it] = ld_sc1(Tg + (rb + (uint32_t)(rf ? NF - 1 - ib : ib)));
             }
 #pragma unroll
-            for (int it = 0; it < NM / 64; ++it) {
-                const int c = sl + 64 * it, cj = c % PJ, ck = c / PJ, jq = j0 + cj, kq = k0 + ck;
+            for (int it = 0; it < NM / (64 * NSW); ++it) {
+                const int c = sl + 64 * NSW * it, cj = c % PJ, ck = c / PJ, jq = j0 + cj, kq = k0 + ck;
                 const int ip = L0 - 1 - jq - kq;
                 const bool col = jq < NJ && kq < NK;
                 Tt[0][lds_row(cj, ck)] = col && (unsigned)ip < (unsigned)NF ? v0[it] : INF;
@@ -385,20 +402,33 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
         fill_halo(0, L0);
         int b = 0;
         int pub_pending = 0;   // progress value of the chunk written back last, not yet published
-        // The phases of a chunk.  The staging wavefront passes a barrier every level (0.36 us), is one wavefront (an instruction every 6-8
-        // cycles, 60 ns to get a scattered 16-byte load out) and a memory round trip is 1-2 us: its work is cut into pieces of < 100
-        // instructions, one per level, none of which waits for an access of the same or the previous two phases -- except where the
+        // The phases of a chunk.  A staging wavefront passes a barrier every level (0.36 us), issues an instruction every 6-8 cycles (60 ns
+        // to get a scattered 16-byte load out) and a memory round trip is 1-2 us: the work is cut into pieces of < 100 instructions,
+        // one per level and wavefront, none of which waits for an access of the same or the previous two phases -- except where the
         // march has to wait anyway:
-        //   0, 1      sample the upwind progress; write back the chunk before this one (tile b^1), half of it per level
-        //   2, 3, 4   the loads of the next chunk's not-yet-swept values go out, three pieces per level; upwind progress there: its halo too
-        //   5         the stores of 0, 1 are done once at most the nine loads behind them are outstanding (accesses complete in the order
-        //             of their issue): publish the chunk before; the pieces of 2 into tile b^1
-        //   6, 7      the pieces of 3, 4; the halo (if its loads went out by 4)
-        //   behind 7  (else) wait, load, fill
+        //   0         sample the upwind progress (second wavefront); write back the chunk before this one (tile b^1), first half
+        //   1         second half
+        //   2, 3      the loads of the next chunk's not-yet-swept values go out; upwind progress there: its halo too (else look again)
+        //   4         upwind progress, again
+        //   5         the stores of 0, 1 are done once at most the loads issued behind them are outstanding (accesses complete in the order of
+        //             their issue): the wavefront that gets there last publishes the chunk before; first pieces into tile b^1
+        //   6, 7      the other pieces; the halo (if its loads went out by 4)
+        //   behind 7  (else; second wavefront) wait, load, fill
+        auto publish = [&](int value, bool drain_all) {
+            if (drain_all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (sw == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // (five / at least four loads behind the stores)
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (sll == 0) {
+                if (atomicAdd(&s_pubcnt, 1) == NSW - 1) {
+                    s_pubcnt = 0;
+                    st_prog(my_prog, value);
+                }
+            }
+        };
         for (;; L0 += C, b ^= 1) {
             const bool last = L0 + C > Le;
             const bool fast_n = !(FSM_PIPED_DBG & 8) && !last && is_fast(L0 + C), fast_p = !(FSM_PIPED_DBG & 4) && L0 > Lc0 && is_fast(L0 - C);
-            int halo_at = -1;   // phase in which the halo loads of the next chunk went out
+            int halo_at = sw == NSW - 1 ? -1 : 0;   // phase in which the halo loads of the next chunk went out (first wavefront: nothing to do)
             auto try_halo = [&](int phase) {
                 if (last || halo_at >= 0) return;
                 if (covered(L0 + C)) { if (fast_n) issue_halo_fast(L0 + C); else issue_halo(L0 + C); halo_at = phase; }
@@ -409,33 +439,28 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
             __syncthreads();                                   // B0: tile b complete (march: carry written)
             const bool wb = L0 > Lc0 && !(FSM_PIPED_EXP & 2) && s_chg[b ^ 1] != 0;
             if (!last) sample();
-            if (wb) { if (fast_p) write_back_fast(b ^ 1, L0 - C, 0, 4); else write_back(b ^ 1, L0 - C, 0, 4); }
+            if (wb) { if (fast_p) write_back_fast(b ^ 1, L0 - C, 0, 2); else write_back(b ^ 1, L0 - C, 0, 2); }
             if (L0 > Lc0) pub_pending = L0;
             __syncthreads();                                   // level 0 done
             if (sl == 0) s_chg[b ^ 1] = 0;
-            if (wb) { if (fast_p) write_back_fast(b ^ 1, L0 - C, 4, 8); else write_back(b ^ 1, L0 - C, 4, 8); }
+            if (wb) { if (fast_p) write_back_fast(b ^ 1, L0 - C, 2, 4); else write_back(b ^ 1, L0 - C, 2, 4); }
             __syncthreads();                                   // level 1
             statics(0, 3);
             try_halo(2);
             __syncthreads();                                   // level 2
-            statics(3, 6);
+            statics(3, NPASS);
             try_halo(3);
             __syncthreads();                                   // level 3
-            statics(6, NPASS);
             try_halo(4);
             __syncthreads();                                   // level 4
-            if (pub_pending) {
-                if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                if (sl == 0) st_prog(my_prog, pub_pending);
-                pub_pending = 0;
-            }
-            fills(0, 3);
+            if (pub_pending) { publish(pub_pending, last); pub_pending = 0; }
+            fills(0, 2);
             __syncthreads();                                   // level 5
-            fills(3, 6);
+            fills(2, 4);
             __syncthreads();                                   // level 6
-            fills(6, NPASS);
-            bool filled = false;
-            if (!last && halo_at >= 0) { if (fast_n) fill_halo_fast(b ^ 1); else fill_halo(b ^ 1, L0 + C); filled = true; }
+            fills(4, NPASS);
+            bool filled = sw != NSW - 1;
+            if (!last && !filled && halo_at >= 0) { if (fast_n) fill_halo_fast(b ^ 1); else fill_halo(b ^ 1, L0 + C); filled = true; }
             __syncthreads();                                   // level 7: the march of this chunk is over
             if (last) break;
             if (!filled) {   // the upwind patches were not there in time: the march waits (at B0) like the four-wave kernel does
@@ -447,8 +472,7 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
         // the last chunk: its flag is final behind one more barrier
         __syncthreads();                                       // BF
         if (s_chg[b]) write_back(b, L0, 0, NWB);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (sl == 0) st_prog(my_prog, 0x3fffffff);
+        publish(0x3fffffff, true);
         return true;
     }
 
@@ -601,7 +625,7 @@ __device__ __forceinline__ bool fsm_piped_unit(const PersistArgs<float>& pa) {
     return true;
 }
 
-__global__ __launch_bounds__(320, FSM_PIPED_WAVES) void fsm_sweep_piped(const PersistArgs<float> pa) {
+__global__ __launch_bounds__(384, FSM_PIPED_WAVES) void fsm_sweep_piped(const PersistArgs<float> pa) {
     (void)pa;
     for (;;) {
         auto kp = __builtin_amdgcn_kernarg_segment_ptr();
