@@ -1,4 +1,13 @@
-mkdir -p gpurun_out/r05
-python -m pytest tests -m gpu -x -q > gpurun_out/r05/pytest_gpu_full.txt 2>&1; tail -3 gpurun_out/r05/pytest_gpu_full.txt
-bash scripts/round5_evidence.sh gpurun_out/r05 > gpurun_out/r05/evidence_log.txt 2>&1; tail -25 gpurun_out/r05/evidence_log.txt
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05/smoke.txt 2>&1; tail -2 gpurun_out/r05/smoke.txt
+mkdir -p gpurun_out/r5g
+{
+for lib in "" variants/skip1w4.so; do
+  if [ -n "$lib" ]; then export TTCR_AMD_LIB=$PWD/$lib; fi
+  echo "== ${lib:-library}"
+  TTCR_FSM_PAIR=0 python scripts/lone_time.py 512 3 8
+  TTCR_FSM_PAIR=0 python scripts/lone_time.py 512 3 4
+  TTCR_FSM_PAIR=0 python scripts/lone_time.py 512 3 2
+  TTCR_FSM_SKIP=1 python scripts/lone_time.py 512 3 1
+  python scripts/config_one.py C4 2 | grep "^C4"
+done
+} > gpurun_out/r5g/skip1w4.txt 2>&1
+sed 's/ lib=[a-z0-9_.]*//' gpurun_out/r5g/skip1w4.txt
