@@ -1,13 +1,11 @@
 mkdir -p gpurun_out/r5g
 {
-for lib in "" variants/skip1w4.so; do
+for lib in "" variants/late5.so variants/late7.so; do
   if [ -n "$lib" ]; then export TTCR_AMD_LIB=$PWD/$lib; fi
   echo "== ${lib:-library}"
-  TTCR_FSM_PAIR=0 python scripts/lone_time.py 512 3 8
-  TTCR_FSM_PAIR=0 python scripts/lone_time.py 512 3 4
-  TTCR_FSM_PAIR=0 python scripts/lone_time.py 512 3 2
-  TTCR_FSM_SKIP=1 python scripts/lone_time.py 512 3 1
-  python scripts/config_one.py C4 2 | grep "^C4"
+  python scripts/lone_time.py 512 3 1
+  python scripts/lone_time.py 256 3 1
+  TTCR_FSM_SKIP=0 python scripts/lone_time.py 512 2 8
 done
-} > gpurun_out/r5g/skip1w4.txt 2>&1
-sed 's/ lib=[a-z0-9_.]*//' gpurun_out/r5g/skip1w4.txt
+} > gpurun_out/r5g/late.txt 2>&1
+sed 's/ lib=[a-z0-9_.]*//; s/ pair=default//' gpurun_out/r5g/late.txt
