@@ -185,6 +185,9 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  2^24 nodes; an iteration that lands in the window without one is decided by the fp64 sum and counted
  *                  (ttcr_fsm_stopping_stats).  0: the fp64 sum alone.  2: as 1 with the sum as ONE chain of additions (the
  *                  round-4 kernel: 0.5 s per 512^3 field; kept as the checker of the parallel form).  tests/test_stopping_rule_gpu.py
+ *   "lone_chunk"   levels per chunk of the sweep kernel for a LONE source of a first-order 3-D fp32 grid that keeps one field per slot
+ *                  (16, default: 6.8 instead of 7.2 ms per sweep-iteration at 512^3; 8: the chunk length of every other case).  The
+ *                  partial order of the node updates and therefore every result is the same.  env TTCR_FSM_LONE_CHUNK
  *   "piped"        1: first-order 3-D sweeps of fp32 grids with one field per slot that evaluate every chunk (lone sources, small batches
  *                  without exact skipping) use the pipelined kernel (fsm_piped_kernels.h: four march wavefronts + two staging wavefronts
  *                  per patch, two LDS tiles, 16-byte buffer accesses; bit-identical; 7.9-8.0 against 7.2 ms per sweep-iteration for a lone

@@ -168,6 +168,7 @@ class GridBase {
     virtual void reference_change_host(const void* times, const void* field, bool parallel, void* out) = 0;
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
     virtual long long prefill_swap_count() const { return 0; }   // calls that took fields initialised on the side stream (ttcr_fsm_prefill_swaps)
+    int lone_chunk = 16;   // option "lone_chunk" / TTCR_FSM_LONE_CHUNK: levels per chunk of a lone fp32 first-order 3-D source (8 or 16)
     int piped = -1;     // option "piped" / TTCR_FSM_PIPED: the pipelined sweep kernel (fsm_piped_kernels.h) wherever it applies (first-order
                         // 3-D sweeps of fp32 grids with one field per slot, whole-iteration launches, no exact skipping); 1 on, 0 off,
                         // -1 (default): GridT::piped_now
@@ -211,6 +212,7 @@ class GridBase {
         else if (k == "stopping_rule") stopping_rule = (int)value;
         else if (k == "prefill") prefill = (int)value;
         else if (k == "piped") piped = (int)value;
+        else if (k == "lone_chunk") lone_chunk = (int)value;
         else throw ValueError("unknown option '" + k + "'");
     }
     virtual void get_niter(int slot, int* it, int* itw) const {
@@ -478,6 +480,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_PREFILL")) prefill = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_PIPED")) piped = std::atoi(e);
+        if (const char* e = std::getenv("TTCR_FSM_LONE_CHUNK")) lone_chunk = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_PIPED_LDS")) piped_lds = (size_t)std::atol(e);   // tuning only
     }
 
@@ -582,6 +585,16 @@ class GridT : public GridBase {
     template <int DIM, int H>
     void launch_sweeps_persistent(int batch) {
         constexpr int C0 = ChunkCfg<T, DIM>::C;
+        // A lone source (one batch entry, one field per workgroup, every chunk evaluated) is bound by the chain of its chunks, not by
+        // registers: chunks of 16 levels halve the staging, the write-back and the hand-offs per level (512^3: 7.19 -> 6.82 ms per
+        // sweep-iteration, 256^3: 3.29 -> 3.18; chunks of 4: 11.99 / 4.96; a batch of 8 with chunks of 16: 48 ms instead of 17 --
+        // profiles/r05/experiment_chunk_length.txt).  Same partial order, same results.
+        if constexpr (DIM == 3 && H == 1 && sizeof(T) == 4 && C0 == 8) {
+            if (NS == 1 && batch == 1 && mode == 2 && lone_chunk == 16 && !skip_now(batch) && !piped_now(batch)) {
+                launch_sweeps_persistent_ns<DIM, H, 1, 16>(batch);
+                return;
+            }
+        }
         // (pair layout only: with one field per slot -- the default of weno grids since round 2 -- the 8-level chunks are
         // 2-4 % faster at every batch size, profiles/r02/weno_chunk.txt)
         if (H == 2 && DIM == 3 && NS == 2 && batch >= weno_ch4_min && C0 == 8) {
