@@ -168,7 +168,7 @@ class GridBase {
     virtual void reference_change_host(const void* times, const void* field, bool parallel, void* out) = 0;
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
     virtual long long prefill_swap_count() const { return 0; }   // calls that took fields initialised on the side stream (ttcr_fsm_prefill_swaps)
-    int lone_chunk = 16;   // option "lone_chunk" / TTCR_FSM_LONE_CHUNK: levels per chunk of a lone fp32 first-order 3-D source (8 or 16)
+    int lone_chunk = 16;   // option "lone_chunk" / TTCR_FSM_LONE_CHUNK: levels per chunk of the fp32 first-order 3-D kernels with one field per workgroup (8 or 16)
     int piped = -1;     // option "piped" / TTCR_FSM_PIPED: the pipelined sweep kernel (fsm_piped_kernels.h) wherever it applies (first-order
                         // 3-D sweeps of fp32 grids with one field per slot, whole-iteration launches, no exact skipping); 1 on, 0 off,
                         // -1 (default): GridT::piped_now
@@ -272,6 +272,7 @@ class GridT : public GridBase {
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // pair layout: slot groups from which the 3-D WENO stage uses chunks of 4 levels
+    int weno_c16_below = 3;  // one field per workgroup, fp32: batch entries below which the 3-D WENO stage uses chunks of 16 levels (option lone_chunk = 16)
     int pre_min = 2;           // 3-D: slot groups in a batch from which the upwind counters are sampled one chunk ahead (PRE)
     // extra (unused) dynamic LDS per workgroup of the whole-iteration launch: caps the resident workgroups per CU.  A lone
     // source is bound by the dependent chain of a marching unit, and a unit that shares its CU's SIMDs with another
@@ -470,6 +471,7 @@ class GridT : public GridBase {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         if (const char* e = std::getenv("TTCR_FSM_SWEEP45")) sweep45_strips = std::string(e) == "strips";
         if (const char* e = std::getenv("TTCR_FSM_WENO_CH4_MIN")) weno_ch4_min = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_WENO_C16_BELOW")) weno_c16_below = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_TIME_ORDER_BELOW")) time_order_below = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_PRE_MIN")) pre_min = std::atoi(e);                     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
@@ -585,13 +587,20 @@ class GridT : public GridBase {
     template <int DIM, int H>
     void launch_sweeps_persistent(int batch) {
         constexpr int C0 = ChunkCfg<T, DIM>::C;
-        // A lone source (one batch entry, one field per workgroup, every chunk evaluated) is bound by the chain of its chunks, not by
-        // registers: chunks of 16 levels halve the staging, the write-back and the hand-offs per level (512^3: 7.19 -> 6.82 ms per
-        // sweep-iteration, 256^3: 3.29 -> 3.18; chunks of 4: 11.99 / 4.96; a batch of 8 with chunks of 16: 48 ms instead of 17 --
-        // profiles/r05/experiment_chunk_length.txt).  Same partial order, same results.
-        if constexpr (DIM == 3 && H == 1 && sizeof(T) == 4 && C0 == 8) {
-            if (NS == 1 && batch == 1 && mode == 2 && lone_chunk == 16 && !skip_now(batch) && !piped_now(batch)) {
-                launch_sweeps_persistent_ns<DIM, H, 1, 16>(batch);
+        // One field per workgroup (lone sources, batches below the pairing threshold): such launches are bound by the chains of their
+        // chunks rather than by registers, and chunks of 16 levels halve the staging, the write-back and the hand-offs per level --
+        // ms per sweep-iteration with chunks of 8 / 16 levels, 512^3: lone source 7.20 / 6.87, 2 sources 8.11 / 7.15, 4: 10.57 / 9.72,
+        // 8 (unpaired): 16.36 / 15.24; 256^3: 1 source 3.29 / 3.15, 2: 3.69 / 3.30, 4: 4.28 / 3.55, 8: 4.49 / 4.04 (chunks of 4: 11.99 /
+        // 4.96 for the lone source; PAIRS with chunks of 16: 48 ms instead of 17 for 8 sources, 22 ms with two workgroups per CU and no
+        // spills).  fp64: the lone source 8.08 / 7.39 (256^3), 13.03 / 11.40 (384^3), but 8 sources 12.0 / 12.3 and 36.0 / 43.9: lone
+        // sources only.  Same partial order, same results, same exact skipping (a chunk is the unit that is skipped: twice as coarse).
+        // The WENO stage likewise where it is bound by its chains: 256^3 fp32 1 source 380.6 / 318.3 ms per solve (46 WENO iterations),
+        // 2 sources 397 / 371, but 4: 501 / 564, 8: 761 / 981 (bound by its arithmetic there, and the longer chunk costs it registers);
+        // fp64 1 source 663.5 / 536.7.  profiles/r05/experiment_chunk_length.txt
+        if constexpr (DIM == 3 && C0 == 8) {
+            const int below = sizeof(T) == 4 ? (H == 1 ? std::numeric_limits<int>::max() : weno_c16_below) : 2;
+            if (NS == 1 && mode == 2 && lone_chunk == 16 && batch < below && !piped_now(batch)) {
+                launch_sweeps_persistent_ns<DIM, H, 1, 16, true>(batch);
                 return;
             }
         }
@@ -605,11 +614,14 @@ class GridT : public GridBase {
         }
     }
 
-    template <int DIM, int H, int NSV, int CH>
+    template <int DIM, int H, int NSV, int CH, bool XS_ONLY = false>   // XS_ONLY: only the whole-iteration launch (mode 2) is instantiated
     void launch_sweeps_persistent_ns(int batch) {
         using C = TileCfg<T, DIM>;
         PersistArgs<T> pa;
         SweepArgs<T>& a = pa.s;
+        // (the occupancy cap of the lone source and the counters sampled ahead that go with it were tuned for chunks of 8 levels: with 16
+        // they cost 3-4 % -- 512^3 6.89 -> 6.68 ms per sweep-iteration without them, 256^3 3.19 -> 3.07)
+        const size_t dyn_lds = (CH == 16 && H == 1 && sizeof(T) == 4) ? 0 : xs_dyn_lds(batch);
         a.tt = d_tt.p;
         a.ts = NS;
         a.lmask = d_lmask.p;
@@ -649,7 +661,7 @@ class GridT : public GridBase {
         const dim3 block(C::PJ * C::PK), grid((unsigned)std::min<size_t>((size_t)n_patches * batch, wg_cap));
         const int ndir = DIM == 3 ? 8 : 4;
         {
-            const bool pre_ = mode == 2 && (DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0);
+            const bool pre_ = mode == 2 && (DIM == 2 || batch >= pre_min || dyn_lds > 0);
             char nm[160];
             std::snprintf(nm, sizeof nm, "fsm_sweep_persistent<%s,%d,%d,%d,%s,%s,%d,%d,%s,%s>", sizeof(T) == 4 ? "float" : "double", C::PJ, C::PK, CH,
                           DIM == 3 ? "true" : "false", skip_now(batch) ? "true" : "false", H, NSV, mode == 2 ? "true" : "false", pre_ ? "true" : "false");
@@ -665,7 +677,7 @@ class GridT : public GridBase {
             pa.timeout_ticks = 1000000000ull;  // 10 s: a unit may wait for most of the previous sweep
             const dim3 gridx((unsigned)std::min<size_t>((size_t)n_patches * batch * ndir, wg_cap));
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
-            const bool pre = DIM == 2 || batch >= pre_min || xs_dyn_lds(batch) > 0;   // counters sampled one chunk ahead (template PRE)
+            const bool pre = DIM == 2 || batch >= pre_min || dyn_lds > 0;   // counters sampled one chunk ahead (template PRE)
             if constexpr (std::is_same<T, float>::value && DIM == 3 && H == 1 && NSV == 1 && CH == 8 && C::PJ == 16 && C::PK == 16) {
                 if (piped_now(batch)) {
                     last_kernel = "fsm_sweep_piped";
@@ -674,16 +686,18 @@ class GridT : public GridBase {
                 }
             }
             if (skip_now(batch) && pre)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, dyn_lds, stream>>>(pa);
             else if (skip_now(batch))
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
             else if (pre)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, dyn_lds, stream>>>(pa);
             else
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, xs_dyn_lds(batch), stream>>>(pa);
+                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
             HIP_CHECK(hipGetLastError());
             return;
         }
+        if constexpr (XS_ONLY) throw std::logic_error("launch_sweeps_persistent_ns: whole-iteration launches only");
+        else {
         pa.ssh = nullptr;
         pa.ssh_stride = 0;
         static const int RX2[4] = {0, 1, 1, 0}, RZ2[4] = {0, 0, 1, 1};
@@ -708,6 +722,7 @@ class GridT : public GridBase {
                 fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, false><<<grid, block, 0, stream>>>(pa);
         }
         HIP_CHECK(hipGetLastError());
+        }
     }
 
     // For every launch w of a sweep, the patches (TJ,TK) whose level window
