@@ -187,11 +187,12 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  round-4 kernel: 0.5 s per 512^3 field; kept as the checker of the parallel form).  tests/test_stopping_rule_gpu.py
  *   "lone_chunk"   levels per chunk of the 3-D sweep kernels that keep ONE field per workgroup, where the longer chunk is faster (16, default):
  *                  fp32 first-order sweeps of lone sources and of batches below the pairing threshold (512^3: lone source 6.7 instead of
- *                  7.2 ms per sweep-iteration, 4 sources 9.7 instead of 10.6; 256^3 x 4 sources 3.5 instead of 4.3), the fp32 WENO stage of
- *                  one or two sources (256^3: 318 instead of 381 ms per solve), fp64 lone sources in both stages (256^3: 7.4 instead of
- *                  8.1 ms; with WENO 537 instead of 664 ms per solve).  8: the chunk length of every other kernel, everywhere.  The
- *                  partial order of the node updates and therefore every result is the same; exact skipping steps over chunks of
- *                  that length.  env TTCR_FSM_LONE_CHUNK.  tests/test_lone_chunk_gpu.py, profiles/r05/experiment_chunk_length.txt
+ *                  7.2 ms per sweep-iteration, 4 sources 9.6 instead of 10.6; 256^3 x 4 sources 3.5 instead of 4.3), fp64 first-order
+ *                  sweeps of up to four sources (256^3: 7.1 instead of 8.1 ms for one, 9.1 instead of 10.4 for four), the WENO stage of
+ *                  one or two sources (256^3: 319 instead of 381 ms per solve, fp64 537 instead of 664).  8: the chunk length of every
+ *                  other kernel, everywhere.  The partial order of the node updates and therefore every result is the same; exact
+ *                  skipping steps over chunks of that length.  env TTCR_FSM_LONE_CHUNK.  tests/test_lone_chunk_gpu.py,
+ *                  profiles/r05/experiment_chunk_length.txt
  *   "piped"        1: first-order 3-D sweeps of fp32 grids with one field per slot that evaluate every chunk (lone sources, small batches
  *                  without exact skipping) use the pipelined kernel (fsm_piped_kernels.h: four march wavefronts + two staging wavefronts
  *                  per patch, two LDS tiles, 16-byte buffer accesses; bit-identical; 7.9-8.0 against 7.2 ms per sweep-iteration for a lone

@@ -1,6 +1,6 @@
 """3-D grids that keep one field per workgroup run on chunks of 16 levels (option "lone_chunk", default 16) instead of 8 where the
-longer chunk is faster -- fp32 first-order sweeps at any batch size below the pairing threshold, the fp32 WENO stage of one or two
-sources, fp64 lone sources (both stages): the partial order of the node updates is the same (Grid3Drn::sweep /
+longer chunk is faster -- fp32 first-order sweeps at any batch size below the pairing threshold, fp64 first-order sweeps of up to four
+sources, the WENO stage of one or two sources: the partial order of the node updates is the same (Grid3Drn::sweep /
 update_node, ttcr/Grid3Drn.h:2816-2959), so fields, iteration counts and the change history are those of the 8-level kernels bit
 for bit (which test_parity_gpu.py pins to the oracle) -- with and without exact skipping, for one source and for a batch."""
 import numpy as np
@@ -51,7 +51,7 @@ def test_chunks_of_16_levels_match_chunks_of_8(seed):
         if c % 4 == 0:
             src[0] = np.round(src[0] / 0.37) * 0.37   # on a node
         skip = (c // 2) % 2
-        dtype = np.float64 if c % 4 == 1 else np.float32   # (fp64: lone sources only)
+        dtype = np.float64 if c % 4 in (1, 2) else np.float32   # (fp64: one source and three)
         r8, k8 = _solve(shape, s, src, 8, weno, skip, dtype)
         r16, k16 = _solve(shape, s, src, 16, weno, skip, dtype)
         for (t8, n8, c8), (t16, n16, c16) in zip(r8, r16):

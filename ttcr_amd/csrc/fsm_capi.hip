@@ -272,7 +272,8 @@ class GridT : public GridBase {
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // pair layout: slot groups from which the 3-D WENO stage uses chunks of 4 levels
-    int weno_c16_below = 3;  // one field per workgroup, fp32: batch entries below which the 3-D WENO stage uses chunks of 16 levels (option lone_chunk = 16)
+    int weno_c16_below = 3;  // one field per workgroup: batch entries below which the 3-D WENO stage uses chunks of 16 levels (option lone_chunk = 16)
+    int f64_c16_below = 5;   // ... below which the fp64 first-order 3-D sweeps do
     int pre_min = 2;           // 3-D: slot groups in a batch from which the upwind counters are sampled one chunk ahead (PRE)
     // extra (unused) dynamic LDS per workgroup of the whole-iteration launch: caps the resident workgroups per CU.  A lone
     // source is bound by the dependent chain of a marching unit, and a unit that shares its CU's SIMDs with another
@@ -472,6 +473,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_SWEEP45")) sweep45_strips = std::string(e) == "strips";
         if (const char* e = std::getenv("TTCR_FSM_WENO_CH4_MIN")) weno_ch4_min = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_WENO_C16_BELOW")) weno_c16_below = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_F64_C16_BELOW")) f64_c16_below = std::atoi(e);     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_TIME_ORDER_BELOW")) time_order_below = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_PRE_MIN")) pre_min = std::atoi(e);                     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
@@ -592,13 +594,14 @@ class GridT : public GridBase {
         // ms per sweep-iteration with chunks of 8 / 16 levels, 512^3: lone source 7.20 / 6.87, 2 sources 8.11 / 7.15, 4: 10.57 / 9.72,
         // 8 (unpaired): 16.36 / 15.24; 256^3: 1 source 3.29 / 3.15, 2: 3.69 / 3.30, 4: 4.28 / 3.55, 8: 4.49 / 4.04 (chunks of 4: 11.99 /
         // 4.96 for the lone source; PAIRS with chunks of 16: 48 ms instead of 17 for 8 sources, 22 ms with two workgroups per CU and no
-        // spills).  fp64: the lone source 8.08 / 7.39 (256^3), 13.03 / 11.40 (384^3), but 8 sources 12.0 / 12.3 and 36.0 / 43.9: lone
-        // sources only.  Same partial order, same results, same exact skipping (a chunk is the unit that is skipped: twice as coarse).
+        // spills).  fp64: the lone source 8.08 / 7.39 (256^3), 13.03 / 11.40 (384^3), 2 sources 9.01 / 7.62, 4: 10.39 / 9.12, but 8 sources
+        // 12.0 / 12.3 and 36.0 / 43.9 (384^3): up to four.  Same partial order, same results, same exact skipping (a chunk is the unit
+        // that is skipped: twice as coarse).
         // The WENO stage likewise where it is bound by its chains: 256^3 fp32 1 source 380.6 / 318.3 ms per solve (46 WENO iterations),
         // 2 sources 397 / 371, but 4: 501 / 564, 8: 761 / 981 (bound by its arithmetic there, and the longer chunk costs it registers);
-        // fp64 1 source 663.5 / 536.7.  profiles/r05/experiment_chunk_length.txt
+        // fp64 1 source 663.5 / 536.7, 2 sources 757 / 589.  profiles/r05/experiment_chunk_length.txt
         if constexpr (DIM == 3 && C0 == 8) {
-            const int below = sizeof(T) == 4 ? (H == 1 ? std::numeric_limits<int>::max() : weno_c16_below) : 2;
+            const int below = H == 2 ? weno_c16_below : sizeof(T) == 4 ? std::numeric_limits<int>::max() : f64_c16_below;
             if (NS == 1 && mode == 2 && lone_chunk == 16 && batch < below && !piped_now(batch)) {
                 launch_sweeps_persistent_ns<DIM, H, 1, 16, true>(batch);
                 return;
@@ -619,9 +622,12 @@ class GridT : public GridBase {
         using C = TileCfg<T, DIM>;
         PersistArgs<T> pa;
         SweepArgs<T>& a = pa.s;
-        // (the occupancy cap of the lone source and the counters sampled ahead that go with it were tuned for chunks of 8 levels: with 16
-        // they cost 3-4 % -- 512^3 6.89 -> 6.68 ms per sweep-iteration without them, 256^3 3.19 -> 3.07)
-        const size_t dyn_lds = (CH == 16 && H == 1 && sizeof(T) == 4) ? 0 : xs_dyn_lds(batch);
+        // (the occupancy cap of the lone source and the upwind counters sampled one chunk ahead (PRE) were tuned for chunks of 8 levels: on
+        // first-order chunks of 16 they cost -- lone source 512^3 6.89 -> 6.68 ms per sweep-iteration without both, 256^3 3.19 -> 3.07, fp64
+        // 256^3 7.35 -> 7.11; batches without PRE: 512^3 x 2 / 4 sources 7.21 -> 7.09 / 9.69 -> 9.64, 256^3 x 2 / 4 / 8 3.30 -> 3.15 /
+        // 3.57 -> 3.47 / 4.04 -> 3.97)
+        constexpr bool NO_PRE = CH == 16 && H == 1 && DIM == 3;
+        const size_t dyn_lds = NO_PRE ? 0 : xs_dyn_lds(batch);
         a.tt = d_tt.p;
         a.ts = NS;
         a.lmask = d_lmask.p;
@@ -661,7 +667,7 @@ class GridT : public GridBase {
         const dim3 block(C::PJ * C::PK), grid((unsigned)std::min<size_t>((size_t)n_patches * batch, wg_cap));
         const int ndir = DIM == 3 ? 8 : 4;
         {
-            const bool pre_ = mode == 2 && (DIM == 2 || batch >= pre_min || dyn_lds > 0);
+            const bool pre_ = mode == 2 && !NO_PRE && (DIM == 2 || batch >= pre_min || dyn_lds > 0);
             char nm[160];
             std::snprintf(nm, sizeof nm, "fsm_sweep_persistent<%s,%d,%d,%d,%s,%s,%d,%d,%s,%s>", sizeof(T) == 4 ? "float" : "double", C::PJ, C::PK, CH,
                           DIM == 3 ? "true" : "false", skip_now(batch) ? "true" : "false", H, NSV, mode == 2 ? "true" : "false", pre_ ? "true" : "false");
@@ -685,14 +691,22 @@ class GridT : public GridBase {
                     return;
                 }
             }
-            if (skip_now(batch) && pre)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, dyn_lds, stream>>>(pa);
-            else if (skip_now(batch))
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
-            else if (pre)
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, dyn_lds, stream>>>(pa);
-            else
-                fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
+            if constexpr (NO_PRE) {
+                (void)pre;
+                if (skip_now(batch))
+                    fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
+                else
+                    fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
+            } else {
+                if (skip_now(batch) && pre)
+                    fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true, true><<<gridx, block, dyn_lds, stream>>>(pa);
+                else if (skip_now(batch))
+                    fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, true, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
+                else if (pre)
+                    fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true, true><<<gridx, block, dyn_lds, stream>>>(pa);
+                else
+                    fsm_sweep_persistent<T, C::PJ, C::PK, CH, DIM == 3, false, H, NSV, true><<<gridx, block, dyn_lds, stream>>>(pa);
+            }
             HIP_CHECK(hipGetLastError());
             return;
         }
