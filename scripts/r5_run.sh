@@ -1,16 +1,14 @@
-mkdir -p gpurun_out/r5n
-O=gpurun_out/r5n
-python -m pytest tests/test_lone_chunk_gpu.py -m gpu -x -q > $O/pytest_lone_chunk.txt 2>&1; tail -3 $O/pytest_lone_chunk.txt
+mkdir -p gpurun_out/r05b
+O=gpurun_out/r05b
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_512x64.json 2> $O/bench_512x64.err; echo "bench rc $?"; tail -c 200 $O/bench_512x64.json; echo
 {
-python scripts/lone_time.py 512 3 1; python scripts/lone_time.py 512 2 2; python scripts/lone_time.py 512 2 4; python scripts/lone_time.py 256 3 1; python scripts/lone_time.py 256 3 4
-python scripts/f64_batch_time.py 256 0 1 2 4 8; python scripts/f64_batch_time.py 256 1 1 2
-} > $O/timings.txt 2>&1
-sed 's/ lib=lib[a-z0-9_.]*//; s/ pair=default//' $O/timings.txt
-{
-echo "== scripts/fuzz_modes.py 240 s seed 63"
-python scripts/fuzz_modes.py 240 63 2>&1 | tail -2
-echo "== tests/test_fuzz_gpu.py with a 160 s budget (HIP path against the oracle)"
-TTCR_FUZZ_SECONDS=160 python -m pytest tests/test_fuzz_gpu.py -m gpu -q 2>&1 | tail -2
+echo "== scripts/fuzz_modes.py 420 s seed 64 (final library)"
+python scripts/fuzz_modes.py 420 64 2>&1 | tail -2
+echo "== scripts/fuzz_modes.py 200 s seed 65 with TTCR_FSM_PREFILL=1 (second set of fields on every grid)"
+TTCR_FSM_PREFILL=1 python scripts/fuzz_modes.py 200 65 2>&1 | tail -2
+echo "== scripts/fuzz_pairing.py 160 s"
+python scripts/fuzz_pairing.py 160 2>&1 | tail -1
+echo "== scripts/piped_check.py 24 cases seed 78 (pipelined kernel against the default kernel)"
+python scripts/piped_check.py --cases 24 --no-time --seed 78 2>&1 | tail -1
 } > $O/fuzz.txt 2>&1
 cat $O/fuzz.txt
-rm -rf gpurun_out/r05; bash scripts/r5_run_final.sh
