@@ -1,14 +1,12 @@
-mkdir -p gpurun_out/r05b
-O=gpurun_out/r05b
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_512x64.json 2> $O/bench_512x64.err; echo "bench rc $?"; tail -c 200 $O/bench_512x64.json; echo
+mkdir -p gpurun_out/r5o
+O=gpurun_out/r5o
 {
-echo "== scripts/fuzz_modes.py 420 s seed 64 (final library)"
-python scripts/fuzz_modes.py 420 64 2>&1 | tail -2
-echo "== scripts/fuzz_modes.py 200 s seed 65 with TTCR_FSM_PREFILL=1 (second set of fields on every grid)"
-TTCR_FSM_PREFILL=1 python scripts/fuzz_modes.py 200 65 2>&1 | tail -2
-echo "== scripts/fuzz_pairing.py 160 s"
-python scripts/fuzz_pairing.py 160 2>&1 | tail -1
-echo "== scripts/piped_check.py 24 cases seed 78 (pipelined kernel against the default kernel)"
-python scripts/piped_check.py --cases 24 --no-time --seed 78 2>&1 | tail -1
-} > $O/fuzz.txt 2>&1
-cat $O/fuzz.txt
+echo "== the 64 sources of the bench, two sweep-iterations (scripts/lone_skip.py 512 64, ITERS=2): host-side tuning switches of the final library, one box"
+ITERS=2 python scripts/lone_skip.py 512 64 | sed "s/^/default: /"
+TTCR_FSM_PRE_MIN=99 ITERS=2 python scripts/lone_skip.py 512 64 | sed "s/^/no sampled counters (PRE): /"
+TTCR_FSM_WGS=768 ITERS=2 python scripts/lone_skip.py 512 64 | sed "s/^/768 workgroups: /"
+TTCR_FSM_WGS=1024 ITERS=2 python scripts/lone_skip.py 512 64 | sed "s/^/1024 workgroups: /"
+TTCR_FSM_TIME_ORDER_BELOW=64 ITERS=2 python scripts/lone_skip.py 512 64 | sed "s/^/units in start-time order: /"
+ITERS=2 python scripts/lone_skip.py 512 64 | sed "s/^/default again: /"
+} > $O/headline_switches.txt 2>&1
+cat $O/headline_switches.txt
