@@ -284,8 +284,12 @@ class GridT : public GridBase {
     size_t xs_lds_bytes = 40000;
     int xs_lds_below = 2;
     size_t xs_dyn_lds(int batch) const { return (dim == 3 && stage == 0 && batch < xs_lds_below) ? xs_lds_bytes : 0; }
-    int time_order_below = 17; // fewer batch entries (slot groups / slots) than this in a batch: the whole-iteration launch hands its units out in the
-                               // order of their expected start times instead of sweep by sweep (build_persistent_lists)
+    int time_order_below = 1 << 30; // fewer batch entries (slot groups / slots) than this in a batch: the whole-iteration launch hands its units out in the
+                               // order of their expected start times instead of sweep by sweep (build_persistent_lists).  Until round 5: 17 -- with
+                               // the kernels of round 5 the start-time order wins at every size measured (512^3, two sweep-iterations: 64 sources
+                               // 169.8 -> 166.8 ms, 34 sources 99.6 -> 96.0, 48: 134.4 -> 133.8; rough model, 64 sources to convergence 2 004 ->
+                               // 1 917 ms; 256^3 x 24 sources 8.17 -> 7.67 ms per sweep-iteration; 2-D 4096^2 x 64 18.5 -> 18.4;
+                               // profiles/r05/experiment_ticket_order.txt)
     DevBuf<T> d_gather;      // scratch for de-interleaving one field
     DevBuf<T> d_rsrc, d_rt0;  // source points / origin times of the source whose rays are traced
     DevBuf<int> d_rstat;
