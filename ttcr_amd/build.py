@@ -7,6 +7,7 @@ which a fused multiply-add would not (ttcr_amd/csrc/fsm_kernels.h header).
 Two translation units, compiled to objects under ttcr_amd/csrc/_obj and linked:
   fsm_capi.hip    the C ABI, the host side and every kernel but one
   fsm_piped.hip   the pipelined sweep kernel (fsm_piped_kernels.h)
+  fsm_fast.hip    the sweep kernels with tolerance-grade arithmetic (option "arith" = 1)
 """
 import os
 import shutil
@@ -19,7 +20,8 @@ LIB = os.path.join(HERE, "libttcr_amd.so")
 INC = os.path.join("..", "..", "include", "ttcr_amd.h")
 # source -> (extra flags, files it is compiled from)
 UNITS = {
-    "fsm_capi.hip": ([], ["fsm_capi.hip", "fsm_kernels.h", "fsm_piped_api.h", "fsm_march_levels.inc", INC]),
+    "fsm_capi.hip": ([], ["fsm_capi.hip", "fsm_kernels.h", "fsm_piped_api.h", "fsm_fast_api.h", "fsm_march_levels.inc", INC]),
+    "fsm_fast.hip": ([], ["fsm_fast.hip", "fsm_fast_api.h", "fsm_kernels.h", "fsm_march_levels.inc"]),
     "fsm_piped.hip": ([], ["fsm_piped.hip", "fsm_piped_kernels.h", "fsm_piped_api.h", "fsm_kernels.h"]),
 }
 SOURCES = list(UNITS)

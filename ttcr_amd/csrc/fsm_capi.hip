@@ -26,6 +26,7 @@
 #include "../../include/ttcr_amd.h"
 #include "fsm_kernels.h"
 #include "fsm_piped_api.h"
+#include "fsm_fast_api.h"
 
 #ifndef FSM_CHUNK3
 #define FSM_CHUNK3 8
@@ -169,6 +170,9 @@ class GridBase {
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
     virtual long long prefill_swap_count() const { return 0; }   // calls that took fields initialised on the side stream (ttcr_fsm_prefill_swaps)
     int lone_chunk = 16;   // option "lone_chunk" / TTCR_FSM_LONE_CHUNK: levels per chunk of the fp32 first-order 3-D kernels with one field per workgroup (8 or 16)
+    int arith = 0;      // option "arith" / TTCR_FSM_ARITH: 0 (default) the reference's arithmetic, results bit-identical to it; 1 tolerance-grade
+                        // fp32 local solvers in the first-order sweeps of fp32 grids (update3_fast / update2_fast, fsm_kernels.h): within
+                        // north_star's 1e-5 s RMS of the reference by orders of magnitude, NOT bit-identical; whole-iteration launches only
     int piped = -1;     // option "piped" / TTCR_FSM_PIPED: the pipelined sweep kernel (fsm_piped_kernels.h) wherever it applies (first-order
                         // 3-D sweeps of fp32 grids with one field per slot, whole-iteration launches, no exact skipping); 1 on, 0 off,
                         // -1 (default): GridT::piped_now
@@ -213,6 +217,10 @@ class GridBase {
         else if (k == "prefill") prefill = (int)value;
         else if (k == "piped") piped = (int)value;
         else if (k == "lone_chunk") lone_chunk = (int)value;
+        else if (k == "arith") {
+            if (value != 0 && value != 1) throw ValueError("option 'arith': 0 (the reference's arithmetic) or 1 (tolerance-grade fp32)");
+            arith = (int)value;
+        }
         else throw ValueError("unknown option '" + k + "'");
     }
     virtual void get_niter(int slot, int* it, int* itw) const {
@@ -489,6 +497,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_PREFILL")) prefill = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_PIPED")) piped = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_LONE_CHUNK")) lone_chunk = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_ARITH")) arith = std::atoi(e) != 0;
         if (const char* e = std::getenv("TTCR_FSM_PIPED_LDS")) piped_lds = (size_t)std::atol(e);   // tuning only
     }
 
@@ -606,7 +615,8 @@ class GridT : public GridBase {
         // fp64 1 source 663.5 / 536.7, 2 sources 757 / 589.  profiles/r05/experiment_chunk_length.txt
         if constexpr (DIM == 3 && C0 == 8) {
             const int below = H == 2 ? weno_c16_below : sizeof(T) == 4 ? std::numeric_limits<int>::max() : f64_c16_below;
-            if (NS == 1 && mode == 2 && lone_chunk == 16 && batch < below && !piped_now(batch)) {
+            // (the tolerance-grade kernels of one field per workgroup exist with chunks of 16 levels only)
+            if (NS == 1 && mode == 2 && (lone_chunk == 16 || fast_now<H>()) && batch < below && !piped_now(batch)) {
                 launch_sweeps_persistent_ns<DIM, H, 1, 16, true>(batch);
                 return;
             }
@@ -688,6 +698,16 @@ class GridT : public GridBase {
             const dim3 gridx((unsigned)std::min<size_t>((size_t)n_patches * batch * ndir, wg_cap));
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             const bool pre = DIM == 2 || batch >= pre_min || dyn_lds > 0;   // counters sampled one chunk ahead (template PRE)
+            if constexpr (std::is_same<T, float>::value && H == 1) {
+                if (fast_now<H>()) {   // tolerance-grade arithmetic: the AR = 1 instantiation of the kernel chosen below (fsm_fast.hip)
+                    const FastCfg fc{DIM, NSV, CH, skip_now(batch), NO_PRE ? false : pre};
+                    last_kernel.insert(last_kernel.size() - 1, ",1");
+                    const hipError_t e = fsm_fast_launch(pa, fc, gridx.x, dyn_lds, stream);
+                    if (e == hipErrorInvalidValue) throw std::logic_error("arith = 1: no such kernel (" + last_kernel + ")");
+                    HIP_CHECK(e);
+                    return;
+                }
+            }
             if constexpr (std::is_same<T, float>::value && DIM == 3 && H == 1 && NSV == 1 && CH == 8 && C::PJ == 16 && C::PK == 16) {
                 if (piped_now(batch)) {
                     last_kernel = "fsm_sweep_piped";
@@ -714,6 +734,7 @@ class GridT : public GridBase {
             HIP_CHECK(hipGetLastError());
             return;
         }
+        if (fast_now<H>()) throw ValueError("option 'arith' = 1 needs whole-iteration launches (option 'mode' = 2)");
         if constexpr (XS_ONLY) throw std::logic_error("launch_sweeps_persistent_ns: whole-iteration launches only");
         else {
         pa.ssh = nullptr;
@@ -981,6 +1002,7 @@ class GridT : public GridBase {
     template <int DIM>
     void launch_sweeps(int batch) {
         using C = TileCfg<T, DIM>;
+        if (fast_now<1>()) throw ValueError("option 'arith' = 1 needs whole-iteration launches (option 'mode' = 2)");
         SweepArgs<T> a;
         a.tt = d_tt.p;
         a.ts = NS;
@@ -1033,7 +1055,11 @@ class GridT : public GridBase {
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
     // the pipelined kernel (fsm_piped_kernels.h): first-order sweeps of a 3-D fp32 grid with one field per slot, whole-iteration
     // launches, every chunk evaluated, byte offsets of a field in 32 bits
+    // tolerance-grade arithmetic applies to the first-order sweeps (H == 1) of fp32 grids
+    template <int H>
+    bool fast_now() const { return sizeof(T) == 4 && H == 1 && arith == 1; }
     bool piped_now(int batch) const {
+        if (arith == 1) return false;
         if (sizeof(T) != 4 || dim != 3 || stage != 0 || NS != 1 || mode != 2 || piped == 0) return false;
         if (skip_now(batch)) return false;
         if (((unsigned long long)n_nodes + 64ull) * 4ull > 0xfff00000ull) return false;

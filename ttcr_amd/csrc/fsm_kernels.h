@@ -229,6 +229,47 @@ __device__ __forceinline__ double update2_xz(double a, double b, double sn, doub
                           ((dx2 + dz2) * (dx2 + dz2)));
 }
 
+// ---- tolerance-grade local solvers (option "arith" = 1; template AR = 1 of the persistent kernels) ---------------------------
+// Same quadratics (ttcr/Grid3Drn.h:2936-2956, ttcr/Grid2Drn.h:945-950), evaluated in fp32 on DIFFERENCES from the smallest
+// neighbour, scaled by 1/fh: with p2 = (a2-a1)/fh, p3 = (a3-a1)/fh
+//     2-D:  t = a1 + fh/2 (p2 + sqrt(2 - p2^2))                        taken when p2 < 1 (the reference's t1 > a2)
+//     3-D:  t = a1 + fh/3 (p2 + p3 + sqrt(3 - p2^2 - p3^2 - (p3-p2)^2))  taken when p3^2 + (p3-p2)^2 < 1, which in exact
+//           arithmetic IS the reference's t2 > a3 (update3 above) -- decided before any root, so ONE v_sqrt_f32 per update
+// Both discriminants are > 1 wherever their branch is taken (no cancellation), the two branches meet continuously at the
+// switch (t2 = t3 = a3), and the scaling makes the result independent of the units of slowness and distance (fh^2 may underflow
+// fp32).  The increment t - a1 is good to a few ulp OF ITSELF, the sum rounds once like the reference's final conversion: a
+// result differs from the reference's by at most an ulp of t, and only where the increment's error straddles a rounding
+// boundary.  v_rcp_f32 / v_sqrt_f32 are the 1-ulp hardware approximations; the ~480 cycles of the fp64 chain of a level
+// become ~100.  NOT bit-identical to the reference: opt-in, within north_star's 1e-5 s RMS by orders of magnitude
+// (tests/test_arith_mode_gpu.py).  fh == 0: p = NaN or inf, the 1-D value a1 + 0 is taken like in the reference.
+__device__ __forceinline__ float update3_fast(float ax, float ay, float az, float s, float dx) {
+    const float a1 = __builtin_fminf(__builtin_fminf(ax, ay), az);
+    const float a3 = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+    const float a2 = __builtin_amdgcn_fmed3f(ax, ay, az);
+    const float fh = s * dx;
+    const float rfh = __builtin_amdgcn_rcpf(fh);
+    const float p2 = (a2 - a1) * rfh, p3 = (a3 - a1) * rfh;
+    const float e = p3 - p2;
+    const float q = __builtin_fmaf(p3, p3, e * e);
+    const float n2 = __builtin_fmaf(-p2, p2, 2.0f);
+    const bool s3 = q < 1.0f;
+    const float disc = s3 ? (n2 + 1.0f) - q : n2;
+    const float root = __builtin_amdgcn_sqrtf(disc);
+    const float psum = s3 ? p2 + p3 : p2;
+    const float w = fh * (s3 ? (1.0f / 3.0f) : 0.5f);
+    const float t = __builtin_fmaf(w, psum + root, a1);
+    return p2 < 1.0f ? t : a1 + fh;
+}
+__device__ __forceinline__ float update2_fast(float a, float b, float s, float dx) {
+    const float fh = s * dx;
+    const float rfh = __builtin_amdgcn_rcpf(fh);
+    const float m = __builtin_fminf(a, b);
+    const float p = __builtin_fabsf(a - b) * rfh;
+    const float root = __builtin_amdgcn_sqrtf(__builtin_fmaf(-p, p, 2.0f));
+    const float t = __builtin_fmaf(0.5f * fh, p + root, m);
+    return p < 1.0f ? t : m + fh;
+}
+
 // ---- sweep-tile kernel ---------------------------------------------------------------------
 // Unified 3-D / 2-D geometry: "fast" axis F (memory stride 1), "mid" axis J (stride NF),
 // "slow" axis K (stride NF*NJ).  3-D: F=x, J=y, K=z.  2-D (z-fastest): F=z, J=x, NK=1.
@@ -909,8 +950,9 @@ __host__ __device__ constexpr bool fsm_looped(bool is3d, int h) { return is3d &&
 
 __device__ __forceinline__ int kmaxp_of(int k0, int NK, int PK) { return (k0 + PK < NK ? k0 + PK : NK) - 1; }
 // One work unit: the body of fsm_sweep_persistent below.  Returns false when the tickets of the launch have run out.
-template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE>
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE, int AR = 0>
 __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
+    static_assert(AR == 0 || (std::is_same<T, float>::value && H == 1), "tolerance-grade arithmetic: fp32 first-order kernels");
     constexpr bool LOOPED = fsm_looped(IS3D, H);   // the workgroup comes back for another unit (see fsm_sweep_persistent)
     using P = Pack<T, NS>;
     constexpr int NT = PJ * PK;
@@ -1967,7 +2009,7 @@ __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
 // workgroups is one for resident ones: a workgroup only waits for units with lower tickets, and those are running or done.
 // The WENO stage and the 2-D kernels keep one workgroup per unit: their units are long and alike, and the loop costs them
 // registers (WENO, one 256^3 source: 365 -> 406 ms looped; 2-D 4096^2 x 64: 17.6 -> 18.2 ms).
-template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE = false>
+template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE = false, int AR = 0>
 #ifndef FSM_WENO_MINW
 #define FSM_WENO_MINW FSM_MINW   // resident workgroups per SIMD asked of the fp32 3-D WENO kernel (one field per workgroup)
 #endif
@@ -1982,10 +2024,10 @@ __global__ __launch_bounds__(PJ* PK, (SKIP && IS3D && H == 1 && NS == 2 && sizeo
             auto kp = __builtin_amdgcn_kernarg_segment_ptr();   // (constant address space)
             asm volatile("" : "+s"(kp));
             // (cast to a generic pointer in sight of the compiler: it still knows the loads are scalar loads of constant memory)
-            if (!fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE>(*(const PersistArgs<T>*)kp)) break;
+            if (!fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE, AR>(*(const PersistArgs<T>*)kp)) break;
         }
     } else {
-        fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE>(pa);
+        fsm_sweep_unit<T, PJ, PK, C, IS3D, SKIP, H, NS, XS, PRE, AR>(pa);
     }
 }
 
