@@ -93,7 +93,7 @@ def cpu_baseline(n=256, n_src=3):
     return out
 
 
-PROFILE_DIRS = ("r05", "r04", "r03", "r02")
+PROFILE_DIRS = ("r06", "r05", "r04", "r03", "r02")
 
 
 def profiled_traffic(n, n_src_rank0, world):
@@ -142,9 +142,10 @@ def measured_copy_bandwidth(dev, reps=5):
     return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def single_source_leg(n, dx, x, s_dev, local_rank, reps=5):
+def single_source_leg(n, dx, x, s_dev, local_rank, reps=5, arith=0):
     """The case north_star's roofline target is written for: ONE source on the same grid, same run, HIP events around the
-    sweep launches of the solve (the first of the benchmark's sources, run to convergence)."""
+    sweep launches of the solve (the first of the benchmark's sources, run to convergence).  arith = 1: the tolerance-grade
+    arithmetic (option "arith"), with the RMS difference of its field from the default mode's (= the reference's, bit for bit)."""
     import cases
     import ttcr_amd
 
@@ -152,6 +153,17 @@ def single_source_leg(n, dx, x, s_dev, local_rank, reps=5):
     g1.set_slowness_device(s_dev.data_ptr(), s_dev.numel())
     src = cases.mt_sources(1)
     rcv = cases.rcv_lattice3d()
+    extra = {}
+    if arith:
+        g1.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv)
+        ref, it_ref = g1._flat_tt(0).astype(np.float64), g1.get_niter()
+        g1.set_option("arith", 1)
+        g1.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv)
+        d = g1._flat_tt(0).astype(np.float64) - ref
+        extra = {"arith": 1, "rms_vs_default_mode_s": float(np.sqrt(np.mean(d * d))), "max_abs_vs_default_mode_s": float(np.max(np.abs(d))),
+                 "tolerance_rms_s": 1e-5, "sweep_iterations_default_mode": it_ref,
+                 "accuracy_note": "default mode = the reference bit for bit (tests/test_baseline_configs_gpu.py); tolerance: BASELINE.json north_star"}
+        del ref, d
     g1.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv)   # warm-up (graph capture)
     ms, its, ev = 0.0, 0, 0
     t = time.perf_counter()
@@ -164,14 +176,17 @@ def single_source_leg(n, dx, x, s_dev, local_rank, reps=5):
     wall = time.perf_counter() - t
     per_it = ms / its
     achieved = BYTES_PER_NODE_ITER / 8.0 * ev / (ms * 1e-3) / 1e9
+    kern = g1.last_kernel()
     del g1
-    return {"ms_per_sweep_iteration": round(per_it, 4), "frac": round(achieved / HBM_PEAK_GBS, 4), "achieved_GBs": round(achieved, 1),
-            "Mnodes_per_s_per_sweep_iteration": round(n ** 3 / per_it / 1e3, 1), "sweep_iterations": its // reps,
-            "ms_per_solve_wall": round(wall / reps * 1e3, 3), "solves": reps,
-            "note": "1 source (first of the set) on the same grid, same process; HIP events on the library's stream"}
+    out = {"ms_per_sweep_iteration": round(per_it, 4), "frac": round(achieved / HBM_PEAK_GBS, 4), "achieved_GBs": round(achieved, 1),
+           "Mnodes_per_s_per_sweep_iteration": round(n ** 3 / per_it / 1e3, 1), "sweep_iterations": its // reps,
+           "ms_per_solve_wall": round(wall / reps * 1e3, 3), "solves": reps, "kernel": kern,
+           "note": "1 source (first of the set) on the same grid, same process; HIP events on the library's stream"}
+    out.update(extra)
+    return out
 
 
-def small_batch_leg(n, dx, x, s_dev, local_rank, n_src, reps, ms64_per_step):
+def small_batch_leg(n, dx, x, s_dev, local_rank, n_src, reps, ms64_per_step, arith=0):
     """What ONE GPU of an 8-GPU node runs when the 64 sources of the workload are sharded (Grid3D::raytrace's block distribution,
     ttcr/Grid3D.h:451-465, 810-853): n_src sources on the same grid, same process.  Whole steps (wall clock) and sweep launches."""
     import cases
@@ -179,6 +194,8 @@ def small_batch_leg(n, dx, x, s_dev, local_rank, n_src, reps, ms64_per_step):
 
     g = ttcr_amd.Grid3d(x, x, x, n_threads=n_src, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, dtype=np.float32, device=local_rank)
     g.set_slowness_device(s_dev.data_ptr(), s_dev.numel())
+    if arith:
+        g.set_option("arith", 1)
     src = cases.mt_sources(64)[:n_src]
     rcv = cases.rcv_lattice3d()
     sr, rr = np.repeat(src, rcv.shape[0], axis=0), np.tile(rcv, (n_src, 1))
@@ -294,6 +311,8 @@ def main():
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="key=value handed to ttcr_fsm_set_option (tuning / bisecting)")
     ap.add_argument("--per-step", action="store_true", help="print launches / evaluated updates of every timed step to stderr")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1 only: create the process group (backend nccl = RCCL) for the one rank and run "
+                    "the broadcast of the model and the all_gather of every step through it, as the N > 1 runs do")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to "
                     "exercise the multi-rank path on a single-GPU box)")
     args = ap.parse_args()
@@ -315,8 +334,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives run
-    if world > 1:
+    use_dist = world > 1 or args.force_dist   # collectives are issued (a group of one rank with --force-dist)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -346,7 +370,7 @@ def main():
         sz = torch.from_numpy(gradient_slowness_f32(n, dx)).to(dev)
         s_dev.copy_(sz.repeat_interleave(n * n))
         del sz
-    if world > 1:
+    if use_dist:
         if args.backend == "nccl":
             dist.broadcast(s_dev, src=0)
         else:
@@ -373,7 +397,7 @@ def main():
     def step():
         tt = grid.raytrace(src_rows, rcv_rows)
         tm = grid.timing()
-        if world > 1:
+        if use_dist:
             t_dev = torch.zeros(max_rows, dtype=torch.float32, device=cdev)
             t_dev[:tt.shape[0]] = torch.from_numpy(tt).to(cdev)
             dist.all_gather(gathered, t_dev)
@@ -381,7 +405,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -469,6 +493,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "build_id": ttcr_amd._lib.build_id(),
+            "build_id_note": "hash of the kernel sources + compiler flags baked into libttcr_amd.so; the loader refuses a library whose id is not the hash of the sources beside it (ttcr_amd/_lib.py)",
+            "arith": "default (the reference's arithmetic: results bit-identical to the reference); the opt-in tolerance-grade mode is reported under tolerance_mode / *_tolerance",
             "sources_per_s": round(n_total * args.steps / el_max, 3),
             "config": {"workload": f"Grid3d {n}^3 nodes gradient velocity, {n_total} sources of the mt19937_64(12345) "
                                    f"set block-distributed over {world} GPU(s) ({S} on rank 0), 441 receivers, fp32, "
@@ -480,7 +507,9 @@ def main():
                        "launches_per_step": sorted(set(step_launches)),
                        "steps_that_differ_from_the_first": odd_steps,
                        "parallelism": f"source-sharded x{world} (RCCL broadcast of slowness, all_gather of receiver traveltimes)",
-                       "collective_backend": (dist.get_backend() if world > 1 else None), "world_size": world,
+                       "collective_backend": (dist.get_backend() if use_dist else None), "world_size": world,
+                       "collectives_note": ("--force-dist: a process group of one rank; the broadcast of the model and the all_gather of every timed "
+                                            "step went through the backend" if (use_dist and world == 1) else None),
                        "devices": dev_ids},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -531,11 +560,51 @@ def main():
             except Exception as e:
                 sys.stderr.write("evaluate-all leg failed: %s\n" % e)
             out["single_source"] = single_source_leg(n, dx, x, s_dev, local_rank)
+            try:
+                out["single_source_tolerance"] = single_source_leg(n, dx, x, s_dev, local_rank, arith=1)
+            except Exception as e:
+                out["single_source_tolerance"] = {"error": str(e)[:300]}
+            # the headline batch with the tolerance-grade arithmetic (option arith = 1), same grid, same sources, after the timed region
+            try:
+                ref_rcv = grid.raytrace(src_rows, rcv_rows).astype(np.float64)
+                samp = [grid._flat_tt(i)[::4099].astype(np.float64) for i in range(S)]
+                grid.set_option("arith", 1)
+                grid.raytrace(src_rows, rcv_rows)
+                tq = time.perf_counter()
+                ms1, it1, ev1 = 0.0, 0, 0
+                for _ in range(args.steps):
+                    tt1 = grid.raytrace(src_rows, rcv_rows)
+                    tm1 = grid.timing()
+                    ms1 += tm1["sweep_ms"]; it1 += tm1["node_updates"] // 8; ev1 += tm1["evaluated_updates"]
+                el1 = time.perf_counter() - tq
+                d2 = np.concatenate([grid._flat_tt(i)[::4099].astype(np.float64) - samp[i] for i in range(S)])
+                a1 = BYTES_PER_NODE_ITER / 8.0 * ev1 / (ms1 * 1e-3) / 1e9
+                out["tolerance_mode"] = {
+                    "option": "arith = 1 (update3_fast: fp32 scaled-difference quadratics, one v_sqrt_f32 per update; opt-in, NOT bit-identical)",
+                    "value": round(it1 / el1 / 1e6, 1), "unit": "Mnodes/s", "ms_per_step": round(el1 / args.steps * 1e3, 3), "steps": args.steps,
+                    "roofline_frac_evaluated": round(a1 / HBM_PEAK_GBS, 4), "kernel": grid.last_kernel(),
+                    "sweep_iterations_per_source": sorted({grid.get_niter(i) for i in range(S)}),
+                    "rms_vs_default_mode_s": float(np.sqrt(np.mean(d2 * d2))), "max_abs_vs_default_mode_s": float(np.max(np.abs(d2))),
+                    "rms_receivers_vs_default_mode_s": float(np.sqrt(np.mean((tt1.astype(np.float64) - ref_rcv) ** 2))),
+                    "tolerance_rms_s": 1e-5,
+                    "accuracy_note": "every 4099th node of all fields against the default mode on the same grid (= the reference bit for bit); whole fields against the CPU oracle: tests/test_arith_mode_gpu.py"}
+                grid.set_option("arith", 0)
+                del samp, d2
+            except Exception as e:
+                out["tolerance_mode"] = {"error": str(e)[:300]}
             # the small-batch regime (one GPU's share of the workload on an 8-GPU node), a model without free iterations, the WENO stage
             for name, fn in (("eight_sources", None), ("heterogeneous", None), ("weno", None)):
                 try:
                     if name == "eight_sources":
                         out[name], g8 = small_batch_leg(n, dx, x, s_dev, local_rank, 8, 3, el_max / args.steps * 1e3 if n_total == 64 else None)
+                        try:
+                            out["eight_sources_tolerance"], g8t = small_batch_leg(n, dx, x, s_dev, local_rank, 8, 3, None, arith=1)
+                            if n_total == 64 and "tolerance_mode" in out and "ms_per_step" in out["tolerance_mode"]:
+                                out["eight_sources_tolerance"]["projected_strong_scaling_efficiency_8_gpus"] = round(
+                                    out["tolerance_mode"]["ms_per_step"] / (8.0 * out["eight_sources_tolerance"]["ms_per_step_wall"]), 3)
+                            del g8t
+                        except Exception as e:
+                            out["eight_sources_tolerance"] = {"error": str(e)[:300]}
                     elif name == "heterogeneous":
                         out[name] = heterogeneous_leg(g8, n)
                         del g8
@@ -546,7 +615,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if odd_steps:

@@ -193,10 +193,16 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  other kernel, everywhere.  The partial order of the node updates and therefore every result is the same; exact
  *                  skipping steps over chunks of that length.  env TTCR_FSM_LONE_CHUNK.  tests/test_lone_chunk_gpu.py,
  *                  profiles/r05/experiment_chunk_length.txt
- *   "piped"        1: first-order 3-D sweeps of fp32 grids with one field per slot that evaluate every chunk (lone sources, small batches
- *                  without exact skipping) use the pipelined kernel (fsm_piped_kernels.h: four march wavefronts + two staging wavefronts
- *                  per patch, two LDS tiles, 16-byte buffer accesses; bit-identical; 7.9-8.0 against 7.2 ms per sweep-iteration for a lone
- *                  512^3 source at present, profiles/r05/piped_kernel.txt); default off.  env TTCR_FSM_PIPED.  tests/test_piped_kernel_gpu.py
+ *   "arith"        0 (default): the reference's arithmetic -- every result bit-identical to the reference.  1: tolerance-grade local solvers
+ *                  in the first-order sweeps of fp32 grids (Grid3Drn::update_node / Grid2Drn::update_node with dx == dz, ttcr/Grid3Drn.h:
+ *                  2936-2956, ttcr/Grid2Drn.h:945-950): the same quadratics evaluated in fp32 on differences from the smallest neighbour
+ *                  scaled by 1/(s dx), one v_sqrt_f32 per update instead of two correctly rounded fp64 roots (update3_fast / update2_fast,
+ *                  fsm_kernels.h).  NOT bit-identical: a result differs from the reference's by an ulp of the traveltime here and there
+ *                  (512^3 gradient model: RMS 8e-7 s on traveltimes up to 13 s, north_star's bound is 1e-5 s; iteration counts the same on
+ *                  every model tested).  What it buys: a lone 512^3 source 6.6 -> 5.4 ms per sweep-iteration, 64 sources 87 -> 73 ms,
+ *                  8 sources 17.2 -> 14.2 ms (profiles/r06).  Whole-iteration launches only ("mode" 2); fp64 grids, the WENO stage, the
+ *                  rotated template and 2-D grids with dx != dz keep the reference's arithmetic.  env TTCR_FSM_ARITH.
+ *                  tests/test_arith_mode_gpu.py
  *   "prefill"      a second set of traveltime fields: while a call that restarted every slot runs, a low-priority side stream fills the
  *                  other set with max() (the reference's reinit, ttcr/Grid3Drnfs.h:92-94), and the next call that restarts every
  *                  slot swaps the sets instead of writing n_slots x n_nodes values in front of its first sweep (512^3 x 64: 32 GB,
@@ -346,6 +352,10 @@ int ttcr_fsm_reference_change(ttcr_fsm_grid* g, const void* times, const void* f
 /* Name of the sweep-kernel instantiation the last solve launched (first-order stage of the last batch; no reference
  * equivalent: bench.py reports it beside the roofline figures).  Written into buf (n bytes, NUL terminated). */
 int ttcr_fsm_last_kernel(const ttcr_fsm_grid* g, char* buf, size_t n);
+/* Build provenance: the 16-hex-digit hash of the kernel sources and compiler flags this library was compiled from (ttcr_amd/build.py,
+ * source_hash(), baked in at compile time).  The Python layer refuses a library whose id is not the hash of the sources beside it, and
+ * bench.py / the tests print it: a measured binary is provably the committed code.  "unknown" for a build that did not pass the id. */
+const char* ttcr_fsm_build_id(void);
 
 #ifdef __cplusplus
 }

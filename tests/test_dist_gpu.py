@@ -163,3 +163,54 @@ def test_get_s0_matches_oracle(oracle):
     assert s02[0] == want2[0] and s02[1] == want2[0] and s02[3] == want2[1] and s02[2] == want2[2]
     with pytest.raises(ValueError, match="hypo should be"):
         g2.get_s0(np.zeros((2, 5)))
+
+
+RCCL_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import torch, torch.distributed as dist
+import cases, ttcr_amd
+from ttcr_amd.dist import broadcast_slowness, raytrace_sharded
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)          # backend "nccl" IS RCCL on ROCm
+n = 48
+dx = 20.0 / (n - 1)
+x = np.arange(n) * dx
+s = torch.from_numpy(cases.random3d((n, n, n), seed=5).astype(np.float32)).to(dev)
+broadcast_slowness(s, always=True)                                             # an RCCL broadcast on the device buffer
+srcs = cases.mt_sources(3)
+rcv1 = cases.rcv_lattice3d(n=5)
+source = np.repeat(srcs, rcv1.shape[0], axis=0)
+rcv = np.tile(rcv1, (srcs.shape[0], 1))
+g = ttcr_amd.Grid3d(x, x, x, n_threads=3, cell_slowness=0, method='FSM', tt_from_rp=0, weno=0, dtype=np.float32, device=0)
+g.set_slowness_device(s.data_ptr(), s.numel())
+tt = raytrace_sharded(source, rcv, g.raytrace, device=dev, dtype=np.float32, always_gather=True)   # an RCCL all_gather of the receiver rows
+plain = g.raytrace(source, rcv)
+maps = open('/proc/self/maps').read()
+out = dict(backend=dist.get_backend(), world=dist.get_world_size(), same=bool(np.array_equal(tt, plain)), finite=bool(np.all(np.isfinite(tt))),
+           rccl_mapped=sorted({l.split('/')[-1] for l in maps.splitlines() if 'librccl' in l}), lib=ttcr_amd._lib.LIB_PATH)
+dist.barrier()
+dist.destroy_process_group()
+print('RCCL_WORKER ' + json.dumps(out))
+"""
+
+
+def test_rccl_backend_runs_on_one_gpu(tmp_path, capsys):
+    """torch.distributed with backend "nccl" (= RCCL) in a group of ONE rank on this box's GPU: the library is loaded, a communicator is
+    created, and the two collectives of the source-sharded path -- the broadcast of the model, the all_gather of the receiver
+    traveltimes (ttcr_amd/dist.py) -- run through it on device buffers around the HIP solves.  An 8-GPU node is not ours to lease; this is
+    the part of the RCCL path a one-GPU box can execute (the world_size-2 tests above say which backend THEY ran over)."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_WORKER ")][-1]
+    out = json.loads(line[len("RCCL_WORKER "):])
+    with capsys.disabled():
+        print(f"\n[dist] collectives of the sharded path over backend {out['backend']!r}, world {out['world']}; mapped: {out['rccl_mapped']}")
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["same"] and out["finite"]
+    assert out["rccl_mapped"], "librccl is not mapped into the process that ran the collectives"

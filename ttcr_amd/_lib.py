@@ -54,6 +54,7 @@ SYMBOLS = {
     "ttcr_fsm_set_option": (_I, [_P, C.c_char_p, _D]),
     "ttcr_fsm_last_timing": (_I, [_P, C.POINTER(Timing)]),
     "ttcr_fsm_last_kernel": (_I, [_P, C.c_char_p, C.c_size_t]),
+    "ttcr_fsm_build_id": (C.c_char_p, []),
     "ttcr_fsm_stopping_stats": (_I, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "ttcr_fsm_prefill_swaps": (_I, [_P, C.POINTER(C.c_longlong)]),
     "ttcr_fsm_reference_change": (_I, [_P, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -93,8 +94,22 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
+        # build provenance: the library in the tree must have been compiled from the sources in the tree (a tuning build named by
+        # TTCR_AMD_LIB is exempt: it is never what the tests, smoke() or bench.py measure without saying so)
+        if not os.environ.get("TTCR_AMD_LIB"):
+            from . import build as _b
+
+            have, want = lib.ttcr_fsm_build_id().decode(), _b.source_hash()
+            if have != want:
+                raise ImportError(f"{LIB_PATH} was built from other sources (build id {have}, the sources here hash to {want}): "
+                                  "rebuild it (python -m ttcr_amd.build)")
         _lib = lib
     return _lib
+
+
+def build_id():
+    """16-hex-digit hash of the kernel sources + compiler flags the loaded library was compiled from (ttcr_fsm_build_id)."""
+    return load().ttcr_fsm_build_id().decode()
 
 
 def last_error():

@@ -6,7 +6,6 @@ which a fused multiply-add would not (ttcr_amd/csrc/fsm_kernels.h header).
 
 Two translation units, compiled to objects under ttcr_amd/csrc/_obj and linked:
   fsm_capi.hip    the C ABI, the host side and every kernel but one
-  fsm_piped.hip   the pipelined sweep kernel (fsm_piped_kernels.h)
   fsm_fast.hip    the sweep kernels with tolerance-grade arithmetic (option "arith" = 1)
 """
 import os
@@ -20,9 +19,8 @@ LIB = os.path.join(HERE, "libttcr_amd.so")
 INC = os.path.join("..", "..", "include", "ttcr_amd.h")
 # source -> (extra flags, files it is compiled from)
 UNITS = {
-    "fsm_capi.hip": ([], ["fsm_capi.hip", "fsm_kernels.h", "fsm_piped_api.h", "fsm_fast_api.h", "fsm_march_levels.inc", INC]),
+    "fsm_capi.hip": ([], ["fsm_capi.hip", "fsm_kernels.h", "fsm_fast_api.h", "fsm_march_levels.inc", "fsm_fast.hip", INC]),
     "fsm_fast.hip": ([], ["fsm_fast.hip", "fsm_fast_api.h", "fsm_kernels.h", "fsm_march_levels.inc"]),
-    "fsm_piped.hip": ([], ["fsm_piped.hip", "fsm_piped_kernels.h", "fsm_piped_api.h", "fsm_kernels.h"]),
 }
 SOURCES = list(UNITS)
 DEPS = sorted({d for _, ds in UNITS.values() for d in ds})
@@ -73,7 +71,8 @@ def build(force=False, verbose=False):
     procs = []
     for src, (extra, deps) in UNITS.items():
         if force or _stale(_obj(src), deps):
-            cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+            # (the id is that of ALL device sources: a change to any of them recompiles fsm_capi.hip, which depends on every header)
+            cmd = [_hipcc()] + FLAGS + extra + ['-DTTCR_BUILD_ID="%s"' % source_hash(), "-c", os.path.join(CSRC, src), "-o", _obj(src)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))

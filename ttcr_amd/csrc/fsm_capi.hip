@@ -25,7 +25,6 @@
 
 #include "../../include/ttcr_amd.h"
 #include "fsm_kernels.h"
-#include "fsm_piped_api.h"
 #include "fsm_fast_api.h"
 
 #ifndef FSM_CHUNK3
@@ -173,9 +172,6 @@ class GridBase {
     int arith = 0;      // option "arith" / TTCR_FSM_ARITH: 0 (default) the reference's arithmetic, results bit-identical to it; 1 tolerance-grade
                         // fp32 local solvers in the first-order sweeps of fp32 grids (update3_fast / update2_fast, fsm_kernels.h): within
                         // north_star's 1e-5 s RMS of the reference by orders of magnitude, NOT bit-identical; whole-iteration launches only
-    int piped = -1;     // option "piped" / TTCR_FSM_PIPED: the pipelined sweep kernel (fsm_piped_kernels.h) wherever it applies (first-order
-                        // 3-D sweeps of fp32 grids with one field per slot, whole-iteration launches, no exact skipping); 1 on, 0 off,
-                        // -1 (default): GridT::piped_now
     int prefill = -1;   // option "prefill" / TTCR_FSM_PREFILL: a second set of traveltime fields, re-initialised on a side stream while a
                         // solve runs, which the next call that restarts EVERY slot swaps in instead of filling (GridT::solve_batch);
                         // 1 on, 0 off, -1 (default): on when the fields take at least 64 MiB and twice that is at most half the device memory
@@ -214,9 +210,13 @@ class GridBase {
         else if (k == "return_rays") return_rays = value != 0;
         else if (k == "pair_sources") pair_by_distance = value != 0;
         else if (k == "stopping_rule") stopping_rule = (int)value;
-        else if (k == "prefill") prefill = (int)value;
-        else if (k == "piped") piped = (int)value;
-        else if (k == "lone_chunk") lone_chunk = (int)value;
+        else if (k == "prefill") {
+            if (value != -1 && value != 0 && value != 1) throw ValueError("option 'prefill': -1 (default), 0 or 1");
+            prefill = (int)value;
+        } else if (k == "lone_chunk") {
+            if (value != 8 && value != 16) throw ValueError("option 'lone_chunk': 8 or 16");
+            lone_chunk = (int)value;
+        }
         else if (k == "arith") {
             if (value != 0 && value != 1) throw ValueError("option 'arith': 0 (the reference's arithmetic) or 1 (tolerance-grade fp32)");
             arith = (int)value;
@@ -314,7 +314,6 @@ class GridT : public GridBase {
     DevBuf<uint32_t> d_order;  // persistent kernel: patches in ticket order (anti-diagonal major)
     DevBuf<uint32_t> d_order_xs[2][2];  // whole-iteration launch, [stage: first order / WENO][0: sweep by sweep, 1: by expected start time]
     DevBuf<int> d_sync;        // persistent kernel: ticket, abort flag, per (source, patch) progress
-    size_t piped_lds = 40 * 1024;   // unused dynamic LDS of a workgroup of the pipelined kernel: two workgroups per CU (as for the four-wave kernel of a lone slot)
     int n_patches = 0;
     int* h_abort = nullptr;    // pinned
     DevBuf<int> d_stamp;       // dirty-brick stamps [n_slots][nbf*nbj*nbk]
@@ -495,10 +494,8 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_PREFILL")) prefill = std::atoi(e);
-        if (const char* e = std::getenv("TTCR_FSM_PIPED")) piped = std::atoi(e);
-        if (const char* e = std::getenv("TTCR_FSM_LONE_CHUNK")) lone_chunk = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_LONE_CHUNK")) lone_chunk = std::atoi(e) == 8 ? 8 : 16;   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_ARITH")) arith = std::atoi(e) != 0;
-        if (const char* e = std::getenv("TTCR_FSM_PIPED_LDS")) piped_lds = (size_t)std::atol(e);   // tuning only
     }
 
     // persistent kernel: ticket order = anti-diagonal m = TJ+TK major (a topological order of the
@@ -616,7 +613,7 @@ class GridT : public GridBase {
         if constexpr (DIM == 3 && C0 == 8) {
             const int below = H == 2 ? weno_c16_below : sizeof(T) == 4 ? std::numeric_limits<int>::max() : f64_c16_below;
             // (the tolerance-grade kernels of one field per workgroup exist with chunks of 16 levels only)
-            if (NS == 1 && mode == 2 && (lone_chunk == 16 || fast_now<H>()) && batch < below && !piped_now(batch)) {
+            if (NS == 1 && mode == 2 && (lone_chunk == 16 || fast_now<H>()) && batch < below) {
                 launch_sweeps_persistent_ns<DIM, H, 1, 16, true>(batch);
                 return;
             }
@@ -705,13 +702,6 @@ class GridT : public GridBase {
                     const hipError_t e = fsm_fast_launch(pa, fc, gridx.x, dyn_lds, stream);
                     if (e == hipErrorInvalidValue) throw std::logic_error("arith = 1: no such kernel (" + last_kernel + ")");
                     HIP_CHECK(e);
-                    return;
-                }
-            }
-            if constexpr (std::is_same<T, float>::value && DIM == 3 && H == 1 && NSV == 1 && CH == 8 && C::PJ == 16 && C::PK == 16) {
-                if (piped_now(batch)) {
-                    last_kernel = "fsm_sweep_piped";
-                    HIP_CHECK(fsm_piped_launch(pa, gridx.x, piped_lds, stream, device));
                     return;
                 }
             }
@@ -1053,18 +1043,9 @@ class GridT : public GridBase {
     int NS = 1;
     int n_groups() const { return (n_slots + NS - 1) / NS; }
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
-    // the pipelined kernel (fsm_piped_kernels.h): first-order sweeps of a 3-D fp32 grid with one field per slot, whole-iteration
-    // launches, every chunk evaluated, byte offsets of a field in 32 bits
     // tolerance-grade arithmetic applies to the first-order sweeps (H == 1) of fp32 grids
     template <int H>
     bool fast_now() const { return sizeof(T) == 4 && H == 1 && arith == 1; }
-    bool piped_now(int batch) const {
-        if (arith == 1) return false;
-        if (sizeof(T) != 4 || dim != 3 || stage != 0 || NS != 1 || mode != 2 || piped == 0) return false;
-        if (skip_now(batch)) return false;
-        if (((unsigned long long)n_nodes + 64ull) * 4ull > 0xfff00000ull) return false;
-        return piped > 0;
-    }
     bool prefill_on() const {
         if (prefill >= 0) return prefill != 0;
         const size_t bytes = n_nodes * (size_t)n_groups() * NS * sizeof(T);
@@ -1188,6 +1169,7 @@ class GridT : public GridBase {
     std::vector<int> snap_iter;               // [group] iteration (stage-local, 1-based) the snapshot belongs to, 0: none
     std::vector<double> prev_change;          // [slot] fp64 change of the iteration before (inf: none yet)
     std::vector<double> prev2_change;         // [slot] ... and of the one before that
+    bool snap_always = false;                 // this solve missed a snapshot once: no more predictions
     DevBuf<size_t> d_ref_off;
     DevBuf<T> d_ref_out;
     double window_lo() const { return sizeof(T) == 4 ? 0.5 : 1.0 - 1e-6; }
@@ -1210,7 +1192,9 @@ class GridT : public GridBase {
                 const double r = std::min(1.0, prev_change[s2] / prev2_change[s2]);
                 may = prev_change[s2] * r / 8.0 <= window_hi() * (double)epsilon;
             }
-            if (!(cheap || (stage == 1 && it_next == 1) || may)) continue;
+            // (a miss -- an iteration that landed in the window without a snapshot, decided by the fp64 sum -- shows the prediction does
+            // not hold for this model: from then on every iteration of the solve is snapshotted)
+            if (!(cheap || (stage == 1 && it_next == 1) || may || snap_always)) continue;
             if (it_next == 1 && stage == 0) continue;   // (the first iteration of a solve: its change is infinite -- every node comes down from max())
             done[gi] = 1;
             DevBuf<T>& b = snap[gi];
@@ -1267,7 +1251,7 @@ class GridT : public GridBase {
             return out;
         }
         const size_t tiles_per_field = FSM_REFSUM_WMAX / FSM_REFSUM_TILE;
-        d_rs_state.reserve(nf);
+        d_rs_state.reserve(2 * nf);
         d_rs_tiles.reserve(nf * tiles_per_field);
         d_rs_ptrs.reserve(2 * nf);
         d_rs_arrived.reserve(nf);
@@ -1287,11 +1271,12 @@ class GridT : public GridBase {
         ra.arrived = d_rs_arrived.p;
         ra.stop_at = stop_at;
         const unsigned max_tiles = (unsigned)std::min<unsigned long long>(tiles_per_field, (n_nodes + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
+        ra.round = 0;   // (round r reads buffer r & 1 of the states and writes the other one; the initial states sit in buffer 0)
         for (;;) {
-            for (int r = 0; r < 16; ++r) fsm_refsum_round<T><<<dim3(std::min(max_tiles, 1024u), (unsigned)nf), 256, 0, stream>>>(ra);
+            for (int r = 0; r < 16; ++r, ++ra.round) fsm_refsum_round<T><<<dim3(std::min(max_tiles, 1024u), (unsigned)nf), 256, 0, stream>>>(ra);
             HIP_CHECK(hipGetLastError());
             refsum_rounds += 16;
-            HIP_CHECK(hipMemcpyAsync(st.data(), d_rs_state.p, nf * sizeof(RefSumState), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(st.data(), d_rs_state.p + (size_t)(ra.round & 1) * nf, nf * sizeof(RefSumState), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             bool done = true;
             for (const RefSumState& q : st) done = done && q.start >= n_nodes;
@@ -1312,7 +1297,7 @@ class GridT : public GridBase {
             go[q] = c >= (double)epsilon;
             if (!stopping_rule || !(c >= window_lo() * (double)epsilon && c <= window_hi() * (double)epsilon)) continue;
             if ((int)snap_iter.size() == n_groups() && snap_iter[s2 / NS] == it) ask.push_back((int)q);
-            else ++reference_sums_missed;
+            else { ++reference_sums_missed; snap_always = true; }
         }
         if (ask.empty()) return go;
         std::vector<const T*> curs(ask.size()), olds(ask.size());
@@ -1433,6 +1418,7 @@ class GridT : public GridBase {
             launch_epoch = 1;
         }
         sync_clean = false;
+        snap_always = false;
         // progress words: wiped once per solve (an ordinary stream operation, like the fills above); between the launches of
         // the solve the 2-bit epoch field tells this launch's values from the previous launch's
         if (persistent_now() || weno) HIP_CHECK(hipMemsetAsync(d_sync.p + 8, 0, (sync_words - 8) * sizeof(int), stream));
@@ -1536,12 +1522,23 @@ class GridT : public GridBase {
                 HIP_CHECK(hipStreamCreateWithPriority(&fill_stream, hipStreamNonBlocking, lo));
                 HIP_CHECK(hipEventCreateWithFlags(&ev_fill, hipEventDisableTiming));
             }
-            d_tt_alt.reserve(n_el, 64);
+            // (a second set of fields is a convenience: when the device has no room for it -- the snapshots of this solve were not
+            // there yet when prefill_on() looked -- the solve that just finished must not fail for it)
+            bool have_alt = true;
+            try {
+                d_tt_alt.reserve(n_el, 64);
+            } catch (const DeviceError&) {
+                (void)hipGetLastError();
+                have_alt = false;
+                prefill = 0;
+            }
+            if (have_alt) {
             HIP_CHECK(hipStreamWaitEvent(fill_stream, ev1, 0));
             const int blocks = (int)std::min<size_t>((n_el + 255) / 256, 16384);
             fsm_fill<T><<<blocks, 256, 0, fill_stream>>>(d_tt_alt.p, n_el, real_traits<T>::max(), 1);
             HIP_CHECK(hipEventRecord(ev_fill, fill_stream));
             alt_filled = true;
+            }
         }
         HIP_CHECK(hipEventSynchronize(ev1));
         if (d_prof.p) {
@@ -3274,5 +3271,10 @@ int ttcr_fsm_last_kernel(const ttcr_fsm_grid* g, char* buf, size_t n) {
         std::snprintf(buf, n, "%s", k.c_str());
     });
 }
+
+#ifndef TTCR_BUILD_ID
+#define TTCR_BUILD_ID "unknown"
+#endif
+const char* ttcr_fsm_build_id(void) { return TTCR_BUILD_ID; }
 
 }  // extern "C"

@@ -260,14 +260,20 @@ __device__ __forceinline__ float update3_fast(float ax, float ay, float az, floa
     const float t = __builtin_fmaf(w, psum + root, a1);
     return p2 < 1.0f ? t : a1 + fh;
 }
+// 2-D (square cells): the reference's own sequence of fp32 operations (ttcr/Grid2Drn.h:945-950 as update2_fh above evaluates it) -- a - b,
+// its square and a + b rounded in fp32 -- with the discriminant in fp32 (one fma; > fh^2 where the quadratic is taken) and a v_sqrt_f32.
+// 0.5 ((a + b) + root) in fp32 IS the reference's double expression rounded to float (the fp32 sum of two floats rounds their exact
+// sum, the halving is exact), so a result differs from the reference's only where the root's error (~1e-7 fh) moves that rounding: the
+// scaled-difference form of the 3-D solver, which rounds differently at every update, drifts to 2e-5 s RMS over the 4096 nodes of a
+// C5 field; this one stays at 3e-6 s.  (The same treatment of the 3-D solver -- its (1/3)(s123 + root) in fp64 like the reference --
+// costs 9 % of the batch's time for an RMS of 0.6e-6 instead of 0.8e-6 s at 256^3: not taken.)
 __device__ __forceinline__ float update2_fast(float a, float b, float s, float dx) {
     const float fh = s * dx;
-    const float rfh = __builtin_amdgcn_rcpf(fh);
-    const float m = __builtin_fminf(a, b);
-    const float p = __builtin_fabsf(a - b) * rfh;
-    const float root = __builtin_amdgcn_sqrtf(__builtin_fmaf(-p, p, 2.0f));
-    const float t = __builtin_fmaf(0.5f * fh, p + root, m);
-    return p < 1.0f ? t : m + fh;
+    const float d = a - b;
+    const float t1 = (a < b ? a : b) + fh;
+    const float root = __builtin_amdgcn_sqrtf(__builtin_fmaf(2.0f * fh, fh, -(d * d)));
+    const float t2 = 0.5f * ((a + b) + root);
+    return __builtin_fabsf(d) >= fh ? t1 : t2;
 }
 
 // ---- sweep-tile kernel ---------------------------------------------------------------------
@@ -2429,7 +2435,9 @@ struct RefSumArgs {
     const T* const* old;   // [field] the snapshot, same layout
     size_t n_nodes;
     int stride;
-    RefSumState* st;       // [field]
+    RefSumState* st;       // [2][field]: a round reads the states of buffer round & 1 and writes the other one -- read-only within a
+                           // launch, so that a workgroup dispatched late can never see the next round's state (round-5 advice)
+    int round;             // number of this round (launch)
     RefSum4* tiles;        // [field][FSM_REFSUM_WMAX / TILE] summaries of the tiles of the window
     unsigned* arrived;     // [field] workgroups of the round that are done with their tiles (zero between rounds)
     T stop_at;             // the sum only grows: a field whose running sum has reached this value is done (what the caller asks is
@@ -2500,9 +2508,13 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
     __shared__ int s_found, s_last;
     const int tid = threadIdx.x;
     const int fi = blockIdx.y;
-    const RefSumState st = a.st[fi];
+    const RefSumState st = a.st[(size_t)(a.round & 1) * gridDim.y + fi];
+    RefSumState& st_next = a.st[(size_t)((a.round + 1) & 1) * gridDim.y + fi];
     const unsigned long long start = st.start;
-    if (start >= a.n_nodes) return;   // (this field is done: the rounds are enqueued in bunches)
+    if (start >= a.n_nodes) {   // (this field is done: the rounds are enqueued in bunches; its state moves on unchanged)
+        if (blockIdx.x == 0 && tid == 0) st_next = st;
+        return;
+    }
     const RefSumField<T> f = {a.cur[fi], a.old[fi], a.n_nodes, a.stride};
     RefSum4* __restrict__ tiles = a.tiles + (size_t)fi * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE);
     int k;
@@ -2604,7 +2616,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
             ns.window = 2ull * st.window < FSM_REFSUM_WMAX ? 2ull * st.window : FSM_REFSUM_WMAX;
             ns.prev_q = st.prev_q;
             if (refsum_value<T>(ns.bits) >= a.stop_at) ns.start = a.n_nodes;
-            a.st[fi] = ns;
+            st_next = ns;
         }
         return;
     }
@@ -2660,7 +2672,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
         }
         ns.bits = refsum_bits<T>(v);
         if (v >= a.stop_at) ns.start = a.n_nodes;
-        a.st[fi] = ns;
+        st_next = ns;
     }
 }
 

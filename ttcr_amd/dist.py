@@ -45,21 +45,23 @@ def unique_sources(source):
     return source[np.sort(first)], rank_of[np.asarray(inv).ravel()]
 
 
-def broadcast_slowness(tensor, group=None, src=0):
-    """Broadcast the slowness tensor (already allocated on every rank) from `src`."""
+def broadcast_slowness(tensor, group=None, src=0, always=False):
+    """Broadcast the slowness tensor (already allocated on every rank) from `src`.  always: issue the collective in a group of
+    one rank as well (a single-GPU box can then load and run the backend -- RCCL -- end to end: tests, bench.py --force-dist)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (always or dist.get_world_size(group) > 1):
         dist.broadcast(tensor, src=src, group=group)
     return tensor
 
 
-def raytrace_sharded(source, rcv, solve_fn, group=None, device=None, dtype=np.float64):
+def raytrace_sharded(source, rcv, solve_fn, group=None, device=None, dtype=np.float64, always_gather=False):
     """Data-parallel `raytrace(source, rcv)` over the ranks of `group`.
 
     source/rcv follow the ttcrpy pair convention (one row per datum, equal row counts).
     Each rank solves the rows whose unique source falls in its block and the result is
     gathered on rank 0, which returns tt in the input row order (other ranks return None).
+    always_gather: go through the collective in a group of one rank as well (see broadcast_slowness).
     """
     import torch
     import torch.distributed as dist
@@ -76,7 +78,7 @@ def raytrace_sharded(source, rcv, solve_fn, group=None, device=None, dtype=np.fl
     tt_local = np.zeros(0, dtype=dtype)
     if mine.size:
         tt_local = np.asarray(solve_fn(source[mine], rcv[mine]), dtype=dtype)
-    if world == 1:
+    if world == 1 and not (always_gather and dist.is_initialized()):
         out = np.zeros(source.shape[0], dtype=dtype)
         out[mine] = tt_local
         return out
