@@ -267,9 +267,10 @@ def heterogeneous_leg(g, n, reps=2):
             "sweep_iterations": sorted({g.get_niter(i) for i in range(n_src)}), "kernel": g.last_kernel(), "steps": reps}
 
 
-def weno_leg(local_rank, n=256):
+def weno_leg(local_rank, n=256, arith=0):
     """The two-stage solver (weno=True, the ttcrpy default: first-order sweeps, then third-order WENO sweeps,
-    ttcr/Grid3Drnfs.h:104-136) on the n^3 gradient model, 1 and 8 sources."""
+    ttcr/Grid3Drnfs.h:104-136) on the n^3 gradient model, 1 and 8 sources.  arith = 2: both stages with the tolerance-grade
+    arithmetic (outside the 1e-5 s bound on grids with the WENO stage: include/ttcr_amd.h, option "arith")."""
     import cases
     import ttcr_amd
 
@@ -280,6 +281,8 @@ def weno_leg(local_rank, n=256):
     for n_src in (1, 8):
         g = ttcr_amd.Grid3d(x, x, x, n_threads=n_src, cell_slowness=0, method="FSM", tt_from_rp=0, weno=1, dtype=np.float32, device=local_rank)
         g.set_slowness(s)
+        if arith:
+            g.set_option("arith", arith)
         src = cases.mt_sources(64)[:n_src]
         rcv = cases.rcv_lattice3d()
         sr, rr = np.repeat(src, rcv.shape[0], axis=0), np.tile(rcv, (n_src, 1))
@@ -294,7 +297,7 @@ def weno_leg(local_rank, n=256):
                                    "sweep_iterations_weno": sorted({g.get_niterw(i) for i in range(n_src)}),
                                    "Mnodes_per_s_per_sweep_iteration": round(its / (wall * 1e-3) / 1e6, 1), "kernel_of_the_last_stage": g.last_kernel()}
         del g
-    out["grid"] = f"{n}^3 nodes, gradient model, fp32, weno=True, tt_from_rp=False"
+    out["grid"] = f"{n}^3 nodes, gradient model, fp32, weno=True, tt_from_rp=False" + (f", option arith = {arith}" if arith else "")
     return out
 
 
@@ -593,7 +596,7 @@ def main():
             except Exception as e:
                 out["tolerance_mode"] = {"error": str(e)[:300]}
             # the small-batch regime (one GPU's share of the workload on an 8-GPU node), a model without free iterations, the WENO stage
-            for name, fn in (("eight_sources", None), ("heterogeneous", None), ("weno", None)):
+            for name, fn in (("eight_sources", None), ("heterogeneous", None), ("weno", None), ("weno_arith2", None)):
                 try:
                     if name == "eight_sources":
                         out[name], g8 = small_batch_leg(n, dx, x, s_dev, local_rank, 8, 3, el_max / args.steps * 1e3 if n_total == 64 else None)
@@ -608,8 +611,10 @@ def main():
                     elif name == "heterogeneous":
                         out[name] = heterogeneous_leg(g8, n)
                         del g8
-                    else:
+                    elif name == "weno":
                         out[name] = weno_leg(local_rank)
+                    else:
+                        out[name] = weno_leg(local_rank, arith=2)
                 except Exception as e:   # (reported, never fatal)
                     out[name] = {"error": str(e)[:300]}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the single-GPU run only

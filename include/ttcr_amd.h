@@ -200,9 +200,14 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  fsm_kernels.h).  NOT bit-identical: a result differs from the reference's by an ulp of the traveltime here and there
  *                  (512^3 gradient model: RMS 8e-7 s on traveltimes up to 13 s, north_star's bound is 1e-5 s; iteration counts the same on
  *                  every model tested).  What it buys: a lone 512^3 source 6.6 -> 5.4 ms per sweep-iteration, 64 sources 87 -> 73 ms,
- *                  8 sources 17.2 -> 14.2 ms (profiles/r06).  Whole-iteration launches only ("mode" 2); fp64 grids, the WENO stage, the
- *                  rotated template and 2-D grids with dx != dz keep the reference's arithmetic.  env TTCR_FSM_ARITH.
- *                  tests/test_arith_mode_gpu.py
+ *                  8 sources 17.2 -> 14.2 ms (profiles/r06).  Whole-iteration launches only ("mode" 2); fp64 grids, the rotated template
+ *                  and 2-D grids with dx != dz keep the reference's arithmetic.  Grids WITH the WENO stage (weno = 1, ttcrpy's default)
+ *                  keep it in both stages under arith = 1: the WENO iteration amplifies an ulp of difference in the first-order field to
+ *                  1e-3 s (the exact WENO stage behind a tolerance-grade first-order stage ends 4e-5 s RMS, 4e-3 s max from the reference:
+ *                  profiles/r06/weno_sensitivity.txt) -- only bit-identical input reproduces the reference there.  2: as 1, and both
+ *                  stages of grids with the WENO stage as well (weno_axis_fast, solve3_literal_fast): OUTSIDE the 1e-5 s bound (RMS up to
+ *                  5e-5 s, max 4e-3 s at 128^3 - 256^3 -- the size of the WENO stage's own response to rounding), for 256^3 solves of
+ *                  240 instead of 319 ms (one source) and 423 instead of 762 ms (eight).  env TTCR_FSM_ARITH.  tests/test_arith_mode_gpu.py
  *   "prefill"      a second set of traveltime fields: while a call that restarted every slot runs, a low-priority side stream fills the
  *                  other set with max() (the reference's reinit, ttcr/Grid3Drnfs.h:92-94), and the next call that restarts every
  *                  slot swaps the sets instead of writing n_slots x n_nodes values in front of its first sweep (512^3 x 64: 32 GB,

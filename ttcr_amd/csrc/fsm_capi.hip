@@ -170,8 +170,9 @@ class GridBase {
     virtual long long prefill_swap_count() const { return 0; }   // calls that took fields initialised on the side stream (ttcr_fsm_prefill_swaps)
     int lone_chunk = 16;   // option "lone_chunk" / TTCR_FSM_LONE_CHUNK: levels per chunk of the fp32 first-order 3-D kernels with one field per workgroup (8 or 16)
     int arith = 0;      // option "arith" / TTCR_FSM_ARITH: 0 (default) the reference's arithmetic, results bit-identical to it; 1 tolerance-grade
-                        // fp32 local solvers in the first-order sweeps of fp32 grids (update3_fast / update2_fast, fsm_kernels.h): within
-                        // north_star's 1e-5 s RMS of the reference by orders of magnitude, NOT bit-identical; whole-iteration launches only
+                        // fp32 local solvers in the first-order sweeps of fp32 grids without the WENO stage (update3_fast / update2_fast,
+                        // fsm_kernels.h): within north_star's 1e-5 s RMS of the reference, NOT bit-identical; 2: the WENO stage too
+                        // (weno_axis_fast; outside that bound, see fast_now); whole-iteration launches only
     int prefill = -1;   // option "prefill" / TTCR_FSM_PREFILL: a second set of traveltime fields, re-initialised on a side stream while a
                         // solve runs, which the next call that restarts EVERY slot swaps in instead of filling (GridT::solve_batch);
                         // 1 on, 0 off, -1 (default): on when the fields take at least 64 MiB and twice that is at most half the device memory
@@ -218,7 +219,8 @@ class GridBase {
             lone_chunk = (int)value;
         }
         else if (k == "arith") {
-            if (value != 0 && value != 1) throw ValueError("option 'arith': 0 (the reference's arithmetic) or 1 (tolerance-grade fp32)");
+            if (value != 0 && value != 1 && value != 2)
+                throw ValueError("option 'arith': 0 (the reference's arithmetic), 1 (tolerance-grade fp32 where it stays within 1e-5 s RMS) or 2 (the WENO stage as well)");
             arith = (int)value;
         }
         else throw ValueError("unknown option '" + k + "'");
@@ -495,7 +497,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_MODE")) mode = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_PREFILL")) prefill = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_LONE_CHUNK")) lone_chunk = std::atoi(e) == 8 ? 8 : 16;   // tuning only
-        if (const char* e = std::getenv("TTCR_FSM_ARITH")) arith = std::atoi(e) != 0;
+        if (const char* e = std::getenv("TTCR_FSM_ARITH")) arith = std::max(0, std::min(2, std::atoi(e)));
     }
 
     // persistent kernel: ticket order = anti-diagonal m = TJ+TK major (a topological order of the
@@ -695,9 +697,11 @@ class GridT : public GridBase {
             const dim3 gridx((unsigned)std::min<size_t>((size_t)n_patches * batch * ndir, wg_cap));
             pa.order = d_order_xs[H == 2 ? 1 : 0][batch < time_order_below ? 1 : 0].p;
             const bool pre = DIM == 2 || batch >= pre_min || dyn_lds > 0;   // counters sampled one chunk ahead (template PRE)
-            if constexpr (std::is_same<T, float>::value && H == 1) {
-                if (fast_now<H>()) {   // tolerance-grade arithmetic: the AR = 1 instantiation of the kernel chosen below (fsm_fast.hip)
-                    const FastCfg fc{DIM, NSV, CH, skip_now(batch), NO_PRE ? false : pre};
+            if constexpr (std::is_same<T, float>::value) {
+                // tolerance-grade arithmetic: the AR = 1 instantiation of the kernel chosen below (fsm_fast.hip); the WENO stage of grids
+                // that keep their fields in pairs (TTCR_FSM_PAIR = 1 on a weno grid: tuning only) has none and keeps the exact kernels
+                if (fast_now<H>() && (H == 1 || NSV == 1)) {
+                    const FastCfg fc{H, DIM, NSV, CH, skip_now(batch), NO_PRE ? false : pre};
                     last_kernel.insert(last_kernel.size() - 1, ",1");
                     const hipError_t e = fsm_fast_launch(pa, fc, gridx.x, dyn_lds, stream);
                     if (e == hipErrorInvalidValue) throw std::logic_error("arith = 1: no such kernel (" + last_kernel + ")");
@@ -724,7 +728,7 @@ class GridT : public GridBase {
             HIP_CHECK(hipGetLastError());
             return;
         }
-        if (fast_now<H>()) throw ValueError("option 'arith' = 1 needs whole-iteration launches (option 'mode' = 2)");
+        if (fast_now<H>() && H == 1) throw ValueError("option 'arith' = 1 needs whole-iteration launches (option 'mode' = 2)");
         if constexpr (XS_ONLY) throw std::logic_error("launch_sweeps_persistent_ns: whole-iteration launches only");
         else {
         pa.ssh = nullptr;
@@ -1043,9 +1047,14 @@ class GridT : public GridBase {
     int NS = 1;
     int n_groups() const { return (n_slots + NS - 1) / NS; }
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
-    // tolerance-grade arithmetic applies to the first-order sweeps (H == 1) of fp32 grids
+    // Tolerance-grade arithmetic (fp32 grids).  arith = 1: the first-order sweeps of grids WITHOUT the WENO stage -- within north_star's
+    // 1e-5 s RMS of the reference.  A grid with the WENO stage keeps the reference's arithmetic in BOTH stages under arith = 1: the WENO
+    // iteration amplifies differences of an ulp in its input field to 1e-3 s (measured, profiles/r06/weno_sensitivity.txt: the exact WENO
+    // stage behind a tolerance-grade first-order stage ends 4e-5 s RMS / 4e-3 s max away from the reference) -- only the bit-identical
+    // first-order field reproduces the reference there.  arith = 2: both stages of such grids as well, outside that bound, for callers
+    // who take the WENO stage's own sensitivity as their tolerance.
     template <int H>
-    bool fast_now() const { return sizeof(T) == 4 && H == 1 && arith == 1; }
+    bool fast_now() const { return sizeof(T) == 4 && (arith == 2 || (arith == 1 && !weno)); }
     bool prefill_on() const {
         if (prefill >= 0) return prefill != 0;
         const size_t bytes = n_nodes * (size_t)n_groups() * NS * sizeof(T);

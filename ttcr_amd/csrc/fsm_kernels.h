@@ -864,6 +864,52 @@ __device__ __forceinline__ double solve3_literal(double a1, double a2, double a3
     return t;
 }
 
+// ---- WENO stage with tolerance-grade arithmetic (option "arith" = 1; the AR = 1 instantiations with H = 2) ----------------------
+// One axis of update_node_weno3 (ttcr/Grid3Drn.h:3084-3196 with weno3_upwind :3047-3075) in fp32.  What keeps it within the tolerance:
+// the smoothness ratios are quotients of squared SECOND differences of traveltimes that differ in their last digits -- they are formed from
+// first differences of neighbours (exact in fp32 wherever the two values lie within a factor of two of each other: everywhere but next to
+// the source), so num and den are the rounded second differences of the stored values, as in the reference's double evaluation.  The
+// one-sided derivative times h is   c +- ((1 - w) (p1 - m1) + w (3 d_near - d_far)) / 2   -- the reference's division by 2 h and
+// multiplication by h cancel.  Quotients by v_rcp_f32 (1 ulp): the weights move by ~1e-7, the derivative by that times the difference of
+// its two stencils.
+__device__ __forceinline__ float weno_axis_fast(float m2, float m1, float c, float p1, float p2, int idx, int n) {
+    const float eps = 1.1920928955078125e-07f;
+    const float d0 = c - m1, d1 = p1 - c, d2 = p2 - p1, dm = m1 - m2;
+    const float den = d1 - d0, nF = d2 - d1, nB = d0 - dm;
+    const float y = __builtin_amdgcn_rcpf(__builtin_fmaf(den, den, eps));
+    const float rF = __builtin_fmaf(nF, nF, eps) * y, rB = __builtin_fmaf(nB, nB, eps) * y;
+    const float wF = __builtin_amdgcn_rcpf(__builtin_fmaf(2.0f * rF, rF, 1.0f));
+    const float wB = __builtin_amdgcn_rcpf(__builtin_fmaf(2.0f * rB, rB, 1.0f));
+    const float d31 = p1 - m1;
+    // (1 - w) d31 + w s = d31 + w (s - d31)
+    const float F = __builtin_fmaf(0.5f, __builtin_fmaf(wF, __builtin_fmaf(3.0f, d1, -d2) - d31, d31), c);
+    const float B = __builtin_fmaf(-0.5f, __builtin_fmaf(wB, __builtin_fmaf(3.0f, d0, -dm) - d31, d31), c);
+    const bool c0 = idx == 0;
+    const bool c1 = !c0 && idx == 1;
+    const bool cn = !c0 && !c1 && idx == n;
+    const bool cm = !c0 && !c1 && !cn && idx == n - 1;
+    float a = cm ? B : F;
+    const float t = c1 ? m1 : (cm ? p1 : B);
+    a = a < t ? a : t;
+    return c0 ? p1 : (cn ? m1 : a);
+}
+// Local solver of the WENO stage (ttcr/Grid3Drn.h:3432-3452): the literal compare / swap network and nested conditions of
+// solve3_literal (NaN and inf axis values travel as they do there), discriminants in fp32 -- the 2-D one as the reference forms it, the
+// 3-D one on differences from the smallest value --, hardware roots.
+__device__ __forceinline__ float solve3_literal_fast(float a1, float a2, float a3, float fh) {
+    if (a1 > a2) { const float w = a1; a1 = a2; a2 = w; }
+    if (a1 > a3) { const float w = a1; a1 = a3; a3 = w; }
+    if (a2 > a3) { const float w = a2; a2 = a3; a3 = w; }
+    const float t1 = a1 + fh;
+    const float df = a1 - a2, d3 = a3 - a1;
+    const float df2 = df * df;
+    const float t2 = 0.5f * ((a1 + a2) + __builtin_amdgcn_sqrtf(__builtin_fmaf(2.0f * fh, fh, -df2)));
+    const float e = d3 + df;
+    const float disc3 = __builtin_fmaf(3.0f * fh, fh, -(df2 + __builtin_fmaf(d3, d3, e * e)));
+    const float t3 = __builtin_fmaf(1.0f / 3.0f, (d3 - df) + __builtin_amdgcn_sqrtf(disc3), a1);
+    return t1 > a2 ? (t2 > a3 ? t3 : t2) : t1;
+}
+
 // ---- persistent sweep kernel, halo width H (1: first-order stage, 2: WENO3 stage) -----------
 #ifndef FSM_POLL_SLEEP
 #define FSM_POLL_SLEEP 2   // s_sleep argument (x64 clocks) between two polls of a progress counter
@@ -958,7 +1004,7 @@ __device__ __forceinline__ int kmaxp_of(int k0, int NK, int PK) { return (k0 + P
 // One work unit: the body of fsm_sweep_persistent below.  Returns false when the tickets of the launch have run out.
 template <typename T, int PJ, int PK, int C, bool IS3D, bool SKIP, int H, int NS, bool XS, bool PRE, int AR = 0>
 __device__ __forceinline__ bool fsm_sweep_unit(const PersistArgs<T>& pa) {
-    static_assert(AR == 0 || (std::is_same<T, float>::value && H == 1), "tolerance-grade arithmetic: fp32 first-order kernels");
+    static_assert(AR == 0 || std::is_same<T, float>::value, "tolerance-grade arithmetic: fp32 kernels");
     constexpr bool LOOPED = fsm_looped(IS3D, H);   // the workgroup comes back for another unit (see fsm_sweep_persistent)
     using P = Pack<T, NS>;
     constexpr int NT = PJ * PK;
