@@ -99,7 +99,7 @@ PROFILE_DIRS = ("r06", "r05", "r04", "r03", "r02")
 def profiled_traffic(n, n_src_rank0, world):
     """HBM bytes per launch (one sweep-iteration of the batch) from the committed rocprofv3 PMC passes of this very command
     (profiles/rNN/traffic.json, written by scripts/pmc_run.sh + scripts/pmc_to_json.py: separate --pmc passes, KB units,
-    gfx950 x2 correction of the read counter calibrated in the same run).  bench.py cannot profile itself; the record is
+    the factors of the two counters calibrated by a 1 GiB copy in the same run).  bench.py cannot profile itself; the record is
     tagged with the hash of the kernel sources it was taken with and is only reported when that hash is the one of the
     library being benchmarked now -- otherwise `traffic` is null rather than stale.  Returns (bytes, source, reads, writes)."""
     try:
@@ -116,7 +116,10 @@ def profiled_traffic(n, n_src_rank0, world):
                 continue
             if not (n == rec["size"] and n_src_rank0 == rec["sources"] and world == 1 and os.environ.get("TTCR_FSM_MODE", "2") == "2"):
                 return None, None, None, None
-            rd, wr = 2.0 * rec["fetch_kb_per_launch"] * 1024.0, rec["write_kb_per_launch"] * 1024.0
+            # (counter values x the factors the calibration copy of the same rocprofv3 run gave: scripts/pmc_to_json.py; records of earlier
+            # rounds carry none: the guide's x2 for FETCH_SIZE on gfx950)
+            rd = float(rec.get("read_factor_used", 2.0)) * rec["fetch_kb_per_launch"] * 1024.0
+            wr = float(rec.get("write_factor_used", 1.0)) * rec["write_kb_per_launch"] * 1024.0
             return rd + wr, "profiles/%s/traffic.json" % d, rd, wr
         return None, note, None, None
     except Exception:
