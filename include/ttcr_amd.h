@@ -216,6 +216,11 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *   "pair_sources" 1 (default): where the grid keeps its fields in pairs (n_slots x patches of a sweep > 6 144, env
  *                  TTCR_FSM_PAIR_UNITS; TTCR_FSM_PAIR = 1 / 0 forces / forbids the pair layout at grid creation) the sources
  *                  of a batch are paired by distance before they share a workgroup two by two
+ *   "pair_layout"  grids whose slots x patches lie between the pairing threshold and 2.5 x that (512^3 nodes: 8 ... 15 slots) change their
+ *                  field layout between calls that restart every slot: pairs while the call before evaluated more than 0.55 of its node
+ *                  updates (rough models: 311 against 360 ms per solve of 8 sources), one field per workgroup on 16-level chunks once it
+ *                  evaluated less (smooth models: 31.5 against 35.5 ms per step), back to pairs above 0.70.  -1 (default): that rule;
+ *                  0 / 1: one field per workgroup / pairs, always.  Results do not depend on the layout.  tests/test_pair_layout_gpu.py
  *   "combine_window_us"  single-source calls from several host threads wait this long for one another before they go
  *                  to the device as one batch (default 200; 0: every call on its own)
  *   "mode"         2: persistent sweep kernel, ONE launch per sweep-iteration: patches ordered by

@@ -9,7 +9,7 @@ import numpy as np, ttcr_amd, cases
 cfg = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 import torch
 _a = torch.ones(1 << 28, dtype=torch.float32, device='cuda'); _b = torch.empty_like(_a)
-for _ in range(3): _b.copy_(_a)
+for _ in range(3): torch.add(_a, 1.0, out=_b)   # (an elementwise kernel, 16 bytes per lane: Tensor.copy_ of a contiguous tensor is a runtime copy instead)
 torch.cuda.synchronize(); del _a, _b; torch.cuda.empty_cache()
 rc3 = cases.rcv_lattice3d()
 if cfg in ('C2', 'W1', 'W8', 'S1', 'E8'):

@@ -18,7 +18,7 @@ for C in ("FETCH_SIZE","WRITE_SIZE"):
             k=r.get("Kernel_Name","?"); tot[k]+=float(r["Counter_Value"]); cnt[k]+=1
     with open("$O/$2_%s_summary.csv"%C, "w") as o:
         o.write("Kernel_Name,Dispatches,Counter,Sum_KB,PerDispatch_KB\n")
-        for k,v in tot.most_common(8): o.write('"%s",%d,%s,%.1f,%.1f\n'%(k,cnt[k],C,v,v/cnt[k]))
+        for k,v in tot.most_common(16): o.write('"%s",%d,%s,%.1f,%.1f\n'%(k,cnt[k],C,v,v/cnt[k]))
 PY
 }
 cd /tmp && export TMPDIR=/tmp

@@ -167,6 +167,7 @@ class GridBase {
     // in node order; parallel: the exact parallel form, else the one-chain kernel (tests compare the two)
     virtual void reference_change_host(const void* times, const void* field, bool parallel, void* out) = 0;
     int pair_by_distance = 1;   // option "pair_sources" (0: every source in the slot the block distribution names)
+    virtual void set_pair_layout(int) {}
     virtual long long prefill_swap_count() const { return 0; }   // calls that took fields initialised on the side stream (ttcr_fsm_prefill_swaps)
     int lone_chunk = 16;   // option "lone_chunk" / TTCR_FSM_LONE_CHUNK: levels per chunk of the fp32 first-order 3-D kernels with one field per workgroup (8 or 16)
     int arith = 0;      // option "arith" / TTCR_FSM_ARITH: 0 (default) the reference's arithmetic, results bit-identical to it; 1 tolerance-grade
@@ -210,6 +211,10 @@ class GridBase {
         else if (k == "interp_vel") interp_vel = value != 0;
         else if (k == "return_rays") return_rays = value != 0;
         else if (k == "pair_sources") pair_by_distance = value != 0;
+        else if (k == "pair_layout") {
+            if (value != -1 && value != 0 && value != 1) throw ValueError("option 'pair_layout': -1 (default), 0 or 1");
+            set_pair_layout((int)value);
+        }
         else if (k == "stopping_rule") stopping_rule = (int)value;
         else if (k == "prefill") {
             if (value != -1 && value != 0 && value != 1) throw ValueError("option 'prefill': -1 (default), 0 or 1");
@@ -279,6 +284,7 @@ class GridT : public GridBase {
     hipEvent_t ev_fill = nullptr;
     long long prefill_swaps = 0;    // calls that found their fields initialised
     long long prefill_swap_count() const override { return prefill_swaps; }
+    void set_pair_layout(int v) override { pair_layout = v; }
     DevBuf<int> d_rslot;
     DevBuf<RaySrc> d_rdesc;
     int weno_ch4_min = 8;  // pair layout: slot groups from which the 3-D WENO stage uses chunks of 4 levels
@@ -411,9 +417,16 @@ class GridT : public GridBase {
             if (const char* e = std::getenv("TTCR_FSM_PAIR_UNITS")) pair_units_min = std::atoll(e);   // tuning only
             const long long patches = dim == 3 ? (long long)((ny + 1 + TileCfg<T, 3>::PJ - 1) / TileCfg<T, 3>::PJ) * ((nz + 1 + TileCfg<T, 3>::PK - 1) / TileCfg<T, 3>::PK) : 0;
             NS = (n_slots >= 2 && dim == 3 && !weno && (long long)n_slots * patches > pair_units_min) ? 2 : 1;
+            // Round 6: between the threshold and 2.5 x the threshold (512^3: 8 ... 15 slots) which layout is faster depends on the MODEL --
+            // smooth (most chunks skipped): one field per workgroup on 16-level chunks, 15.2 against 17.2 ms per sweep-iteration for 8 sources;
+            // rough (most chunks evaluated): pairs, 311 against 360 ms per solve.  Both layouts take the same memory, so such a grid follows
+            // the evaluated fraction of its last call that restarted every slot (choose_layout); option "pair_layout" pins it.
+            ns_window = NS == 2 && (long long)n_slots * patches <= (5 * pair_units_min) / 2;
         }
-        if (const char* e = std::getenv("TTCR_FSM_PAIR")) NS = (std::atoi(e) != 0 && n_slots >= 2) ? 2 : 1;
-        d_tt.reserve(n_nodes * (size_t)n_groups() * NS, 64);
+        if (const char* e = std::getenv("TTCR_FSM_PAIR")) { NS = (std::atoi(e) != 0 && n_slots >= 2) ? 2 : 1; ns_window = false; }
+        if (const char* e = std::getenv("TTCR_FSM_LAYOUT_LO")) layout_lo = std::atof(e);
+        if (const char* e = std::getenv("TTCR_FSM_LAYOUT_HI")) layout_hi = std::atof(e);
+        d_tt.reserve(n_nodes * (size_t)(n_slots + (n_slots & 1)), 64);   // (room for either layout)
         mask_words = (n_nodes + 31) / 32;
         d_mask.reserve(mask_words * (size_t)n_slots);
         d_bbox.reserve(6 * (size_t)n_slots);
@@ -432,7 +445,7 @@ class GridT : public GridBase {
         *h_abort = 0;
         HIP_CHECK(hipHostMalloc((void**)&h_iter, 2 * sizeof(int)));
         HIP_CHECK(hipHostMalloc((void**)&h_evals, sizeof(unsigned long long) * n_slots));
-        HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)n_groups() * NS * sizeof(T), stream));
+        HIP_CHECK(hipMemsetAsync(d_tt.p, 0, n_nodes * (size_t)(n_slots + (n_slots & 1)) * sizeof(T), stream));
 
         if (dim == 3) {
             using C = TileCfg<T, 3>;
@@ -476,7 +489,7 @@ class GridT : public GridBase {
             HIP_CHECK(hipMemset(d_cmap.p, 0, (size_t)n_patches * n_slots * (dim == 3 ? 8 : 4) * 2 * cmap_words * sizeof(unsigned long long)));
             // whole-sweep tallies: one entry per sweep of a solve (both stages); solves with more sweeps simply stop using them
             sw_sweeps = (dim == 3 ? 8 : 4) * (2 * std::min(nitermax, 256) + 2);
-            d_sw.reserve((size_t)sw_sweeps * n_groups());
+            d_sw.reserve((size_t)sw_sweeps * n_slots);   // (one entry per slot group: at most n_slots of them, whichever the layout)
         }
         d_iter.reserve(2);
         d_evals.reserve(n_slots);
@@ -1045,6 +1058,23 @@ class GridT : public GridBase {
     // marches the NS sources of a group together: one address computation, one 8-byte load/store
     // and one LDS access serve both, and the per-level bookkeeping is shared.
     int NS = 1;
+    bool ns_window = false;       // the grid may change its layout between calls (see the constructor)
+    int pair_layout = -1;         // option "pair_layout": -1 (default) by the rule above, 0 one field per workgroup, 1 pairs (grids in the window only)
+    double last_eval_frac = -1;   // evaluated / all node updates of the last batch that restarted every slot (-1: none yet)
+    double layout_lo = 0.55, layout_hi = 0.70;   // pairs -> one field per workgroup below lo, back above hi (TTCR_FSM_LAYOUT_LO / _HI: tests, tuning)
+    // Called at the top of a batch that restarts EVERY slot (no field of an earlier call survives it): pairs (NS = 2) or one field per
+    // workgroup (NS = 1) for this and the following calls.  Nothing else depends on the layout across calls: stamps, change maps, sweep
+    // tallies and snapshots are per solve, the second set of fields is filled with max() whatever its layout, host-side results are per slot.
+    void choose_layout() {
+        if (!ns_window) return;
+        int want = NS;
+        if (pair_layout >= 0) want = pair_layout ? 2 : 1;
+        else if (last_eval_frac >= 0) want = NS == 2 ? (last_eval_frac < layout_lo ? 1 : 2) : (last_eval_frac > layout_hi ? 2 : 1);
+        if (want == NS) return;
+        NS = want;
+        graph_batches[0] = graph_batches[1] = -1;   // (captured launches hold the layout)
+        for (int q = 0; q < n_slots; ++q) phys[q] = q;
+    }
     int n_groups() const { return (n_slots + NS - 1) / NS; }
     T* tt_ptr(int slot) const { return d_tt.p + (size_t)(slot / NS) * n_nodes * NS + slot % NS; }
     // Tolerance-grade arithmetic (fp32 grids).  arith = 1: the first-order sweeps of grids WITHOUT the WENO stage -- within north_star's
@@ -1057,7 +1087,7 @@ class GridT : public GridBase {
     bool fast_now() const { return sizeof(T) == 4 && (arith == 2 || (arith == 1 && !weno)); }
     bool prefill_on() const {
         if (prefill >= 0) return prefill != 0;
-        const size_t bytes = n_nodes * (size_t)n_groups() * NS * sizeof(T);
+        const size_t bytes = n_nodes * (size_t)(n_slots + (n_slots & 1)) * sizeof(T);
         if (bytes < ((size_t)64 << 20)) return false;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
@@ -1524,7 +1554,7 @@ class GridT : public GridBase {
             // workgroup slots and bandwidth from the sweep kernel and was not done when the next call came (512^3 x 64 back to back:
             // 191.8 ms per step instead of 185.7, profiles/r05/README.md); behind them it runs beside the receiver interpolation and
             // whatever the caller does between two calls, and a call that comes at once waits for what is left of it
-            const size_t n_el = n_nodes * (size_t)n_groups() * NS;
+            const size_t n_el = n_nodes * (size_t)(n_slots + (n_slots & 1));   // (room for either layout)
             if (!fill_stream) {
                 int lo = 0, hi = 0;
                 HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1574,12 +1604,15 @@ class GridT : public GridBase {
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         timing.sweep_ms += ms;
+        const long long evaluated_before = timing.evaluated_updates;
         if (was_persistent) {
             HIP_CHECK(hipMemcpy(h_evals, d_evals.p, sizeof(unsigned long long) * n_slots, hipMemcpyDeviceToHost));
             for (int s2 : slot_ids) timing.evaluated_updates += (long long)h_evals[s2];
         } else {
             timing.evaluated_updates += timing.node_updates - node_updates_before;   // every update is evaluated
         }
+        if (nb == n_slots && timing.node_updates > node_updates_before && skip_now(n_groups()))   // (what choose_layout goes by; kernels that skip only)
+            last_eval_frac = (double)(timing.evaluated_updates - evaluated_before) / (double)(timing.node_updates - node_updates_before);
     }
 
     void interp(int slot, int n, const void* pts, void* out) override {
@@ -2418,6 +2451,7 @@ class GridT : public GridBase {
                 // logical -> physical slots; the sources of a block-distributed batch are first paired by distance
                 // (also when the caller names the slots -- the replicas of a multi-device grid, single-source calls of several host
                 // threads that went to the device together: the permutation stays among the slots of the batch)
+                if ((int)sl.size() == n_slots) choose_layout();   // (every slot restarts: the layout may follow the model, see the constructor)
                 if (forced_slot < 0) pair_sources(sl, sr, tx_off, tx.data());
                 for (int& q : sl) q = P(q);
                 {   // (the batch driver takes its entries in ascending slot order)
