@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if want in r["Kernel_Name"] and c not in vals:
             vals[c] = float(r["PerDispatch_KB"]); disp[c] = int(r["Dispatches"]); kern = r["Kernel_Name"]
         # the calibration kernel: torch.add(a, 1.0, out=b) on 2^28 floats -- the elementwise kernel that WRITES 1 GiB per dispatch
-        if "elementwise_kernel" in r["Kernel_Name"] and c == "WRITE_SIZE" and abs(float(r["PerDispatch_KB"]) / float(1 << 20) - 1.0) < 0.25 and "WRITE_SIZE" not in calib:
+        if "elementwise_kernel" in r["Kernel_Name"] and "Fill" not in r["Kernel_Name"] and c == "WRITE_SIZE" and abs(float(r["PerDispatch_KB"]) / float(1 << 20) - 1.0) < 0.25 and "WRITE_SIZE" not in calib:
             calib["WRITE_SIZE"] = (float(r["PerDispatch_KB"]), int(r["Dispatches"]), r["Kernel_Name"])
 if "WRITE_SIZE" in calib:   # the same kernel in the FETCH_SIZE pass
     for r in csv.DictReader(open(os.path.join(d, f"{tag}_FETCH_SIZE_summary.csv"))):
