@@ -78,3 +78,4 @@ cdef extern from "ttcr_amd.h" nogil:
     int ttcr_fsm_slot_l_size(const ttcr_fsm_grid* g, int slot, size_t* n_rows, size_t* nnz)
     int ttcr_fsm_get_slot_l(const ttcr_fsm_grid* g, int slot, long long* row_off, long long* cell, void* v)
     int ttcr_fsm_last_timing(const ttcr_fsm_grid* g, ttcr_fsm_timing* out)
+    const char* ttcr_fsm_build_id()
