@@ -500,6 +500,35 @@ class _Grid3d(_GridBase):
                     np.min(pts[:, 1]) < self._y[0] or np.max(pts[:, 1]) > self._y[-1] or
                     np.min(pts[:, 2]) < self._z[0] or np.max(pts[:, 2]) > self._z[-1])
 
+    def compute_D(self, coord):
+        """compute_D(coord) -> csr_matrix (npts x nparams) of interpolation weights for velocity data points (rgrid.pyx:610-677)"""
+        from . import inversion as _inv
+        coord = np.asarray(coord, dtype=np.float64)
+        if self.is_outside(coord):
+            raise ValueError('Velocity data point outside grid')
+        return _inv.interp_matrix((self._x, self._y, self._z), coord, self.cell_slowness)
+
+    def compute_K(self):
+        """compute_K() -> (Kx, Ky, Kz): second-derivative smoothing matrices on the parameters (rgrid.pyx:679-756)"""
+        from . import inversion as _inv
+        return _inv.smoothing_matrices(self.shape, (self.dx, self.dy, self.dz), order=2)
+
+    def _save_raypaths(self, rays, filename):
+        """rays (list of npts x 3 arrays) as a vtkPolyData of poly-lines (rgrid.pyx:1284-1312)"""
+        from . import io as _io
+        _io.write_vtp_lines(filename, rays)
+
+    @staticmethod
+    def data_kernel_straight_rays(Tx, Rx, grx, gry, grz, centers=False):
+        """data_kernel_straight_rays(Tx, Rx, grx, gry, grz, centers=False) -> L[, (xc, yc, zc)]: straight rays through the cells of
+        the grid with node coordinates grx, gry, grz; tt = L @ slowness (rgrid.pyx:1381-1816)"""
+        from . import inversion as _inv
+        grx, gry, grz = (np.asarray(a, dtype=np.float64) for a in (grx, gry, grz))
+        L = _inv.straight_ray_kernel(Tx, Rx, (grx, gry, grz))
+        if centers:
+            return L, ((grx[1:] + grx[:-1]) / 2, (gry[1:] + gry[:-1]) / 2, (grz[1:] + grz[:-1]) / 2)
+        return L
+
     def get_grid_traveltimes(self, thread_no=0):
         """traveltimes at the grid nodes, shape (nx, ny, nz)  (rgrid.pyx:410-435)"""
         tt = self._flat_tt(thread_no)
@@ -823,6 +852,32 @@ class _Grid2d(_GridBase):
         pts = np.asarray(pts)
         return bool(np.min(pts[:, 0]) < self._x[0] or np.max(pts[:, 0]) > self._x[-1] or
                     np.min(pts[:, 1]) < self._z[0] or np.max(pts[:, 1]) > self._z[-1])
+
+    def compute_D(self, coord):
+        """compute_D(coord) -> csr_matrix (npts x nparams) of interpolation weights for velocity data points (rgrid.pyx:3565-3627)"""
+        from . import inversion as _inv
+        coord = np.asarray(coord, dtype=np.float64)
+        if self.is_outside(coord):
+            raise ValueError('Velocity data point outside grid')
+        return _inv.interp_matrix((self._x, self._z), coord, self.cell_slowness)
+
+    def compute_K(self, order=1):
+        """compute_K(order=1) -> (Kx, Kz): first- or second-derivative smoothing matrices on the parameters (rgrid.pyx:3630-3733)"""
+        from . import inversion as _inv
+        return _inv.smoothing_matrices(self.shape, (self.dx, self.dz), order=order)
+
+    def _save_raypaths(self, rays, filename):
+        """rays (list of npts x 2 arrays, x and z) as a vtkPolyData of poly-lines in the plane y = 0 (rgrid.pyx:4228-4256)"""
+        from . import io as _io
+        _io.write_vtp_lines(filename, rays)
+
+    @staticmethod
+    def data_kernel_straight_rays(Tx, Rx, grx, grz, aniso=False):
+        """data_kernel_straight_rays(Tx, Rx, grx, grz, aniso=False) -> L: straight rays through the cells of the grid with node
+        coordinates grx, grz; tt = L @ slowness, or the x / z components of the segments in two blocks of columns for an elliptically
+        anisotropic medium (rgrid.pyx:4259-4470)"""
+        from . import inversion as _inv
+        return _inv.straight_ray_kernel(Tx, Rx, (np.asarray(grx, dtype=np.float64), np.asarray(grz, dtype=np.float64)), aniso=aniso)
 
     def get_grid_traveltimes(self, thread_no=0):
         """traveltimes at the grid nodes, shape (nx, nz)  (rgrid.pyx:3102-3127)"""
