@@ -1039,3 +1039,7 @@ def Grid2d(x, z, n_threads=1, cell_slowness=1, method='SPM', aniso='iso', eps=1.
 
 
 Grid3d.builder = Grid3d_d.builder
+Grid3d.data_kernel_straight_rays = Grid3d_d.data_kernel_straight_rays   # (rgrid.pyx:5624)
+
+
+Grid2d.data_kernel_straight_rays = Grid2d_d.data_kernel_straight_rays   # (rgrid.pyx:5690)
