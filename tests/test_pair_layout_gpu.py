@@ -85,3 +85,68 @@ def test_layout_follows_the_model_and_results_do_not_depend_on_it(tmp_path, caps
             got = res[k][i]
             assert got["tt"] == ref["tt"] and got["niter"] == ref["niter"] and got["fields"] == ref["fields"] and got["f0"] == ref["f0"], (k, i)
     assert all(v[-1]["kept"] for v in res.values())
+
+
+SKIP_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import cases, ttcr_amd
+n = 64
+dx = 20.0 / (n - 1)
+x = np.arange(n) * dx
+smooth = np.full((n, n, n), 0.4, dtype=np.float32)
+rough = np.random.default_rng(5).uniform(0.25, 1.0, (n, n, n)).astype(np.float32)
+src = cases.mt_sources(1)
+rcv = cases.rcv_lattice3d(n=5)
+grids = {}
+for name, sk in (("auto", -1), ("off", 0), ("on", 1)):
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=1, cell_slowness=0, method='FSM', tt_from_rp=0, weno=0, dtype=np.float32)
+    g.set_option("skip", sk)
+    grids[name] = g
+out = []
+for model, calls in ((smooth, 3), (rough, 11), (smooth, 2)):
+    for g in grids.values(): g.set_slowness(model)
+    for _ in range(calls):
+        rec = {}
+        for name, g in grids.items():
+            tt = g.raytrace(np.repeat(src, rcv.shape[0], axis=0), rcv)
+            tm = g.timing()
+            rec[name] = dict(kernel=g.last_kernel(), frac=tm["evaluated_updates"] / max(tm["node_updates"], 1), niter=g.get_niter(0),
+                             tt=tt.tolist(), s=float(np.sum(g.get_grid_traveltimes(0).astype(np.float64))))
+        out.append(rec)
+print("SKIP_WORKER " + json.dumps(out))
+"""
+
+
+def test_exact_skipping_follows_the_model_in_the_probe_window(tmp_path, capsys):
+    """launches of skip_probe_min ... skip_units_min - 1 work units (fp32, 3-D, first order): exact skipping stays on while the grid's last
+    skipping solve evaluated less than 0.6 of its node updates, goes off above, and is tried again after eight solves without
+    (GridT::skip_default) -- and no result depends on it.  The two thresholds are lowered so that a 64^3 grid (16 patches) sits in the window."""
+    script = tmp_path / "skip_worker.py"
+    script.write_text(SKIP_WORKER % dict(root=ROOT))
+    env = dict(os.environ, TTCR_FSM_SKIP_PROBE_UNITS="8", TTCR_FSM_SKIP_UNITS="32")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("SKIP_WORKER ")][-1][len("SKIP_WORKER "):])
+    skipping = lambda k: k.split(",")[5] == "true"
+    on = [skipping(c["auto"]["kernel"]) for c in out]
+    f = [c["auto"]["frac"] for c in out]
+    with capsys.disabled():
+        print("\n[skip probe] auto grid, call by call (3 x constant, 11 x rough, 2 x constant): skipping", ["on" if v else "off" for v in on])
+        print("    evaluated fraction:", [round(v, 3) for v in f])
+    assert all(skipping(c["on"]["kernel"]) for c in out) and not any(skipping(c["off"]["kernel"]) for c in out)
+    # the rule, replayed
+    want, off_calls = True, 0
+    for i, c in enumerate(out):
+        assert on[i] == want, (i, on, f)
+        if on[i]:
+            want, off_calls = f[i] < 0.6, 0
+        else:
+            off_calls += 1
+            if off_calls >= 8:
+                want, off_calls = True, 0
+    assert not all(on) and on[0] and any(on[4:14])   # the rough model switches it off, the probe after eight calls switches it on once
+    for c in out:
+        for k in ("off", "on"):
+            assert c["auto"]["tt"] == c[k]["tt"] and c["auto"]["niter"] == c[k]["niter"] and c["auto"]["s"] == c[k]["s"]

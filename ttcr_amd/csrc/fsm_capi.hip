@@ -504,6 +504,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_PRE_MIN")) pre_min = std::atoi(e);                     // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_SKIP_UNITS")) skip_units_min = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_SKIP_PROBE_UNITS")) skip_probe_min = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_WGS")) persist_wgs = std::atoi(e);              // tuning only
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
@@ -1103,10 +1104,22 @@ class GridT : public GridBase {
     // (1.03x ... 1.19x from 1 to 64 sources on 1024^2 ... 8192^2 nodes, although the SKIP kernels do not follow the
     // previous sweep up the columns).  TTCR_FSM_SKIP_UNITS: work units per sweep from which the first-order 3-D sweeps skip.
     int skip_units_min = 2048;
+    // Round 6: between 1 024 and 2 048 units (a lone 512^3 source, 2 - 4 sources at 384^3 ...) whether skipping pays depends on the MODEL -- 512^3,
+    // one source, ms per solve without / with: gradient model 13.3 / 12.8 (arith = 1: 10.9 / 9.6), rough 16^3-block model 65.5 / 68.2 (52.2 / 54.9);
+    // 384^3: 9.4 / 9.2 and 32.5 / 35.1 (profiles/r06/lone_skip_models.txt).  Such fp32 launches follow the evaluated fraction of the grid's last
+    // skipping solve: on while it stayed below 0.6, off above, and tried again after eight solves without.
+    int skip_probe_min = 1024;
+    bool probe_skip = true;      // what a launch in that window does now
+    int probe_off_calls = 0;     // solves in the window since skipping was switched off
     int persist_wgs = 2048;   // workgroups of a sweep launch (each takes units until none is left): 8 per CU; 0: one per unit
+    bool in_probe_window(int entries) const {
+        const long long u = (long long)n_patches * entries;
+        return dim == 3 && sizeof(T) == 4 && u >= skip_probe_min && u < skip_units_min;
+    }
     int skip_default(int entries) const {
         if (dim != 3) return 1;
         if (stage == 1) return 1;
+        if (in_probe_window(entries)) return probe_skip ? 1 : 0;
         return (long long)n_patches * entries >= skip_units_min ? 1 : 0;
     }
     bool persistent_now() const { return mode >= 1 || stage == 1; }
@@ -1611,8 +1624,18 @@ class GridT : public GridBase {
         } else {
             timing.evaluated_updates += timing.node_updates - node_updates_before;   // every update is evaluated
         }
-        if (nb == n_slots && timing.node_updates > node_updates_before && skip_now(n_groups()))   // (what choose_layout goes by; kernels that skip only)
+        const bool skipped_now = skip_now(n_groups());
+        if (nb == n_slots && timing.node_updates > node_updates_before && skipped_now)   // (what choose_layout goes by; kernels that skip only)
             last_eval_frac = (double)(timing.evaluated_updates - evaluated_before) / (double)(timing.node_updates - node_updates_before);
+        if (skip < 0 && !weno && in_probe_window((nb + NS - 1) / NS) && timing.node_updates > node_updates_before) {   // (see skip_probe_min)
+            if (skipped_now) {
+                probe_skip = (double)(timing.evaluated_updates - evaluated_before) / (double)(timing.node_updates - node_updates_before) < 0.6;
+                probe_off_calls = 0;
+            } else if (++probe_off_calls >= 8) {
+                probe_skip = true;
+                probe_off_calls = 0;
+            }
+        }
     }
 
     void interp(int slot, int n, const void* pts, void* out) override {
