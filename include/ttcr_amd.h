@@ -251,7 +251,10 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                     were last visited is a no-op, and so is every sweep that follows a sweep without a change --
  *                     exact, fields and iteration counts are unchanged; 0: evaluate every chunk; -1 (default): on
  *                     where it was measured to pay (2-D grids, the WENO stage, first-order 3-D batches with at least 2048 work
- *                     units per sweep -- not a lone first-order 3-D source), see DESIGN.md 4a */
+ *                     units per sweep); fp32 first-order 3-D launches of 1024 ... 2047 units (a lone 512^3 source) follow the model:
+ *                     skipping while the grid's last skipping solve evaluated less than 0.6 of its node updates (smooth models: 13.3 ->
+ *                     12.8 ms per solve), everything evaluated above that (rough models lose 4 - 9 % with it), tried again after eight
+ *                     solves; smaller launches never skip.  DESIGN.md 4a, profiles/r06/lone_skip_models.txt */
 int ttcr_fsm_set_option(ttcr_fsm_grid* g, const char* key, double value);
 
 /* Replaces: the r_data output of the raytrace overloads above (std::vector<std::vector<sxyz<T1>>>&,

@@ -37,7 +37,7 @@ for TAG in r06_512x64 r06_512x64_arith1; do
 done
 (cd $ROOT && python scripts/pmc_to_json.py $O r06_512x64 512 64 $O/traffic.json > /dev/null && python scripts/pmc_to_json.py $O r06_512x64_arith1 512 64 $O/traffic_arith1.json > /dev/null)
 # one process per configuration: kernel stats + the two counter passes
-for CF in S1 S1a E8 E8a C2 C4 C5 W1 W8; do
+for CF in S1 S1a S1d S1da E8 E8a C2 C4 C5 W1 W8; do
   mkdir -p $O/raw_$CF
   C1=${CF%a}; if [ $CF != $C1 ]; then export TTCR_FSM_ARITH=1; else unset TTCR_FSM_ARITH; fi
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_$CF -o r06_$CF -- python $ROOT/scripts/config_one.py $C1 2 > $O/r06_${CF}_run.txt 2>&1
@@ -47,7 +47,7 @@ for CF in S1 S1a E8 E8a C2 C4 C5 W1 W8; do
   done
   summarise $O/raw_$CF r06_$CF
   rm -rf $O/raw_$CF
-  case $C1 in S1|E8) SZ=512;; C5) SZ=4096;; *) SZ=256;; esac
+  case $C1 in S1|S1d|E8) SZ=512;; C5) SZ=4096;; *) SZ=256;; esac
   case $C1 in E8|C4|W8) NS=8;; C5) NS=16;; *) NS=1;; esac
   (cd $ROOT && python scripts/pmc_to_json.py $O r06_$CF $SZ $NS $O/traffic_$CF.json > /dev/null 2>&1)
   grep "^$C1:" $O/r06_${CF}_run.txt | sed "s/^$C1:/$CF:/" | tee -a $O/configs.txt
