@@ -162,6 +162,10 @@ int ttcr_fsm_get_niter(ttcr_fsm_grid* g, int slot, int* niter, int* niterw);
  * iterations that ran are 0).  Here it is the fp64 sum of the decreases of all nodes over the iteration's sweeps (equal to
  * the reference's sum of |T_old - T_new| in exact arithmetic; the reference adds it up sequentially in T1). */
 int ttcr_fsm_get_changes(ttcr_fsm_grid* g, int slot, double* first_order, int n_first, double* weno, int n_weno);
+/* The same iterations as the REFERENCE summed them (ttcr/Grid3Drnfs.h:141-152: sequentially, in node order, in T1), for the iterations
+ * that were decided with that sum itself (options "stopping_rule", "stopping_shortcuts"); NaN for the others.  A value below eps * N is what `change >= epsilon`
+ * saw (:153), bit for bit; one at or above it may have been cut short there (the sum only grows: the decision is taken). */
+int ttcr_fsm_get_reference_changes(ttcr_fsm_grid* g, int slot, double* first_order, int n_first, double* weno, int n_weno);
 
 /* Replaces: getNthreads() (ttcr/Grid3D.h) and the node/cell counts of rgrid.pyx:386-404. */
 int ttcr_fsm_n_slots(const ttcr_fsm_grid* g);
@@ -185,6 +189,15 @@ size_t ttcr_fsm_n_cells(const ttcr_fsm_grid* g);
  *                  2^24 nodes; an iteration that lands in the window without one is decided by the fp64 sum and counted
  *                  (ttcr_fsm_stopping_stats).  0: the fp64 sum alone.  2: as 1 with the sum as ONE chain of additions (the
  *                  round-4 kernel: 0.5 s per 512^3 field; kept as the checker of the parallel form).  tests/test_stopping_rule_gpu.py
+ *                  The sum runs over the non-zero terms alone, in node order (zeros add nothing; in the iterations the rule decides
+ *                  all but 1e-4 ... 5e-2 of the nodes did not change): one pass writes the terms of the fields that were asked for
+ *                  and brings the snapshot up to the current field, a scan and a second pass compact them.
+ *   "stopping_shortcuts"  bits (default 3).  1: on 3-D grids whose sweep kernels keep dirty-brick stamps (exact skipping on), those passes
+ *                  and the snapshots read only the 16^3 bricks that changed since the snapshot was last right.  2: the ordered pass is left
+ *                  out where it cannot change the decision: with M non-zero terms the sequential T1 sum lies within M u / (1 - M u) of the
+ *                  exact sum (u the unit roundoff of T1), which the fp64 sum of decreases gives to 2 (nx + ny + nz) u; `change >= epsilon`
+ *                  is then decided as the reference decides it, and ttcr_fsm_get_reference_changes has no value (NaN) for that
+ *                  iteration.  0: whole fields, every sum (tests, bisecting).  tests/test_stopping_rule_gpu.py
  *   "lone_chunk"   levels per chunk of the 3-D sweep kernels that keep ONE field per workgroup, where the longer chunk is faster (16, default):
  *                  fp32 first-order sweeps of lone sources and of batches below the pairing threshold (512^3: lone source 6.7 instead of
  *                  7.2 ms per sweep-iteration, 4 sources 9.6 instead of 10.6; 256^3 x 4 sources 3.5 instead of 4.3), fp64 first-order

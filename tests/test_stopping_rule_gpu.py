@@ -97,3 +97,96 @@ def test_parallel_form_of_the_sequential_sum(dt):
                 dd = np.abs(old - base).astype(dt)
                 assert a == _seq_sum(dd), (n, rep, kind, a, _seq_sum(dd))
         print(n, dt.__name__, g.stopping_stats())
+
+
+def _solve_all(n, n_src, eps, opts, s, dx=0.25):
+    import ttcr_amd
+
+    x = np.arange(n) * dx
+    g = ttcr_amd.Grid3d(x, x, x, n_threads=n_src, cell_slowness=0, method="FSM", tt_from_rp=0, weno=0, eps=eps, dtype=np.float32)
+    g.set_slowness(s)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    rng = np.random.default_rng(4)
+    src = rng.uniform(0.1, 0.9, (n_src, 3)) * (n - 1) * dx
+    rcv = np.array([[0.0, 0.0, 0.0]])
+    g.raytrace(np.repeat(src, 1, axis=0), np.tile(rcv, (n_src, 1)))
+    out = []
+    for i in range(n_src):
+        out.append((g.get_niter(i), g.get_reference_changes(i)[0], g.get_grid_traveltimes(i).flatten("F")))
+    return out, g.stopping_stats(), src, g.last_kernel()
+
+
+def _same_decisions(got, ref, thr):
+    """Sums handed out by get_reference_changes against the full sums of the same iterations: the NaN pattern is the same, a sum below
+    the threshold is the whole sum bit for bit, one that reached it may have been cut short there (the sum only grows)."""
+    m = ~np.isnan(got)
+    if not np.array_equal(m, ~np.isnan(ref)):
+        return False
+    below = m & (ref < thr)
+    return bool(np.array_equal(got[below], ref[below]) and np.all(got[m & ~below] >= thr))
+
+
+@pytest.mark.parametrize("layout", [1, 0])
+def test_compacted_terms_and_brick_passes_give_the_reference_sum(oracle, layout, monkeypatch):
+    """The default form of the rule -- non-zero terms compacted in node order, the passes over field and snapshot restricted to the
+    bricks the skipping sweep kernels stamped, snapshots brought up to date brick by brick -- against (i) the one-chain sum over whole
+    strided fields with whole-field snapshots (stopping_rule = 2, stopping_shortcuts = 0) and (ii) the reference's own `change` of the
+    same iterations (restatement pinned to the compiled reference): the sums that decided are equal bit for bit, so are the
+    iteration counts.  Eight sources, both field layouts, exact skipping forced on (it is what keeps the stamps)."""
+    n, n_src, eps = 96, 8, 1e-5
+    thr = float(np.float32(eps) * np.float32(n ** 3))            # epsilon *= N in T1 (ttcr/Grid3Drnfs.h:49)
+    s = _model(n, 21)
+    monkeypatch.setenv("TTCR_FSM_PAIR", str(layout))             # (read when a grid is made: two fields per workgroup / one)
+    a, st_a, src, kern = _solve_all(n, n_src, eps, {"skip": 1, "stopping_shortcuts": 1}, s)
+    b, st_b, _, _ = _solve_all(n, n_src, eps, {"skip": 1, "stopping_rule": 2, "stopping_shortcuts": 0}, s)
+    d, st_d, _, _ = _solve_all(n, n_src, eps, {"skip": 1}, s)    # the default: sums that bounds already decide are not computed
+    print(kern, st_a, st_b, st_d, [q[0] for q in a])
+    assert kern.split(",")[7] == ("2" if layout else "1") and kern.split(",")[5] == "true", kern
+    assert st_d["reference_sums"] == st_b["reference_sums"] and st_d["reference_sums_missed"] == 0 and st_d["rounds"] <= st_a["rounds"]
+    for i in range(n_src):
+        assert d[i][0] == b[i][0] and np.array_equal(d[i][2], b[i][2])
+        m = ~np.isnan(d[i][1])
+        assert np.all(~np.isnan(b[i][1][m])) and _same_decisions(d[i][1][m], b[i][1][m], thr), (i, d[i][1], b[i][1])
+    print("sums computed in full by default:", sum(int(np.sum(~np.isnan(q[1]))) for q in d), "of", st_d["reference_sums"])
+    assert st_a["reference_sums"] == st_b["reference_sums"] > 0 and st_a["reference_sums_missed"] == st_b["reference_sums_missed"] == 0
+    asked = 0
+    for i in range(n_src):
+        assert a[i][0] == b[i][0]
+        assert _same_decisions(a[i][1], b[i][1], thr), (i, a[i][1], b[i][1])
+        assert np.array_equal(a[i][2], b[i][2])
+        asked += int(np.sum(~np.isnan(a[i][1])))
+    assert asked == st_a["reference_sums"]
+    sF = s.flatten("F")
+    whole = 0
+    for i in (0, 5):
+        o = oracle.solve3d(np.float32, (n - 1,) * 3, 0.25, (0, 0, 0), sF, src[i:i + 1], eps=eps)
+        assert a[i][0] == o["niter"]
+        ref = np.asarray(o["change"], dtype=np.float64)
+        got = a[i][1]
+        m = ~np.isnan(got)
+        full = np.where(m, ref[:got.size], np.nan)
+        assert m.any() and _same_decisions(got, full, thr), (i, got, ref)
+        whole += int(np.sum(m & (full < thr)))
+        assert np.array_equal(a[i][2], o["tt"])
+    assert whole > 0, "none of the sums compared with the reference's was a whole one"
+
+
+def test_brick_passes_beyond_the_always_snapshot_size(monkeypatch):
+    """The same comparison (i) on a grid above 2^24 values per slot group, where snapshots are taken on prediction only: the first one of
+    a group is a whole copy, the later ones and the passes of the sums go by the stamps."""
+    n, n_src, eps = 208, 2, 1e-5
+    thr = float(np.float32(eps) * np.float32(n ** 3))
+    s = _model(n, 22)
+    monkeypatch.setenv("TTCR_FSM_PAIR", "1")
+    a, st_a, _, kern = _solve_all(n, n_src, eps, {"skip": 1, "stopping_shortcuts": 1}, s)
+    b, st_b, _, _ = _solve_all(n, n_src, eps, {"skip": 1, "stopping_rule": 2, "stopping_shortcuts": 0}, s)
+    d, st_d, _, _ = _solve_all(n, n_src, eps, {"skip": 1}, s)
+    print(kern, st_a, st_b, st_d, [q[0] for q in a])
+    assert kern.split(",")[7] == "2" and kern.split(",")[5] == "true", kern
+    assert [q[0] for q in d] == [q[0] for q in b] and all(np.array_equal(d[i][2], b[i][2]) for i in range(n_src))
+    assert st_a["reference_sums"] == st_b["reference_sums"] > 0 and st_a["reference_sums_missed"] == st_b["reference_sums_missed"] == 0
+    for i in range(n_src):
+        assert a[i][0] == b[i][0]
+        assert _same_decisions(a[i][1], b[i][1], thr), (i, a[i][1], b[i][1])
+        assert np.array_equal(a[i][2], b[i][2])

@@ -48,6 +48,7 @@ SYMBOLS = {
     "ttcr_fsm_compute_slowness": (_I, [_P, _I, _P, _I, _P]),
     "ttcr_fsm_get_niter": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ttcr_fsm_get_changes": (_I, [_P, _I, C.POINTER(_D), _I, C.POINTER(_D), _I]),
+    "ttcr_fsm_get_reference_changes": (_I, [_P, _I, C.POINTER(_D), _I, C.POINTER(_D), _I]),
     "ttcr_fsm_n_slots": (_I, [_P]),
     "ttcr_fsm_n_nodes": (C.c_size_t, [_P]),
     "ttcr_fsm_n_cells": (C.c_size_t, [_P]),

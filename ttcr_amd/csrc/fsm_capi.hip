@@ -153,6 +153,9 @@ class GridBase {
     // point that takes a slot translates.
     std::vector<int> phys;
     int P(int slot) const { return phys.empty() ? slot : phys[slot]; }
+    int stopping_shortcuts = 3; // option "stopping_shortcuts", bits: 1 the passes of the stopping rule over a field and its snapshot read only the bricks
+                                // the sweep kernels stamped as changed, where such stamps are kept; 2 the ordered sum is left out where bounds on
+                                // it already put it on one side of eps * N (GridT::decide_go_on).  0: whole fields, every sum (tests, bisecting)
     int stopping_rule = 1;      // option "stopping_rule": 1 (default) the reference's sequential T1 sum decides wherever it could differ from the
                                 // fp64 sum of decreases, 0 the fp64 sum alone (default: the sequential sum is 1.3e8 dependent additions
                                 // per 512^3 field and iteration it is asked for -- 11.7 s instead of 0.32 s for the heterogeneous bench leg)
@@ -180,6 +183,14 @@ class GridBase {
     // L1 change of every sweep-iteration of the last solve of a slot (what the stopping rule compared with eps * N), first-
     // order stage then WENO stage
     std::vector<std::vector<double>> change_hist, change_histw;
+    // ... and the reference's own sum (sequential, in T1) for the iterations that were decided with it (option stopping_rule; NaN: the others)
+    std::vector<std::vector<double>> ref_hist, ref_histw;
+    virtual void get_reference_changes(int slot, double* first, int n_first, double* wen, int n_weno) const {
+        if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
+        slot = P(slot);
+        for (int q = 0; q < n_first; ++q) first[q] = (!ref_hist.empty() && q < (int)ref_hist[slot].size()) ? ref_hist[slot][q] : std::nan("");
+        for (int q = 0; q < n_weno; ++q) wen[q] = (!ref_histw.empty() && q < (int)ref_histw[slot].size()) ? ref_histw[slot][q] : std::nan("");
+    }
     virtual void get_changes(int slot, double* first, int n_first, double* wen, int n_weno) const {
         if (slot < 0 || slot >= n_slots) throw ValueError("Thread number is larger than number of threads");
         slot = P(slot);
@@ -216,6 +227,7 @@ class GridBase {
             set_pair_layout((int)value);
         }
         else if (k == "stopping_rule") stopping_rule = (int)value;
+        else if (k == "stopping_shortcuts") { if (value < 0 || value > 3 || value != (double)(int)value) throw ValueError("option stopping_shortcuts: 0 ... 3"); stopping_shortcuts = (int)value; }
         else if (k == "prefill") {
             if (value != -1 && value != 0 && value != 1) throw ValueError("option 'prefill': -1 (default), 0 or 1");
             prefill = (int)value;
@@ -1222,6 +1234,34 @@ class GridT : public GridBase {
     std::vector<double> prev_change;          // [slot] fp64 change of the iteration before (inf: none yet)
     std::vector<double> prev2_change;         // [slot] ... and of the one before that
     bool snap_always = false;                 // this solve missed a snapshot once: no more predictions
+    std::vector<int> snap_T;                  // [group] global iteration index the snapshot is the field in front of (-1: none / not to be trusted)
+    bool stamps_ok = false;                   // every iteration of this solve (and stage) so far ran a kernel that keeps the dirty-brick stamps
+    int iter_T = 0;                           // global index of the iteration that runs / has just run (sweep numbers of the stamps: ndir * iter_T + 1 ...)
+    bool stamps_live_for(int entries) const { return (stopping_shortcuts & 1) && dim == 3 && !weno && persistent_now() && skip_now(entries) && n_nodes * (size_t)NS < ((size_t)1 << 31); }
+    // the pass over the fields of group gi and its snapshot (fsm_refsum_terms): terms of the sources asked for (x0 / x1, counts c0 / c1;
+    // all nullptr: the snapshot alone); since_T >= 0: only the bricks that changed in iteration since_T or later
+    void terms_pass(int gi, T* x0, T* x1, unsigned* c0, unsigned* c1, int since_T) {
+        RefTermsArgs<T> ta;
+        ta.cur = d_tt.p + (size_t)gi * n_nodes * NS;
+        ta.old = snap[gi].p;
+        ta.x[0] = x0; ta.x[1] = x1;
+        ta.cnt[0] = c0; ta.cnt[1] = c1;
+        ta.n_nodes = (uint32_t)n_nodes;
+        ta.ns = NS;
+        constexpr int V = 16 / (int)sizeof(T);
+        const size_t n_el = n_nodes * (size_t)NS;
+        const bool vec = n_el % V == 0 && ((uintptr_t)ta.cur | (uintptr_t)ta.old) % 16 == 0;
+        const int nodes_per_vec = vec ? std::max(1, V / NS) : 1;
+        const bool bricks = since_T >= 0 && geom.NF % nodes_per_vec == 0;
+        ta.stamp = bricks ? d_stamp.p + (size_t)gi * n_bricks : nullptr;
+        ta.thr = (dim == 3 ? 8 : 4) * since_T + 1;
+        ta.NF = geom.NF; ta.NJ = geom.NJ; ta.nbf = nbf; ta.nbj = nbj;
+        const unsigned nblk = (unsigned)((n_nodes + FSM_REFSUM_CB - 1) / FSM_REFSUM_CB);
+        const unsigned blocks = std::min(nblk, 8192u);
+        if (vec) fsm_refsum_terms<T, V><<<blocks, 256, 0, stream>>>(ta);
+        else fsm_refsum_terms<T, 1><<<blocks, 256, 0, stream>>>(ta);
+        HIP_CHECK(hipGetLastError());
+    }
     DevBuf<size_t> d_ref_off;
     DevBuf<T> d_ref_out;
     double window_lo() const { return sizeof(T) == 4 ? 0.5 : 1.0 - 1e-6; }
@@ -1249,10 +1289,15 @@ class GridT : public GridBase {
             if (!(cheap || (stage == 1 && it_next == 1) || may || snap_always)) continue;
             if (it_next == 1 && stage == 0) continue;   // (the first iteration of a solve: its change is infinite -- every node comes down from max())
             done[gi] = 1;
+            if (snap_iter[gi] == it_next) continue;     // (brought up to date by the pass that wrote the terms of the last sum: decide_go_on)
             DevBuf<T>& b = snap[gi];
             b.reserve(n_nodes * (size_t)NS);
-            HIP_CHECK(hipMemcpyAsync(b.p, d_tt.p + (size_t)gi * n_nodes * NS, n_nodes * (size_t)NS * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            if ((int)snap_T.size() != n_groups()) snap_T.assign(n_groups(), -1);
+            // (a snapshot that was right in front of an earlier iteration: the bricks that changed since then, by their stamps)
+            if (stamps_ok && snap_T[gi] >= 0 && n_nodes * (size_t)NS < ((size_t)1 << 32)) terms_pass(gi, nullptr, nullptr, nullptr, nullptr, snap_T[gi]);
+            else HIP_CHECK(hipMemcpyAsync(b.p, d_tt.p + (size_t)gi * n_nodes * NS, n_nodes * (size_t)NS * sizeof(T), hipMemcpyDeviceToDevice, stream));
             snap_iter[gi] = it_next;
+            snap_T[gi] = iter_T;
         }
     }
     // The reference's `change` of one field: sum over the nodes, in order, in T1, of abs(times[n] - T[n]).  stopping_rule = 2: the
@@ -1260,8 +1305,11 @@ class GridT : public GridBase {
     // parallel, exactly (fsm_refsum_*, fsm_kernels.h): rounds of a tile scan over a window of the field + one workgroup that finds
     // where the running sum leaves its binade; the window follows the distance between such places.
     DevBuf<RefSumState> d_rs_state;
-    DevBuf<RefSum4> d_rs_tiles;
+    DevBuf<RefSum4<T>> d_rs_tiles;
     DevBuf<T> d_rc_a, d_rc_b;
+    DevBuf<T> d_rs_x, d_rs_xc;               // [asked field][n_nodes, padded] terms of the sums of one decision; the non-zero ones, in order
+    DevBuf<unsigned> d_rs_cnt;               // [asked field][block of FSM_REFSUM_CB nodes] non-zero terms
+    DevBuf<unsigned long long> d_rs_off, d_rs_n, d_rs_n2;   // ... exclusive scan of them; [asked field] number of terms
     void reference_change_host(const void* times, const void* field, bool parallel, void* out) override {
         HIP_CHECK(hipSetDevice(device));
         d_rc_a.reserve(n_nodes);
@@ -1279,7 +1327,9 @@ class GridT : public GridBase {
     // several fields at once: the rounds of all of them run side by side, enqueued in bunches (the state of every field stays on the
     // device between its rounds: start, sum, window; a field that is done lets its later rounds pass)
     // stop_at: a field is done once its running sum has reached this value (the sum only grows; the value returned is then a lower bound)
-    std::vector<T> reference_changes(const std::vector<const T*>& cur, const std::vector<const T*>& old, int stride, bool one_chain, T stop_at) {
+    // d_n: [field] number of terms on the device (compacted fields: fsm_refsum_scan's totals); nullptr: n_nodes each
+    std::vector<T> reference_changes(const std::vector<const T*>& cur, const std::vector<const T*>& old, int stride, bool one_chain, T stop_at,
+                                     const unsigned long long* d_n = nullptr) {
         const size_t nf = cur.size();
         std::vector<T> out(nf, (T)0);
         if (one_chain) {
@@ -1316,22 +1366,38 @@ class GridT : public GridBase {
         RefSumArgs<T> ra;
         ra.cur = d_rs_ptrs.p;
         ra.old = d_rs_ptrs.p + nf;
-        ra.n_nodes = n_nodes;
+        std::vector<unsigned long long> h_n(nf, (unsigned long long)n_nodes);
+        unsigned long long n_max = n_nodes;
+        if (!d_n) {
+            d_rs_n.reserve(nf);
+            HIP_CHECK(hipMemcpyAsync(d_rs_n.p, h_n.data(), nf * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+            d_n = d_rs_n.p;
+        } else {
+            // compacted fields: their lengths size the launches (windows that always reach to the end of the field were tried: fewer
+            // rounds, 176 against 240 per solve of bench.py's heterogeneous leg, but 136 us each against 29 -- the scan is arithmetic)
+            HIP_CHECK(hipMemcpyAsync(h_n.data(), d_n, nf * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            n_max = 0;
+            for (size_t f = 0; f < nf; ++f) n_max = std::max(n_max, h_n[f]);
+            if (n_max == 0) return out;   // (no node changed at all: the sum of no terms)
+        }
+        ra.n = d_n;
         ra.stride = stride;
         ra.st = d_rs_state.p;
         ra.tiles = d_rs_tiles.p;
         ra.arrived = d_rs_arrived.p;
         ra.stop_at = stop_at;
-        const unsigned max_tiles = (unsigned)std::min<unsigned long long>(tiles_per_field, (n_nodes + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
+        const unsigned max_tiles = (unsigned)std::min<unsigned long long>(tiles_per_field, (n_max + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
         ra.round = 0;   // (round r reads buffer r & 1 of the states and writes the other one; the initial states sit in buffer 0)
-        for (;;) {
-            for (int r = 0; r < 16; ++r, ++ra.round) fsm_refsum_round<T><<<dim3(std::min(max_tiles, 1024u), (unsigned)nf), 256, 0, stream>>>(ra);
+        fsm_refsum_head<T><<<(unsigned)nf, 256, 0, stream>>>(ra);   // (... written by the pass over the head of every field)
+        for (int bunch = 16;; bunch = 8) {   // (rounds are enqueued in bunches: a field that is done lets the rest of its bunch pass)
+            for (int r = 0; r < bunch; ++r, ++ra.round) fsm_refsum_round<T><<<dim3(std::min(max_tiles, 1024u), (unsigned)nf), 256, 0, stream>>>(ra);
             HIP_CHECK(hipGetLastError());
-            refsum_rounds += 16;
+            refsum_rounds += bunch;
             HIP_CHECK(hipMemcpyAsync(st.data(), d_rs_state.p + (size_t)(ra.round & 1) * nf, nf * sizeof(RefSumState), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             bool done = true;
-            for (const RefSumState& q : st) done = done && q.start >= n_nodes;
+            for (size_t f = 0; f < nf; ++f) done = done && st[f].start >= h_n[f];
             if (done) break;
         }
         for (size_t f = 0; f < nf; ++f) {
@@ -1343,6 +1409,8 @@ class GridT : public GridBase {
     std::vector<char> decide_go_on(const std::vector<int>& active, int it) {
         std::vector<char> go(active.size(), 0);
         std::vector<int> ask;
+        if ((int)ref_change_last.size() != n_slots) ref_change_last.assign(n_slots, std::nan(""));
+        for (int s2 : active) ref_change_last[s2] = std::nan("");
         for (size_t q = 0; q < active.size(); ++q) {
             const int s2 = active[q];
             const double c = h_change[s2];
@@ -1352,21 +1420,97 @@ class GridT : public GridBase {
             else { ++reference_sums_missed; snap_always = true; }
         }
         if (ask.empty()) return go;
-        std::vector<const T*> curs(ask.size()), olds(ask.size());
-        for (size_t a = 0; a < ask.size(); ++a) {
-            const int s2 = active[ask[a]], gi = s2 / NS;
-            curs[a] = d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS;
-            olds[a] = snap[gi].p + s2 % NS;
+        std::vector<T> res(ask.size());
+        std::vector<char> res_known(ask.size(), 0), res_go(ask.size(), 0);   // the sum itself / the side of eps * N it provably lies on
+        if (stopping_rule == 2 || n_nodes * (size_t)NS >= ((size_t)1 << 32)) {
+            std::vector<const T*> curs(ask.size()), olds(ask.size());
+            for (size_t a = 0; a < ask.size(); ++a) {
+                const int s2 = active[ask[a]], gi = s2 / NS;
+                curs[a] = d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS;
+                olds[a] = snap[gi].p + s2 % NS;
+            }
+            res = reference_changes(curs, olds, NS, stopping_rule == 2, epsilon);   // (asked: change >= epsilon)
+            res_known.assign(ask.size(), 1);
+        } else {
+            // The terms of the fields that were asked for, compact (fsm_refsum_terms: one pass over a group's fields and its snapshot, which
+            // leaves the snapshot equal to the current field -- the one the next iteration would take), then the non-zero ones alone in
+            // node order (fsm_refsum_scan / _compact), then the ordered pass over those.  Up to 16 fields at a time (whole groups).
+            const size_t pitch = (n_nodes + FSM_REFSUM_CB - 1) / FSM_REFSUM_CB * FSM_REFSUM_CB;
+            const unsigned nblk = (unsigned)(pitch / FSM_REFSUM_CB);
+            for (size_t a0 = 0; a0 < ask.size();) {
+                size_t a1 = a0;
+                while (a1 < ask.size() && (a1 - a0 < 15 || (a1 > a0 && active[ask[a1]] / NS == active[ask[a1 - 1]] / NS))) ++a1;
+                const size_t nf = a1 - a0;
+                d_rs_x.reserve(nf * pitch);
+                d_rs_xc.reserve(nf * pitch);
+                d_rs_cnt.reserve(nf * (size_t)nblk);
+                d_rs_off.reserve(nf * (size_t)nblk);
+                d_rs_n.reserve(std::max<size_t>(nf, 64));
+                std::vector<const T*> curs(nf), olds(nf, nullptr);
+                for (size_t a = a0; a < a1; ++a) {
+                    curs[a - a0] = d_rs_xc.p + (a - a0) * pitch;
+                    const int gi = active[ask[a]] / NS;
+                    if (a > a0 && active[ask[a - 1]] / NS == gi) continue;   // (with the source in front of it: `active` is in slot order)
+                    T* xp[2] = {nullptr, nullptr};
+                    unsigned* cp[2] = {nullptr, nullptr};
+                    for (size_t b = a; b < a1 && active[ask[b]] / NS == gi; ++b) {
+                        xp[active[ask[b]] % NS] = d_rs_x.p + (b - a0) * pitch;
+                        cp[active[ask[b]] % NS] = d_rs_cnt.p + (b - a0) * (size_t)nblk;
+                    }
+                    // (the snapshot is the field in front of this iteration: the bricks this iteration changed hold all the terms)
+                    const bool bricks = stamps_ok && (int)snap_T.size() == n_groups() && snap_T[gi] == iter_T;
+                    terms_pass(gi, xp[0], xp[1], cp[0], cp[1], bricks ? iter_T : -1);
+                    snap_iter[gi] = it + 1;
+                    if ((int)snap_T.size() != n_groups()) snap_T.assign(n_groups(), -1);
+                    snap_T[gi] = iter_T + 1;
+                }
+                const dim3 cgrid(std::min(nblk, 4096u), (unsigned)nf);
+                fsm_refsum_scan<0><<<(unsigned)nf, 1024, 0, stream>>>(d_rs_cnt.p, d_rs_off.p, nblk, d_rs_n.p);
+                HIP_CHECK(hipGetLastError());
+                // With M non-zero terms the sequential T1 sum lies within gamma = M u / (1 - M u) of the exact one (recursive summation of
+                // non-negative terms, u the unit roundoff of T1; zeros are added exactly), and the fp64 sum of decreases the sweep kernels
+                // hand over is the exact one to within m: every thread adds the decreases of its nodes of a unit -- at most
+                // NF + NJ + NK of them -- in T1 before they go to the fp64 atomics.  Where these bounds put the reference's sum on one
+                // side of eps * N, `change >= epsilon` is decided as the reference decides it without computing the sum (option
+                // "stopping_shortcuts", bit 1); the ordered pass runs for the rest.
+                std::vector<unsigned long long> h_m(nf);
+                HIP_CHECK(hipMemcpyAsync(h_m.data(), d_rs_n.p, nf * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                std::vector<size_t> need;
+                for (size_t f = 0; f < nf; ++f) {
+                    const double u = 0.5 * (double)std::numeric_limits<T>::epsilon(), mu = (double)h_m[f] * u;
+                    const double c = h_change[active[ask[a0 + f]]], e = (double)epsilon;
+                    if (host_prof) std::fprintf(stderr, "[host]   ask: slot %d iteration %d  fp64 change / (eps N) %.4f  non-zero terms %llu (M u = %.4f)\n", active[ask[a0 + f]], it, c / e, h_m[f], mu);
+                    if (h_m[f] == 0ull) { res[a0 + f] = (T)0; res_known[a0 + f] = 1; continue; }   // (the sum of no terms)
+                    if ((stopping_shortcuts & 2) && stage == 0 && mu < 0.25) {   // (first-order sweeps: a node only ever comes down)
+                        const double g = mu / (1.0 - mu), m = 2.0 * (double)(geom.NF + geom.NJ + geom.NK + 64) * u + 1e-6;
+                        if (c * (1.0 - m) * (1.0 - g) >= e) { res_go[a0 + f] = 1; continue; }
+                        if (c * (1.0 + m) * (1.0 + g) < e) { res_go[a0 + f] = 0; continue; }
+                    }
+                    need.push_back(f);
+                }
+                if (!need.empty()) {
+                    fsm_refsum_compact<T><<<cgrid, 256, 0, stream>>>(d_rs_x.p, d_rs_xc.p, pitch, n_nodes, d_rs_cnt.p, d_rs_off.p, nblk);
+                    HIP_CHECK(hipGetLastError());
+                    std::vector<const T*> c2(need.size()), o2(need.size(), nullptr);
+                    std::vector<unsigned long long> m2(need.size());
+                    for (size_t q = 0; q < need.size(); ++q) { c2[q] = curs[need[q]]; m2[q] = h_m[need[q]]; }
+                    d_rs_n2.reserve(std::max<size_t>(need.size(), 64));
+                    HIP_CHECK(hipMemcpyAsync(d_rs_n2.p, m2.data(), need.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+                    const std::vector<T> r = reference_changes(c2, o2, 1, false, epsilon, d_rs_n2.p);   // (asked: change >= epsilon)
+                    for (size_t q = 0; q < need.size(); ++q) { res[a0 + need[q]] = r[q]; res_known[a0 + need[q]] = 1; }
+                }
+                a0 = a1;
+            }
         }
-        const std::vector<T> res = reference_changes(curs, olds, NS, stopping_rule == 2, epsilon);   // (asked: change >= epsilon)
         for (size_t a = 0; a < ask.size(); ++a) {
-            go[ask[a]] = res[a] >= epsilon;   // `change >= epsilon`, both T1 (ttcr/Grid3Drnfs.h:153)
-            ref_change_last[active[ask[a]]] = (double)res[a];
+            go[ask[a]] = res_known[a] ? res[a] >= epsilon : res_go[a] != 0;   // `change >= epsilon`, both T1 (ttcr/Grid3Drnfs.h:153)
+            if (res_known[a]) ref_change_last[active[ask[a]]] = (double)res[a];
             ++reference_sums;
         }
         return go;
     }
-    std::vector<double> ref_change_last;   // [slot] the reference's sum of the last iteration decided with it (NaN: none)
+    std::vector<double> ref_change_last;   // [slot] the reference's sum of the iteration just decided, if it was decided with it (NaN: not)
 
     // TTCR_FSM_HOST_PROF=1: wall clock of the host-side phases of a call (stderr), tuning only
     bool host_prof = std::getenv("TTCR_FSM_HOST_PROF") != nullptr;
@@ -1450,8 +1594,11 @@ class GridT : public GridBase {
             niter[slot] = 0;
             niterw[slot] = 0;
             if (change_hist.empty()) { change_hist.resize(n_slots); change_histw.resize(n_slots); }
+            if (ref_hist.empty()) { ref_hist.resize(n_slots); ref_histw.resize(n_slots); }
             change_hist[slot].clear();
             change_histw[slot].clear();
+            ref_hist[slot].clear();
+            ref_histw[slot].clear();
         }
         HIP_CHECK(hipGetLastError());
         hp_mark("reinit + initFSM issued");
@@ -1485,6 +1632,8 @@ class GridT : public GridBase {
             prev_change.assign(n_slots, std::numeric_limits<double>::infinity());   // (the first iteration of a stage always runs: no snapshot)
             prev2_change.assign(n_slots, std::numeric_limits<double>::infinity());
             snap_iter.assign(n_groups(), 0);
+            snap_T.assign(n_groups(), -1);
+            stamps_ok = false;
             if ((int)ref_change_last.size() != n_slots) ref_change_last.assign(n_slots, std::nan(""));
             // batch entries: slot groups for the persistent kernel (with a lane mask), slots otherwise
             std::vector<int> groups;
@@ -1508,8 +1657,10 @@ class GridT : public GridBase {
                 HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemcpyAsync(d_lmask.p, h_lmask, sizeof(int) * n_entries, hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemsetAsync(d_change.p, 0, sizeof(double) * n_slots, stream));
+                iter_T = it_total;
                 snapshots_before_iteration(active, it + 1);
                 if (host_prof) { HIP_CHECK(hipStreamSynchronize(stream)); hp_mark("snapshots"); }
+                stamps_ok = (it == 0 ? true : stamps_ok) && stamps_live_for(n_entries);   // (per stage: the stamps are rewritten between the stages)
                 h_iter[0] = it_total;
                 h_iter[1] = (int)launch_epoch;   // epoch of this iteration's (first) sweep launch
                 launch_epoch += (persistent_now() && mode == 2) ? 1u : (unsigned)ndir;
@@ -1527,12 +1678,14 @@ class GridT : public GridBase {
                 ++it;
                 ++it_total;
                 std::vector<int> next;
+                if (fixed_iters > 0) ref_change_last.assign(n_slots, std::nan(""));
                 const std::vector<char> go = fixed_iters > 0 ? std::vector<char>(active.size(), 1) : decide_go_on(active, it);
                 hp_mark("stopping rule");
                 for (size_t q = 0; q < active.size(); ++q) {
                     const int s2 = active[q];
                     (stage == 0 ? niter : niterw)[s2] = it;
                     (stage == 0 ? change_hist : change_histw)[s2].push_back(h_change[s2]);
+                    (stage == 0 ? ref_hist : ref_histw)[s2].push_back((int)ref_change_last.size() == n_slots ? ref_change_last[s2] : std::nan(""));
                     timing.node_updates += (long long)n_nodes * ndir;
                     prev2_change[s2] = prev_change[s2];
                     prev_change[s2] = h_change[s2];
@@ -2597,6 +2750,9 @@ class MultiGrid : public GridBase {
     void get_changes(int slot, double* first, int n_first, double* wen, int n_weno) const override {
         int l; GridBase& g = of(slot, l); g.get_changes(l, first, n_first, wen, n_weno);
     }
+    void get_reference_changes(int slot, double* first, int n_first, double* wen, int n_weno) const override {
+        int l; GridBase& g = of(slot, l); g.get_reference_changes(l, first, n_first, wen, n_weno);
+    }
     void rays_size(size_t* n_rays, size_t* n_points) const override { *n_rays = rays_off.size() - 1; *n_points = (size_t)rays_off.back(); }
     void get_rays(long long* offsets, void* pts) const override {
         std::memcpy(offsets, rays_off.data(), rays_off.size() * sizeof(long long));
@@ -3287,6 +3443,12 @@ int ttcr_fsm_get_changes(ttcr_fsm_grid* g, int slot, double* first_order, int n_
     return guarded_on(g, [&] {
         if ((n_first > 0 && !first_order) || (n_weno > 0 && !weno) || n_first < 0 || n_weno < 0) throw ValueError("bad output buffers");
         g->impl->get_changes(slot, first_order, n_first, weno, n_weno);
+    });
+}
+int ttcr_fsm_get_reference_changes(ttcr_fsm_grid* g, int slot, double* first_order, int n_first, double* weno, int n_weno) {
+    return guarded_on(g, [&] {
+        if ((n_first > 0 && !first_order) || (n_weno > 0 && !weno) || n_first < 0 || n_weno < 0) throw ValueError("bad output buffers");
+        g->impl->get_reference_changes(slot, first_order, n_first, weno, n_weno);
     });
 }
 int ttcr_fsm_n_slots(const ttcr_fsm_grid* g) { return g->impl->n_slots; }

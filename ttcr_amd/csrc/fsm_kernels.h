@@ -2394,14 +2394,15 @@ __global__ __launch_bounds__(256) void fsm_reference_change(const RefChangeArgs<
 // (integer arithmetic on the significands; nothing is approximated), tests/test_stopping_rule_gpu.py checks it against the
 // one-chain kernel above on fields with ties at every scale.
 template <typename T> struct refsum_traits;
-template <> struct refsum_traits<float> { static constexpr int P = 24, EMIN = -149; };
-template <> struct refsum_traits<double> { static constexpr int P = 53, EMIN = -1074; };
+// (U: the integer the summaries count units in -- everything saturates at 2^(P+1), so 32 bits do for float: half the instructions)
+template <> struct refsum_traits<float> { static constexpr int P = 24, EMIN = -149; using U = uint32_t; };
+template <> struct refsum_traits<double> { static constexpr int P = 53, EMIN = -1074; using U = unsigned long long; };
 // v = M 2^E, M the integer significand (0 for v == 0), exact (v finite, >= 0)
-__device__ __forceinline__ void refsum_split(float v, unsigned long long& M, int& E) {
+__device__ __forceinline__ void refsum_split(float v, uint32_t& M, int& E) {
     const unsigned b = __float_as_uint(v);
     const int e = (int)((b >> 23) & 0xffu);
-    const unsigned long long f = b & 0x7fffffu;
-    M = e ? (f | 0x800000ull) : f;
+    const uint32_t f = b & 0x7fffffu;
+    M = e ? (f | 0x800000u) : f;
     E = (e ? e : 1) - 150;
 }
 __device__ __forceinline__ void refsum_split(double v, unsigned long long& M, int& E) {
@@ -2413,56 +2414,64 @@ __device__ __forceinline__ void refsum_split(double v, unsigned long long& M, in
 }
 // element x against the unit 2^k: nn = floor(x / u) (capped at 2^P), cls = 0 / 1 / 2: fraction below / exactly / above one half
 template <typename T>
-__device__ __forceinline__ void refsum_element(T x, int k, unsigned long long& nn, int& cls) {
-    constexpr unsigned long long LIMIT = 1ull << refsum_traits<T>::P;
-    unsigned long long M;
+__device__ __forceinline__ void refsum_element(T x, int k, typename refsum_traits<T>::U& nn, int& cls) {
+    using U = typename refsum_traits<T>::U;
+    constexpr U LIMIT = (U)1 << refsum_traits<T>::P;
+    constexpr int BITS = 8 * (int)sizeof(U);
+    U M;
     int E;
     refsum_split(x, M, E);
     cls = 0;
-    if (M == 0ull) { nn = 0ull; return; }
+    if (M == (U)0) { nn = (U)0; return; }
     if (E >= k) {
         const int sh = E - k;
-        nn = sh >= 12 ? LIMIT : (M << sh);   // (M < 2^53: no overflow below 12 bits of shift; anything that large is "beyond the binade" anyway)
+        // (M < 2^P: a shift that would run out of the integer is far "beyond the binade" anyway -- at P + 1 bits the value is capped)
+        nn = sh >= BITS - refsum_traits<T>::P - 1 ? LIMIT : (M << sh);
     } else {
         const int sh = k - E;
-        if (sh >= 64) { nn = 0ull; return; }   // (x < u / 2^10: far below half a unit)
+        if (sh >= BITS) { nn = (U)0; return; }   // (x < u / 2^(BITS - P): far below half a unit)
         nn = M >> sh;
-        const unsigned long long rem = M & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+        const U rem = M & (((U)1 << sh) - (U)1), half = (U)1 << (sh - 1);
         cls = rem < half ? 0 : (rem == half ? 1 : 2);
     }
     nn = nn > LIMIT ? LIMIT : nn;
 }
 // increment of the element for the parity `par` of the running sum in units
-__device__ __forceinline__ unsigned long long refsum_incr(unsigned long long nn, int cls, unsigned par) {
-    return nn + (cls == 2 ? 1ull : (cls == 1 ? ((par + (unsigned)nn) & 1u) : 0ull));
+template <typename U>
+__device__ __forceinline__ U refsum_incr(U nn, int cls, unsigned par) {
+    return nn + (cls == 2 ? (U)1 : (cls == 1 ? (U)((par + (unsigned)nn) & 1u) : (U)0));
 }
 // Summary of a block of elements for a fixed unit: d[x] = its increment when the sum in front of it has parity x; r[x] = the largest
 // "sum in front of an element + the most that element can add" inside the block, relative to the block's start (0: empty block).
 // An element is taken by the recurrence only while S + nn + (fraction != 0) < 2^P -- the sum provably stays in the binade --; the
 // first element for which that fails ends the round (it is added with a T addition).  With the start state S of a block that is
 // S + r[S & 1] >= 2^P.  Values saturate at 2^(P+1) (far beyond the limit: only "reached" matters from there on).
-struct RefSum4 { unsigned long long d[2], r[2]; };
+template <typename U> struct RefSum4T { U d[2], r[2]; };
+template <typename T> using RefSum4 = RefSum4T<typename refsum_traits<T>::U>;
 template <typename T>
-__device__ __forceinline__ unsigned long long refsum_sat(unsigned long long v) {
-    constexpr unsigned long long CAP = 1ull << (refsum_traits<T>::P + 1);
+__device__ __forceinline__ typename refsum_traits<T>::U refsum_sat(typename refsum_traits<T>::U v) {
+    using U = typename refsum_traits<T>::U;
+    constexpr U CAP = (U)1 << (refsum_traits<T>::P + 1);
     return v > CAP ? CAP : v;
 }
 template <typename T>
-__device__ __forceinline__ void refsum_push(RefSum4& s, unsigned long long nn, int cls) {   // s <- s then one element
+__device__ __forceinline__ void refsum_push(RefSum4<T>& s, typename refsum_traits<T>::U nn, int cls) {   // s <- s then one element
+    using U = typename refsum_traits<T>::U;
 #pragma unroll
     for (unsigned x = 0; x < 2; ++x) {
-        const unsigned long long reach = refsum_sat<T>(s.d[x] + nn + (cls ? 1ull : 0ull));
+        const U reach = refsum_sat<T>(s.d[x] + nn + (cls ? (U)1 : (U)0));
         s.r[x] = s.r[x] > reach ? s.r[x] : reach;
-        s.d[x] = refsum_sat<T>(s.d[x] + refsum_incr(nn, cls, ((unsigned)s.d[x] + x) & 1u));
+        s.d[x] = refsum_sat<T>(s.d[x] + refsum_incr<U>(nn, cls, ((unsigned)s.d[x] + x) & 1u));
     }
 }
 template <typename T>
-__device__ __forceinline__ RefSum4 refsum_then(const RefSum4& A, const RefSum4& B) {        // A then B
-    RefSum4 c;
+__device__ __forceinline__ RefSum4<T> refsum_then(const RefSum4<T>& A, const RefSum4<T>& B) {        // A then B
+    using U = typename refsum_traits<T>::U;
+    RefSum4<T> c;
 #pragma unroll
     for (unsigned x = 0; x < 2; ++x) {
         const unsigned y = ((unsigned)A.d[x] + x) & 1u;
-        const unsigned long long reach = refsum_sat<T>(A.d[x] + B.r[y]);
+        const U reach = refsum_sat<T>(A.d[x] + B.r[y]);
         c.r[x] = A.r[x] > reach ? A.r[x] : reach;
         c.d[x] = refsum_sat<T>(A.d[x] + B.d[y]);
     }
@@ -2478,13 +2487,13 @@ constexpr unsigned long long FSM_REFSUM_WMIN = 1ull << 16, FSM_REFSUM_WMAX = 1ul
 template <typename T>
 struct RefSumArgs {
     const T* const* cur;   // [field] current field (element i at cur[f][i * stride])
-    const T* const* old;   // [field] the snapshot, same layout
-    size_t n_nodes;
+    const T* const* old;   // [field] the snapshot, same layout (nullptr: cur holds the terms themselves)
+    const unsigned long long* n;   // [field] number of terms
     int stride;
     RefSumState* st;       // [2][field]: a round reads the states of buffer round & 1 and writes the other one -- read-only within a
                            // launch, so that a workgroup dispatched late can never see the next round's state (round-5 advice)
     int round;             // number of this round (launch)
-    RefSum4* tiles;        // [field][FSM_REFSUM_WMAX / TILE] summaries of the tiles of the window
+    RefSum4<T>* tiles;     // [field][FSM_REFSUM_WMAX / TILE] summaries of the tiles of the window
     unsigned* arrived;     // [field] workgroups of the round that are done with their tiles (zero between rounds)
     T stop_at;             // the sum only grows: a field whose running sum has reached this value is done (what the caller asks is
                            // `change >= epsilon`); infinity: the whole sum
@@ -2507,24 +2516,195 @@ __device__ __forceinline__ T refsum_make(unsigned long long S, int k) {
 template <typename T>
 __device__ __forceinline__ void refsum_unit(T s, int& k, unsigned long long& S) {
     int E;
-    refsum_split(s, S, E);
+    typename refsum_traits<T>::U M;
+    refsum_split(s, M, E);
+    S = M;
     k = S ? E : refsum_traits<T>::EMIN;
 }
 template <typename T>
 struct RefSumField { const T* cur; const T* old; size_t n_nodes; int stride; };
 template <typename T>
 __device__ __forceinline__ T refsum_x(const RefSumField<T>& a, unsigned long long i) {
+    if (a.old == nullptr) return a.cur[i * a.stride];          // (the terms themselves: fsm_refsum_terms below)
     const T df = a.old[i * a.stride] - a.cur[i * a.stride];   // times[n] - T[n], in T1 (ttcr/Grid3Drnfs.h:145)
     return df < 0 ? -df : df;
 }
+// The terms abs(times[n] - T[n]) of the fields of one slot group, one compact array per source that was asked for: the rounds above then
+// read 4 bytes per term instead of two fields with the stride of the group's layout.  Zeros add nothing to the sum -- and in the
+// iterations the rule decides, all but 1e-4 ... 5e-2 of the terms are zero (nodes that did not change; profiles/r06/stopping_rule.txt):
+// the ordered pass runs over the non-zero terms alone, kept in node order.  fsm_refsum_terms writes the terms of a block of
+// FSM_REFSUM_CB nodes and counts the non-zero ones; fsm_refsum_scan turns the counts into offsets (one workgroup per field; the total is
+// the length of the compacted field); fsm_refsum_compact writes the non-zero terms of a block behind those of the blocks in front of it.
+// In the same pass the snapshot is brought up to the current field -- the copy the next iteration would otherwise take
+// (GridT::snapshots_before_iteration).  With the dirty-brick stamps of the SKIP sweep kernels (stamp != nullptr: 3-D grids) only the
+// bricks that changed since the snapshot was taken (stamp >= thr) are read at all: the others hold zeros and a snapshot that is already
+// right; a block none of whose bricks changed costs the stamps of its bricks.  x[] = cnt[] = nullptr: the snapshot alone.
+// V elements per lane (16 bytes when the group's fields are aligned to that and V divides their length).
+constexpr int FSM_REFSUM_CB = 4096;
+template <typename T>
+struct RefTermsArgs {
+    const T* cur;          // [n_nodes * ns] the fields of the group, source l of node n at n * ns + l
+    T* old;                // the snapshot, same layout; becomes a copy of cur
+    T* x[2];               // [l] terms of source l, dense (nullptr: not asked); defined in the blocks with cnt > 0
+    unsigned* cnt[2];      // [l][block] non-zero terms
+    uint32_t n_nodes;
+    int ns;
+    const int* stamp;      // the group's brick stamps (sweep number of the last change), nullptr: every brick counts as changed
+    int thr;
+    int NF, NJ, nbf, nbj;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void fsm_refsum_terms(const RefTermsArgs<T> a) {
+    struct alignas(sizeof(T) * V) Vec { T v[V]; };
+    constexpr int H = V > 1 ? V / 2 : 1;
+    struct alignas(sizeof(T) * H) Half { T v[H]; };
+    __shared__ unsigned s_c[2];
+    __shared__ int s_any;
+    const uint32_t n_el = a.n_nodes * (uint32_t)a.ns;
+    const uint32_t vpb = (uint32_t)FSM_REFSUM_CB * a.ns / V;          // vectors per block
+    const int subs = (int)(vpb / 256u);                               // (<= 32)
+    const uint32_t nblk = (a.n_nodes + FSM_REFSUM_CB - 1) / FSM_REFSUM_CB;
+    const bool want = a.x[0] != nullptr || a.x[1] != nullptr;
+    for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        if (threadIdx.x == 0) { s_c[0] = 0u; s_c[1] = 0u; s_any = 0; }
+        __syncthreads();
+        // which of this lane's vectors lie in a brick that changed (one bit per vector; a vector never straddles two bricks: the
+        // host sees to it that NF is a multiple of the nodes of a vector)
+        unsigned chg = 0u;
+        for (int sub = 0; sub < subs; ++sub) {
+            const uint32_t q = blk * vpb + (uint32_t)sub * 256u + threadIdx.x;
+            if ((uint64_t)q * V >= n_el) break;
+            bool c = true;
+            if (a.stamp) {
+                const uint32_t node = q * (uint32_t)V / (uint32_t)a.ns;
+                const uint32_t line = node / (uint32_t)a.NF, f = node - line * (uint32_t)a.NF;
+                const uint32_t k = line / (uint32_t)a.NJ, j = line - k * (uint32_t)a.NJ;
+                c = a.stamp[((size_t)(k / FSM_BRICK) * a.nbj + j / FSM_BRICK) * a.nbf + f / FSM_BRICK] >= a.thr;
+            }
+            chg |= c ? 1u << sub : 0u;
+        }
+        if (__ballot(chg != 0u) && (threadIdx.x & 63) == 0) s_any = 1;
+        __syncthreads();
+        if (!s_any) {   // (uniform) nothing changed in the block: no terms, the snapshot stands
+            if (threadIdx.x < 2 && a.cnt[threadIdx.x]) a.cnt[threadIdx.x][blk] = 0u;
+            __syncthreads();
+            continue;
+        }
+        unsigned c0 = 0u, c1 = 0u;   // (wave-uniform tallies)
+        for (int sub = 0; sub < subs; ++sub) {
+            const uint32_t q = blk * vpb + (uint32_t)sub * 256u + threadIdx.x;
+            const bool in = (uint64_t)q * V < n_el;
+            Vec x;
+#pragma unroll
+            for (int e = 0; e < V; ++e) x.v[e] = (T)0;
+            if (in && ((chg >> sub) & 1u)) {
+                const Vec c = ((const Vec*)a.cur)[q];
+                if (want) {
+                    const Vec o = ((const Vec*)a.old)[q];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const T df = o.v[e] - c.v[e];   // times[n] - T[n], in T1 (ttcr/Grid3Drnfs.h:145)
+                        x.v[e] = df < 0 ? -df : df;
+                    }
+                }
+                ((Vec*)a.old)[q] = c;
+            }
+            if (!want) continue;
+            if (a.ns == 1) {
+                if (in) ((Vec*)a.x[0])[q] = x;
+#pragma unroll
+                for (int e = 0; e < V; ++e) c0 += (unsigned)__builtin_popcountll(__ballot(x.v[e] != (T)0));
+            } else if constexpr (V == 1) {
+                if (in && a.x[q & 1u]) a.x[q & 1u][q >> 1] = x.v[0];
+                c0 += (unsigned)__builtin_popcountll(__ballot(x.v[0] != (T)0 && !(q & 1u)));
+                c1 += (unsigned)__builtin_popcountll(__ballot(x.v[0] != (T)0 && (q & 1u)));
+            } else {
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    if (!a.x[l]) continue;
+                    Half h;
+#pragma unroll
+                    for (int e = 0; e < H; ++e) {
+                        h.v[e] = x.v[2 * e + l];
+                        const unsigned n1 = (unsigned)__builtin_popcountll(__ballot(h.v[e] != (T)0));
+                        if (l == 0) c0 += n1; else c1 += n1;
+                    }
+                    if (in) ((Half*)a.x[l])[q] = h;
+                }
+            }
+        }
+        if (want) {
+            if ((threadIdx.x & 63) == 0) { if (c0) atomicAdd(&s_c[0], c0); if (c1) atomicAdd(&s_c[1], c1); }
+            __syncthreads();
+            if (threadIdx.x < 2 && a.cnt[threadIdx.x]) a.cnt[threadIdx.x][blk] = s_c[threadIdx.x];
+        }
+        __syncthreads();
+    }
+}
+template <int DUMMY = 0>   // (a template: the header is part of two translation units)
+__global__ __launch_bounds__(1024) void fsm_refsum_scan(const unsigned* __restrict__ cnt, unsigned long long* __restrict__ off, unsigned nblk,
+                                                        unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long s_t[1024];
+    const unsigned* __restrict__ c = cnt + (size_t)blockIdx.x * nblk;
+    unsigned long long* __restrict__ o = off + (size_t)blockIdx.x * nblk;
+    const unsigned per = (nblk + 1023u) / 1024u, b0 = threadIdx.x * per < nblk ? threadIdx.x * per : nblk, b1 = b0 + per < nblk ? b0 + per : nblk;
+    unsigned long long s = 0;
+    for (unsigned b = b0; b < b1; ++b) s += c[b];
+    s_t[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // (1024 values: one lane)
+        unsigned long long run = 0;
+        for (int t = 0; t < 1024; ++t) { const unsigned long long v = s_t[t]; s_t[t] = run; run += v; }
+        total[blockIdx.x] = run;
+    }
+    __syncthreads();
+    unsigned long long run = s_t[threadIdx.x];
+    for (unsigned b = b0; b < b1; ++b) { o[b] = run; run += c[b]; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fsm_refsum_compact(const T* __restrict__ x, T* __restrict__ out, size_t pitch, size_t n,
+                                                          const unsigned* __restrict__ cnt, const unsigned long long* __restrict__ off, unsigned nblk) {
+    constexpr int PER = FSM_REFSUM_CB / 256;
+    __shared__ unsigned s_w[4];
+    const T* __restrict__ xf = x + (size_t)blockIdx.y * pitch;
+    T* __restrict__ of = out + (size_t)blockIdx.y * pitch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        if (cnt[(size_t)blockIdx.y * nblk + blk] == 0u) continue;   // (uniform: most blocks of a late iteration)
+        const size_t base = (size_t)blk * FSM_REFSUM_CB + (size_t)threadIdx.x * PER;   // PER consecutive terms per lane, in node order
+        T v[PER];
+        unsigned c = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            v[q] = base + q < n ? xf[base + q] : (T)0;
+            c += v[q] != (T)0 ? 1u : 0u;
+        }
+        // exclusive scan of the lanes' counts: within the wavefront, then over the four wavefronts
+        unsigned inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        unsigned before = inc - c;
+        for (int w = 0; w < wave; ++w) before += s_w[w];
+        unsigned long long p = off[(size_t)blockIdx.y * nblk + blk] + before;
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            if (v[q] != (T)0) of[p++] = v[q];
+        __syncthreads();
+    }
+}
 // summary of the FSM_REFSUM_PER consecutive elements from i0 on
 template <typename T>
-__device__ __forceinline__ RefSum4 refsum_chunk(const RefSumField<T>& a, unsigned long long i0, int k) {
-    RefSum4 s = {{0ull, 0ull}, {0ull, 0ull}};
+__device__ __forceinline__ RefSum4<T> refsum_chunk(const RefSumField<T>& a, unsigned long long i0, int k) {
+    RefSum4<T> s = {{0, 0}, {0, 0}};
     for (int q = 0; q < FSM_REFSUM_PER; ++q) {
         const unsigned long long i = i0 + q;
         if (i >= a.n_nodes) break;
-        unsigned long long nn;
+        typename refsum_traits<T>::U nn;
         int cls;
         refsum_element<T>(refsum_x(a, i), k, nn, cls);
         refsum_push<T>(s, nn, cls);
@@ -2533,9 +2713,9 @@ __device__ __forceinline__ RefSum4 refsum_chunk(const RefSumField<T>& a, unsigne
 }
 // ordered composition of the 256 summaries in sd[] (thread t holds elements before thread t + 1's): the result is in sd[0]
 template <typename T>
-__device__ __forceinline__ void refsum_tree(RefSum4* sd, int tid) {
+__device__ __forceinline__ void refsum_tree(RefSum4<T>* sd, int tid) {
     for (int off = 1; off < 256; off <<= 1) {
-        RefSum4 c = {{0ull, 0ull}, {0ull, 0ull}};
+        RefSum4<T> c = {{0, 0}, {0, 0}};
         const bool act = (tid & (2 * off - 1)) == 0;
         if (act) c = refsum_then<T>(sd[tid], sd[tid + off]);
         __syncthreads();
@@ -2543,30 +2723,62 @@ __device__ __forceinline__ void refsum_tree(RefSum4* sd, int tid) {
         __syncthreads();
     }
 }
+// The head of a field (blockIdx.x), added the reference's way: the running sum doubles every few terms at first -- a round per binade
+// would spend a launch on a handful of elements a dozen times over --, so the first FSM_REFSUM_HEAD terms are staged in LDS and added by
+// one lane, one T addition after the other (ttcr/Grid3Drnfs.h:147).  Leaves the state the rounds start from.
+constexpr int FSM_REFSUM_HEAD = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void fsm_refsum_head(const RefSumArgs<T> a) {
+    __shared__ T xs[FSM_REFSUM_HEAD];
+    const int fi = blockIdx.x;
+    const unsigned long long n_terms = a.n[fi];
+    const RefSumField<T> f = {a.cur[fi], a.old[fi], n_terms, a.stride};
+    const int m = (int)(n_terms < (unsigned long long)FSM_REFSUM_HEAD ? n_terms : (unsigned long long)FSM_REFSUM_HEAD);
+    for (int i = threadIdx.x; i < FSM_REFSUM_HEAD; i += 256) xs[i] = i < m ? refsum_x(f, (unsigned long long)i) : (T)0;   // (zeros add nothing)
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    T s = (T)0;
+    int done = m;
+    for (int i = 0; i < m; i += 16) {   // (16 values in flight ahead of the chain of additions; a sum that has reached stop_at is decided)
+        T v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = xs[i + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s = s + v[q];
+        if (s >= a.stop_at) { done = -1; break; }
+    }
+    RefSumState ns;
+    ns.start = done < 0 ? n_terms : (unsigned long long)done;
+    ns.bits = refsum_bits<T>(s);
+    ns.window = FSM_REFSUM_WMIN;
+    ns.prev_q = ns.start;
+    a.st[(size_t)(a.round & 1) * gridDim.x + fi] = ns;
+}
 // One round of a field (blockIdx.y): the workgroups summarise the tiles of the window for the unit of the current sum (grid stride);
 // the one that finishes last composes the summaries in order up to the first tile in which an element may take the sum out of its
 // binade, finds that element and adds it with a T addition -- or takes the whole window -- and writes the next state.
 template <typename T>
 __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
     constexpr unsigned long long LIMIT = 1ull << refsum_traits<T>::P;
-    __shared__ RefSum4 sd[256];
+    __shared__ RefSum4<T> sd[256];
     __shared__ unsigned long long s_S, s_tile;
     __shared__ int s_found, s_last;
     const int tid = threadIdx.x;
     const int fi = blockIdx.y;
+    const unsigned long long n_terms = a.n[fi];
     const RefSumState st = a.st[(size_t)(a.round & 1) * gridDim.y + fi];
     RefSumState& st_next = a.st[(size_t)((a.round + 1) & 1) * gridDim.y + fi];
     const unsigned long long start = st.start;
-    if (start >= a.n_nodes) {   // (this field is done: the rounds are enqueued in bunches; its state moves on unchanged)
+    if (start >= n_terms) {   // (this field is done: the rounds are enqueued in bunches; its state moves on unchanged)
         if (blockIdx.x == 0 && tid == 0) st_next = st;
         return;
     }
-    const RefSumField<T> f = {a.cur[fi], a.old[fi], a.n_nodes, a.stride};
-    RefSum4* __restrict__ tiles = a.tiles + (size_t)fi * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE);
+    const RefSumField<T> f = {a.cur[fi], a.old[fi], n_terms, a.stride};
+    RefSum4<T>* __restrict__ tiles = a.tiles + (size_t)fi * (FSM_REFSUM_WMAX / FSM_REFSUM_TILE);
     int k;
     unsigned long long S0;
     refsum_unit<T>(refsum_value<T>(st.bits), k, S0);
-    unsigned long long n_left = a.n_nodes - start;
+    unsigned long long n_left = n_terms - start;
     n_left = n_left < st.window ? n_left : st.window;
     const unsigned long long n_tiles = (n_left + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE;
     if (blockIdx.x >= n_tiles) return;   // (no tile for this workgroup in this round: it is not counted either)
@@ -2580,13 +2792,13 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
         for (int q = 0; q < FSM_REFSUM_PER; ++q) {
             const int e = q * 256 + tid;
             const unsigned long long i = tb + e;
-            xs[e + e / FSM_REFSUM_PER] = i < a.n_nodes ? refsum_x(f, i) : (T)0;   // (beyond the field: zeros add nothing)
+            xs[e + e / FSM_REFSUM_PER] = i < n_terms ? refsum_x(f, i) : (T)0;   // (beyond the field: zeros add nothing)
         }
         __syncthreads();
-        RefSum4 c = {{0ull, 0ull}, {0ull, 0ull}};
+        RefSum4<T> c = {{0, 0}, {0, 0}};
 #pragma unroll 4
         for (int q = 0; q < FSM_REFSUM_PER; ++q) {
-            unsigned long long nn;
+            typename refsum_traits<T>::U nn;
             int cls;
             refsum_element<T>(xs[tid * (FSM_REFSUM_PER + 1) + q], k, nn, cls);
             refsum_push<T>(c, nn, cls);
@@ -2613,7 +2825,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
     // ranges of tiles per thread (their loads overlap across the threads), composed by thread 0
     const unsigned long long per = (n_tiles + 255) / 256;
     {
-        RefSum4 s = {{0ull, 0ull}, {0ull, 0ull}};
+        RefSum4<T> s = {{0, 0}, {0, 0}};
         for (unsigned long long t = (unsigned long long)tid * per; t < ((unsigned long long)tid + 1) * per && t < n_tiles; ++t) s = refsum_then<T>(s, tiles[t]);
         sd[tid] = s;
     }
@@ -2636,7 +2848,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
         __syncthreads();
         for (unsigned long long q = tid; q < per; q += 256) {
             // (per <= WMAX / TILE / 256 = 32 tiles: one pass)
-            if (q < 256) sd[q] = t0 + q < n_tiles ? tiles[t0 + q] : RefSum4{{0ull, 0ull}, {0ull, 0ull}};
+            if (q < 256) sd[q] = t0 + q < n_tiles ? tiles[t0 + q] : RefSum4<T>{{0, 0}, {0, 0}};
         }
         __syncthreads();
         if (tid == 0) {
@@ -2661,7 +2873,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
             ns.bits = refsum_bits<T>(refsum_make<T>(s_S, k));
             ns.window = 2ull * st.window < FSM_REFSUM_WMAX ? 2ull * st.window : FSM_REFSUM_WMAX;
             ns.prev_q = st.prev_q;
-            if (refsum_value<T>(ns.bits) >= a.stop_at) ns.start = a.n_nodes;
+            if (refsum_value<T>(ns.bits) >= a.stop_at) ns.start = n_terms;
             st_next = ns;
         }
         return;
@@ -2684,7 +2896,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
     __shared__ T s_x[FSM_REFSUM_PER + 1];
     {
         const unsigned long long q0 = tbase + (unsigned long long)s_range * FSM_REFSUM_PER;
-        if (tid <= FSM_REFSUM_PER) s_x[tid] = q0 + tid < a.n_nodes ? refsum_x(f, q0 + tid) : (T)0;
+        if (tid <= FSM_REFSUM_PER) s_x[tid] = q0 + tid < n_terms ? refsum_x(f, q0 + tid) : (T)0;
     }
     __syncthreads();
     if (tid == 0) {
@@ -2692,12 +2904,12 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
         const int c = s_range;
         unsigned long long q = tbase + (unsigned long long)c * FSM_REFSUM_PER;
         const unsigned long long q0 = q, qend = q + FSM_REFSUM_PER;
-        for (; q < qend && q < a.n_nodes; ++q) {
-            unsigned long long nn;
+        for (; q < qend && q < n_terms; ++q) {
+            typename refsum_traits<T>::U nn;
             int cls;
             refsum_element<T>(s_x[q - q0], k, nn, cls);
             if (S + nn + (cls ? 1ull : 0ull) >= LIMIT) break;
-            S += refsum_incr(nn, cls, (unsigned)S & 1u);
+            S += refsum_incr<typename refsum_traits<T>::U>(nn, cls, (unsigned)S & 1u);
         }
         // q: the element that may take the sum out of the binade, S: the state in front of it (c == 256 or q == qend cannot happen --
         // the summaries said so -- and would only cost a round: any element may be added the reference's way)
@@ -2705,19 +2917,19 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
         RefSumState ns;
         ns.window = st.window;
         ns.prev_q = st.prev_q;
-        if (q < a.n_nodes) {
+        if (q < n_terms) {
             v = v + s_x[q - q0];   // the reference's own addition (ttcr/Grid3Drnfs.h:147)
             ns.start = q + 1ull;
-            // the sum left its binade here (or nearly): the next such place is about as far again; whole tiles (a tile is summarised to its end)
-            unsigned long long w = 2ull * (q + 1ull - st.prev_q);
+            // the sum left its binade here (or nearly): the next such place is about twice as far again; whole tiles (a tile is summarised to its end)
+            unsigned long long w = 4ull * (q + 1ull - st.prev_q);   // (twice that distance ended just short of the next place every other time)
             w = w < FSM_REFSUM_WMIN ? FSM_REFSUM_WMIN : (w > FSM_REFSUM_WMAX ? FSM_REFSUM_WMAX : w);
             ns.window = (w + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE * FSM_REFSUM_TILE;
             ns.prev_q = q + 1ull;
         } else {
-            ns.start = a.n_nodes;
+            ns.start = n_terms;
         }
         ns.bits = refsum_bits<T>(v);
-        if (v >= a.stop_at) ns.start = a.n_nodes;
+        if (v >= a.stop_at) ns.start = n_terms;
         st_next = ns;
     }
 }

@@ -147,6 +147,14 @@ class _GridBase:
         _lib.check(self._lib.ttcr_fsm_get_changes(self._h, int(thread_no), a, n1, b, n2))
         return np.array(a[:n1]), np.array(b[:n2])
 
+    def get_reference_changes(self, thread_no=0):
+        """(first-order, WENO) arrays like get_changes(), holding the reference's own sum -- sequential, in node order, in the grid's
+        precision (ttcr/Grid3Drnfs.h:141-152) -- for the iterations that were decided with it (option stopping_rule), NaN elsewhere."""
+        n1, n2 = self.get_niter(thread_no), self.get_niterw(thread_no)
+        a, b = (C.c_double * max(n1, 1))(), (C.c_double * max(n2, 1))()
+        _lib.check(self._lib.ttcr_fsm_get_reference_changes(self._h, int(thread_no), a, n1, b, n2))
+        return np.array(a[:n1]), np.array(b[:n2])
+
     def timing(self):
         """HIP-event timing of the last raytrace call (dict)."""
         t = _lib.Timing()
