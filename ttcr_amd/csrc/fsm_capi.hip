@@ -1329,7 +1329,7 @@ class GridT : public GridBase {
     // stop_at: a field is done once its running sum has reached this value (the sum only grows; the value returned is then a lower bound)
     // d_n: [field] number of terms on the device (compacted fields: fsm_refsum_scan's totals); nullptr: n_nodes each
     std::vector<T> reference_changes(const std::vector<const T*>& cur, const std::vector<const T*>& old, int stride, bool one_chain, T stop_at,
-                                     const unsigned long long* d_n = nullptr) {
+                                     const unsigned long long* d_n = nullptr, const std::vector<unsigned long long>* h_n_known = nullptr) {
         const size_t nf = cur.size();
         std::vector<T> out(nf, (T)0);
         if (one_chain) {
@@ -1375,8 +1375,11 @@ class GridT : public GridBase {
         } else {
             // compacted fields: their lengths size the launches (windows that always reach to the end of the field were tried: fewer
             // rounds, 176 against 240 per solve of bench.py's heterogeneous leg, but 136 us each against 29 -- the scan is arithmetic)
-            HIP_CHECK(hipMemcpyAsync(h_n.data(), d_n, nf * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            if (h_n_known) h_n = *h_n_known;
+            else {
+                HIP_CHECK(hipMemcpyAsync(h_n.data(), d_n, nf * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+            }
             n_max = 0;
             for (size_t f = 0; f < nf; ++f) n_max = std::max(n_max, h_n[f]);
             if (n_max == 0) return out;   // (no node changed at all: the sum of no terms)
@@ -1390,12 +1393,19 @@ class GridT : public GridBase {
         const unsigned max_tiles = (unsigned)std::min<unsigned long long>(tiles_per_field, (n_max + FSM_REFSUM_TILE - 1) / FSM_REFSUM_TILE);
         ra.round = 0;   // (round r reads buffer r & 1 of the states and writes the other one; the initial states sit in buffer 0)
         fsm_refsum_head<T><<<(unsigned)nf, 256, 0, stream>>>(ra);   // (... written by the pass over the head of every field)
-        for (int bunch = 16;; bunch = 8) {   // (rounds are enqueued in bunches: a field that is done lets the rest of its bunch pass)
+        static const bool trace = std::getenv("TTCR_FSM_REFSUM_TRACE") != nullptr;   // tuning: one round per bunch, its state and wall clock on stderr
+        for (int bunch = trace ? 1 : 16;; bunch = trace ? 1 : 8) {   // (rounds are enqueued in bunches: a field that is done lets the rest of its bunch pass)
+            const auto t_b = std::chrono::steady_clock::now();
             for (int r = 0; r < bunch; ++r, ++ra.round) fsm_refsum_round<T><<<dim3(std::min(max_tiles, 1024u), (unsigned)nf), 256, 0, stream>>>(ra);
             HIP_CHECK(hipGetLastError());
             refsum_rounds += bunch;
             HIP_CHECK(hipMemcpyAsync(st.data(), d_rs_state.p + (size_t)(ra.round & 1) * nf, nf * sizeof(RefSumState), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
+            if (trace) {
+                std::fprintf(stderr, "[refsum] round %3d  %7.1f us ", ra.round, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_b).count());
+                for (size_t f = 0; f < nf; ++f) std::fprintf(stderr, " | start %llu of %llu window %llu", st[f].start, h_n[f], st[f].window);
+                std::fprintf(stderr, "\n");
+            }
             bool done = true;
             for (size_t f = 0; f < nf; ++f) done = done && st[f].start >= h_n[f];
             if (done) break;
@@ -1497,7 +1507,7 @@ class GridT : public GridBase {
                     for (size_t q = 0; q < need.size(); ++q) { c2[q] = curs[need[q]]; m2[q] = h_m[need[q]]; }
                     d_rs_n2.reserve(std::max<size_t>(need.size(), 64));
                     HIP_CHECK(hipMemcpyAsync(d_rs_n2.p, m2.data(), need.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
-                    const std::vector<T> r = reference_changes(c2, o2, 1, false, epsilon, d_rs_n2.p);   // (asked: change >= epsilon)
+                    const std::vector<T> r = reference_changes(c2, o2, 1, false, epsilon, d_rs_n2.p, &m2);   // (asked: change >= epsilon)
                     for (size_t q = 0; q < need.size(); ++q) { res[a0 + need[q]] = r[q]; res_known[a0 + need[q]] = 1; }
                 }
                 a0 = a1;

@@ -2754,6 +2754,26 @@ __global__ __launch_bounds__(256) void fsm_refsum_head(const RefSumArgs<T> a) {
     ns.prev_q = ns.start;
     a.st[(size_t)(a.round & 1) * gridDim.x + fi] = ns;
 }
+// The ordered walk over n summaries in LDS (n a multiple of 8; empty summaries change nothing): the first entry at which the sum may
+// leave its binade, S left at the state in front of it; n if there is none.  Eight summaries are fetched whole before the dependent chain
+// of selects and additions runs over them: fetching sd[c].r[S & 1] -- an address that depends on S -- made every entry two LDS round
+// trips, 14 us per 256 entries and most of a round (profiles/r06/stopping_rule.txt).
+template <typename T>
+__device__ __forceinline__ int refsum_walk(const RefSum4<T>* sd, int n, unsigned long long& S) {
+    constexpr unsigned long long LIMIT = 1ull << refsum_traits<T>::P;
+    for (int c = 0; c < n; c += 8) {
+        RefSum4<T> e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) e[q] = sd[c + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool odd = ((unsigned)S & 1u) != 0u;
+            if (S + (unsigned long long)(odd ? e[q].r[1] : e[q].r[0]) >= LIMIT) return c + q;
+            S += (unsigned long long)(odd ? e[q].d[1] : e[q].d[0]);
+        }
+    }
+    return n;
+}
 // One round of a field (blockIdx.y): the workgroups summarise the tiles of the window for the unit of the current sum (grid stride);
 // the one that finishes last composes the summaries in order up to the first tile in which an element may take the sum out of its
 // binade, finds that element and adds it with a T addition -- or takes the whole window -- and writes the next state.
@@ -2835,30 +2855,24 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
     __shared__ int s_range;
     if (tid == 0) {
         unsigned long long S = S0;
-        int c = 0;
-        for (; c < 256; ++c) {
-            if (S + sd[c].r[S & 1ull] >= LIMIT) break;   // in this range
-            S += sd[c].d[S & 1ull];
-        }
+        const int c = refsum_walk<T>(sd, 256, S);   // (the range in which the sum may leave its binade)
         s_S = S; s_range = c; s_found = c < 256;
     }
     __syncthreads();
     if (s_found) {   // the tiles of that range, one by one
         const unsigned long long t0 = (unsigned long long)s_range * per;
         __syncthreads();
-        for (unsigned long long q = tid; q < per; q += 256) {
-            // (per <= WMAX / TILE / 256 = 32 tiles: one pass)
-            if (q < 256) sd[q] = t0 + q < n_tiles ? tiles[t0 + q] : RefSum4<T>{{0, 0}, {0, 0}};
+        {   // (per <= WMAX / TILE / 256 = 32 tiles: one pass; padded with empty summaries to a multiple of 8 for the walk)
+            const unsigned long long q = (unsigned long long)tid;
+            if (q < ((per + 7ull) & ~7ull) && q < 256ull) sd[q] = (q < per && t0 + q < n_tiles) ? tiles[t0 + q] : RefSum4<T>{{0, 0}, {0, 0}};
         }
         __syncthreads();
         if (tid == 0) {
             unsigned long long S = s_S, t = t0;
             int found = 0;
-            for (unsigned long long q = 0; q < per && q < 256 && t0 + q < n_tiles; ++q) {
-                t = t0 + q;
-                if (S + sd[q].r[S & 1ull] >= LIMIT) { found = 1; break; }
-                S += sd[q].d[S & 1ull];
-            }
+            const int n2 = (int)(per < 256ull ? (per + 7ull) & ~7ull : 256ull);
+            const int c = refsum_walk<T>(sd, n2, S);   // (entries behind the range or the window are empty: they cannot be it)
+            if (c < n2) { t = t0 + (unsigned long long)c; found = 1; }
             // (found == 0 cannot happen -- the summary of the range said so; the walk then stands at the end of the range with the
             // exact state: go on from the next tile, or the window is over)
             if (!found) { t = t0 + per; found = t < n_tiles; }
@@ -2885,11 +2899,7 @@ __global__ __launch_bounds__(256) void fsm_refsum_round(const RefSumArgs<T> a) {
     __syncthreads();
     if (tid == 0) {
         unsigned long long S = s_S;
-        int c = 0;
-        for (; c < 256; ++c) {
-            if (S + sd[c].r[S & 1ull] >= LIMIT) break;
-            S += sd[c].d[S & 1ull];
-        }
+        const int c = refsum_walk<T>(sd, 256, S);
         s_S = S; s_range = c;
     }
     __syncthreads();
