@@ -190,3 +190,25 @@ def test_brick_passes_beyond_the_always_snapshot_size(monkeypatch):
         assert a[i][0] == b[i][0]
         assert _same_decisions(a[i][1], b[i][1], thr), (i, a[i][1], b[i][1])
         assert np.array_equal(a[i][2], b[i][2])
+
+
+@pytest.mark.parametrize("fields", [0, 2])
+def test_small_batches_and_the_strided_fallback_decide_alike(fields, monkeypatch):
+    """Where the device has no room for the compact term arrays of 16 fields the batches shrink, and with no room for a pair the sums go by
+    the strided fields (TTCR_FSM_RS_FIELDS, read when a grid is made, forces either): same sums, same iteration counts, same fields."""
+    n, n_src, eps = 96, 8, 1e-5
+    thr = float(np.float32(eps) * np.float32(n ** 3))
+    s = _model(n, 23)
+    monkeypatch.setenv("TTCR_FSM_PAIR", "1")
+    b, st_b, _, _ = _solve_all(n, n_src, eps, {"skip": 1, "stopping_shortcuts": 1}, s)
+    monkeypatch.setenv("TTCR_FSM_RS_FIELDS", str(fields))
+    a, st_a, _, kern = _solve_all(n, n_src, eps, {"skip": 1, "stopping_shortcuts": 1}, s)
+    print(kern, st_a, st_b)
+    assert st_a["reference_sums"] == st_b["reference_sums"] > 0 and st_a["reference_sums_missed"] == 0
+    for i in range(n_src):
+        assert a[i][0] == b[i][0] and np.array_equal(a[i][2], b[i][2])
+        m = ~np.isnan(b[i][1])
+        assert np.array_equal(m, ~np.isnan(a[i][1]))
+        # (cut-short sums may stop at different places: whole sums are equal, the others lie on the same side)
+        whole = m & (b[i][1] < thr)
+        assert np.array_equal(a[i][1][whole], b[i][1][whole]) and np.all(a[i][1][m & ~whole] >= thr)

@@ -517,6 +517,7 @@ class GridT : public GridBase {
         if (const char* e = std::getenv("TTCR_FSM_SKIP")) skip = std::atoi(e);
         if (const char* e = std::getenv("TTCR_FSM_SKIP_UNITS")) skip_units_min = std::atoi(e);   // tuning only
         if (const char* e = std::getenv("TTCR_FSM_SKIP_PROBE_UNITS")) skip_probe_min = std::atoi(e);   // tuning only
+        if (const char* e = std::getenv("TTCR_FSM_RS_FIELDS")) rs_fields_max = (size_t)std::max(0, std::atoi(e));   // tests: batches of the stopping rule's sums (0: strided fields)
         if (const char* e = std::getenv("TTCR_FSM_WGS")) persist_wgs = std::atoi(e);              // tuning only
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS")) xs_lds_bytes = (size_t)std::atol(e);
         if (const char* e = std::getenv("TTCR_FSM_XS_LDS_BELOW")) xs_lds_below = std::atoi(e);
@@ -1307,6 +1308,7 @@ class GridT : public GridBase {
     DevBuf<RefSumState> d_rs_state;
     DevBuf<RefSum4<T>> d_rs_tiles;
     DevBuf<T> d_rc_a, d_rc_b;
+    size_t rs_fields_max = 16;               // fields of one batch of decide_go_on (0: no room for the compact arrays on this device)
     DevBuf<T> d_rs_x, d_rs_xc;               // [asked field][n_nodes, padded] terms of the sums of one decision; the non-zero ones, in order
     DevBuf<unsigned> d_rs_cnt;               // [asked field][block of FSM_REFSUM_CB nodes] non-zero terms
     DevBuf<unsigned long long> d_rs_off, d_rs_n, d_rs_n2;   // ... exclusive scan of them; [asked field] number of terms
@@ -1448,14 +1450,40 @@ class GridT : public GridBase {
             const size_t pitch = (n_nodes + FSM_REFSUM_CB - 1) / FSM_REFSUM_CB * FSM_REFSUM_CB;
             const unsigned nblk = (unsigned)(pitch / FSM_REFSUM_CB);
             for (size_t a0 = 0; a0 < ask.size();) {
-                size_t a1 = a0;
-                while (a1 < ask.size() && (a1 - a0 < 15 || (a1 > a0 && active[ask[a1]] / NS == active[ask[a1 - 1]] / NS))) ++a1;
-                const size_t nf = a1 - a0;
-                d_rs_x.reserve(nf * pitch);
-                d_rs_xc.reserve(nf * pitch);
-                d_rs_cnt.reserve(nf * (size_t)nblk);
-                d_rs_off.reserve(nf * (size_t)nblk);
-                d_rs_n.reserve(std::max<size_t>(nf, 64));
+                // (two arrays of n_nodes values per field of a batch: where the device has no room for 16 fields the batches get smaller,
+                // and a grid that has none for a pair goes by the strided fields and whole-field snapshots, as in round 5)
+                size_t a1 = a0, nf = 0;
+                bool room = false;
+                while (rs_fields_max >= 2) {
+                    a1 = a0;
+                    while (a1 < ask.size() && (a1 - a0 + 1 < rs_fields_max || (a1 > a0 && active[ask[a1]] / NS == active[ask[a1 - 1]] / NS))) ++a1;
+                    nf = a1 - a0;
+                    try {
+                        d_rs_x.reserve(nf * pitch);
+                        d_rs_xc.reserve(nf * pitch);
+                        d_rs_cnt.reserve(nf * (size_t)nblk);
+                        d_rs_off.reserve(nf * (size_t)nblk);
+                        d_rs_n.reserve(std::max<size_t>(nf, 64));
+                        room = true;
+                        break;
+                    } catch (const DeviceError&) {
+                        (void)hipGetLastError();
+                        d_rs_x.release();
+                        d_rs_xc.release();
+                        rs_fields_max = rs_fields_max > 2 ? std::max<size_t>(2, rs_fields_max / 2) : 0;
+                    }
+                }
+                if (!room) {
+                    std::vector<const T*> curs(ask.size() - a0), olds(ask.size() - a0);
+                    for (size_t a = a0; a < ask.size(); ++a) {
+                        const int s2 = active[ask[a]], gi = s2 / NS;
+                        curs[a - a0] = d_tt.p + (size_t)gi * n_nodes * NS + s2 % NS;
+                        olds[a - a0] = snap[gi].p + s2 % NS;
+                    }
+                    const std::vector<T> r = reference_changes(curs, olds, NS, false, epsilon);
+                    for (size_t a = a0; a < ask.size(); ++a) { res[a] = r[a - a0]; res_known[a] = 1; }
+                    break;
+                }
                 std::vector<const T*> curs(nf), olds(nf, nullptr);
                 for (size_t a = a0; a < a1; ++a) {
                     curs[a - a0] = d_rs_xc.p + (a - a0) * pitch;
